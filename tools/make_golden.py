@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""
+Generate tests/golden/ by running the REAL reference (py-graph-imputation @ /root/reference)
+in this build container.  The reference never travels: only its inputs/outputs (data) are
+committed.  Re-run with:  python tools/make_golden.py
+
+Recipe: scratch-copy grim/ + graph_generation/, build the one Cython
+module, then for every scenario run produce_hpf -> graph_freqs -> impute exactly as a user
+would, from a per-graph work directory.
+"""
+
+import contextlib
+import hashlib
+import io
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+import synth  # noqa: E402
+
+REF = "/root/reference"
+SCRATCH = "/tmp/grim_ref_scratch"
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def prepare_reference():
+    if not os.path.isdir(os.path.join(SCRATCH, "grim")):
+        os.makedirs(SCRATCH, exist_ok=True)
+        for d in ("grim", "graph_generation"):
+            shutil.copytree(os.path.join(REF, d), os.path.join(SCRATCH, d))
+        subprocess.check_call(["chmod", "-R", "u+w", SCRATCH])
+    so = [f for f in os.listdir(os.path.join(SCRATCH, "grim", "imputation")) if f.startswith("cutils.") and f.endswith(".so")]
+    if not so:
+        with open(os.path.join(SCRATCH, "setup_cutils.py"), "w") as fh:
+            fh.write(
+                "from setuptools import setup, Extension\n"
+                "from Cython.Build import cythonize\n"
+                "setup(ext_modules=cythonize([Extension('grim.imputation.cutils',"
+                " ['grim/imputation/cutils.pyx'])], language_level='3'))\n"
+            )
+        subprocess.check_call([sys.executable, "setup_cutils.py", "build_ext", "--inplace"], cwd=SCRATCH,
+                              stdout=subprocess.DEVNULL)
+    sys.path.insert(0, SCRATCH)
+
+
+BASE_CONF = {
+    "populations": ["CAU"],
+    "freq_trim_threshold": 1e-5,
+    "priority": {"alpha": 0.4999999, "eta": 0, "beta": 1e-7, "gamma": 1e-7, "delta": 0.4999999},
+    "UNK_priors": "SR",
+    "FULL_LOCI": "ABCQR",
+    "loci_map": {"A": 1, "B": 2, "C": 3, "DQB1": 4, "DRB1": 5},
+    "factor_missing_data": 0.0001,
+    "Plan_B_Matrix": [
+        [[1, 2, 3, 4, 5]],
+        [[1, 2, 3], [4, 5]],
+        [[1], [2, 3], [4, 5]],
+        [[1, 2, 3], [4], [5]],
+        [[1], [2, 3], [4], [5]],
+        [[1], [2], [3], [4], [5]],
+    ],
+    "planb": True,
+    "number_of_options_threshold": 100000,
+    "epsilon": 1e-3,
+    "number_of_results": 10,
+    "number_of_pop_results": 100,
+    "output_MUUG": True,
+    "output_haplotypes": True,
+    "freq_data_dir": "data/freqs",
+    "freq_file": "output/hpf.csv",
+    "graph_files_path": "output/csv/",
+    "node_csv_file": "nodes.csv",
+    "edges_csv_file": "edges.csv",
+    "info_node_csv_file": "info_node.csv",
+    "top_links_csv_file": "top_links.csv",
+    "imputation_in_file": "data/subjects/input.csv",
+    "imputation_out_umug_freq_filename": "don.umug",
+    "imputation_out_umug_pops_filename": "don.umug.pops",
+    "imputation_out_hap_freq_filename": "don.pmug",
+    "imputation_out_hap_pops_filename": "don.pmug.pops",
+    "imputation_out_miss_filename": "don.miss",
+    "imputation_out_problem_filename": "don.problem",
+    "max_haplotypes_number_in_phase": 100,
+    "imputation_out_path": "output",
+    "pops_count_file": "output/pop_counts_file.txt",
+}
+
+POP4 = ["CAU", "AFA", "HIS", "API"]
+
+
+def md5(path, sort_lines=False):
+    with open(path, "rb") as fh:
+        data = fh.read()
+    if sort_lines:
+        lines = data.split(b"\n")
+        data = b"\n".join([lines[0]] + sorted(lines[1:]))
+    return hashlib.md5(data).hexdigest()
+
+
+def build_graph(name, pops):
+    """Run the reference's produce_hpf + graph_freqs in SCRATCH/work/<name>."""
+    from graph_generation.generate_hpf import produce_hpf
+    from grim import grim
+
+    work = os.path.join(SCRATCH, "work", name)
+    os.makedirs(os.path.join(work, "data", "freqs"), exist_ok=True)
+    os.makedirs(os.path.join(work, "data", "subjects"), exist_ok=True)
+    for p in pops:
+        shutil.copy(os.path.join(GOLD, "data", "freqs", p + ".freqs.gz"), os.path.join(work, "data", "freqs"))
+    conf = dict(BASE_CONF, populations=list(pops))
+    with open(os.path.join(work, "graph_conf.json"), "w") as fh:
+        json.dump(conf, fh, indent=1)
+    cwd = os.getcwd()
+    os.chdir(work)
+    try:
+        sys.argv = ["x"]
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            produce_hpf("graph_conf.json")
+            grim.graph_freqs("graph_conf.json")
+    finally:
+        os.chdir(cwd)
+    gdir = os.path.join(GOLD, "graphs", name)
+    os.makedirs(gdir, exist_ok=True)
+    csvd = os.path.join(work, "output", "csv")
+    info = {
+        "populations": list(pops),
+        "md5": {
+            "hpf.csv": md5(os.path.join(work, "output", "hpf.csv")),
+            "pop_counts_file.txt": md5(os.path.join(work, "output", "pop_counts_file.txt")),
+            "nodes.csv": md5(os.path.join(csvd, "nodes.csv")),
+            "edges.csv": md5(os.path.join(csvd, "edges.csv")),
+            "top_links.csv(sorted rows)": md5(os.path.join(csvd, "top_links.csv"), sort_lines=True),
+            "info_node.csv": md5(os.path.join(csvd, "info_node.csv")),
+        },
+        "rows": {f: sum(1 for _ in open(os.path.join(csvd, f))) - 1 for f in ("nodes.csv", "edges.csv", "top_links.csv")},
+    }
+    with open(os.path.join(gdir, "graph_info.json"), "w") as fh:
+        json.dump(info, fh, indent=1)
+    shutil.copy(os.path.join(work, "output", "pop_counts_file.txt"), gdir)
+    return work
+
+
+def run_scenario(name, work, pops, lines, overrides=None, hap_pop_pair=False):
+    from grim import grim
+
+    conf = dict(BASE_CONF, populations=list(pops))
+    conf.update(overrides or {})
+    with open(os.path.join(work, "data", "subjects", "input.csv"), "w") as fh:
+        fh.write("\n".join(lines) + "\n")
+    with open(os.path.join(work, "conf.json"), "w") as fh:
+        json.dump(conf, fh, indent=1)
+    for f in ("don.umug", "don.umug.pops", "don.pmug", "don.pmug.pops", "don.miss", "don.problem"):
+        p = os.path.join(work, "output", f)
+        if os.path.exists(p):
+            os.remove(p)
+    cwd = os.getcwd()
+    os.chdir(work)
+    buf = io.StringIO()
+    try:
+        with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()):
+            grim.impute("conf.json", hap_pop_pair=hap_pop_pair)
+    finally:
+        os.chdir(cwd)
+    out = os.path.join(GOLD, name)
+    os.makedirs(out, exist_ok=True)
+    shutil.copy(os.path.join(work, "conf.json"), os.path.join(out, "conf.json"))
+    shutil.copy(os.path.join(work, "data", "subjects", "input.csv"), os.path.join(out, "input.csv"))
+    for f in ("don.umug", "don.umug.pops", "don.pmug", "don.pmug.pops", "don.miss", "don.problem"):
+        p = os.path.join(work, "output", f)
+        if os.path.exists(p):
+            shutil.copy(p, os.path.join(out, f))
+    log = [l for l in buf.getvalue().splitlines() if "Subject:" in l or l.startswith("in reduce")]
+    with open(os.path.join(out, "log.txt"), "w") as fh:
+        fh.write("\n".join(log) + "\n")
+    meta = {"graph": os.path.basename(work), "hap_pop_pair": hap_pop_pair, "n_subjects": len(lines)}
+    with open(os.path.join(out, "meta.json"), "w") as fh:
+        json.dump(meta, fh)
+    print("scenario %-18s %5d subjects  umug=%d rows" % (
+        name, len(lines), sum(1 for _ in open(os.path.join(out, "don.umug"))) if os.path.exists(os.path.join(out, "don.umug")) else -1))
+
+
+def main():
+    os.environ.setdefault("PYTHONHASHSEED", "0")
+    prepare_reference()
+    # ---- data files -----------------------------------------------------------------
+    fdir = os.path.join(GOLD, "data", "freqs")
+    os.makedirs(fdir, exist_ok=True)
+    os.makedirs(os.path.join(GOLD, "data", "subjects"), exist_ok=True)
+    shutil.copy(os.path.join(REF, "data", "freqs", "CAU.freqs.gz"), fdir)
+    shutil.copy(os.path.join(REF, "data", "subjects", "donor.csv"), os.path.join(GOLD, "data", "subjects"))
+    import numpy as np
+
+    cau = synth.read_freqs(os.path.join(fdir, "CAU.freqs.gz"))
+    rng = np.random.default_rng(1)
+    pop_rows = {"CAU": cau}
+    for p in POP4[1:]:
+        pop_rows[p] = synth.synth_population(cau, rng)
+        synth.write_freqs(os.path.join(fdir, p + ".freqs.gz"), pop_rows[p])
+
+    w1 = build_graph("cau", ["CAU"])
+    w4 = build_graph("pop4", POP4)
+
+    donor = [l.rstrip("\n") for l in open(os.path.join(REF, "data", "subjects", "donor.csv"))]
+    run_scenario("cau_min", w1, ["CAU"], donor)
+    run_scenario("cau_full", w1, ["CAU"], synth.SubjectGen(cau, 0).full(300))
+    run_scenario("cau_mixed", w1, ["CAU"], synth.SubjectGen(cau, 2).mixed(250))
+    run_scenario("cau_amb_only", w1, ["CAU"], synth.SubjectGen(cau, 5).mixed(150, amb=0.5, miss=0.0, recomb=0.0))
+    run_scenario("cau_edge", w1, ["CAU"], synth.edge_cases("CAU"))
+    run_scenario("cau_mr_res1000", w1, ["CAU"], synth.SubjectGen(cau, 7).mixed(60),
+                 {"UNK_priors": "MR", "number_of_results": 1000, "number_of_pop_results": 3})
+    run_scenario("cau_noplanb", w1, ["CAU"], synth.SubjectGen(cau, 8).mixed(80), {"planb": False})
+    run_scenario("cau_muug_only", w1, ["CAU"], synth.SubjectGen(cau, 9).mixed(60), {"output_haplotypes": False})
+    run_scenario("cau_haps_only", w1, ["CAU"], synth.SubjectGen(cau, 10).mixed(60), {"output_MUUG": False})
+    run_scenario("cau_filter", w1, ["CAU"], synth.SubjectGen(cau, 11).high_ambiguity(12, width=6),
+                 {"number_of_options_threshold": 1000})
+    run_scenario("cau_top5", w1, ["CAU"], synth.SubjectGen(cau, 12).mixed(60, amb=0.4, miss=0.3),
+                 {"max_haplotypes_number_in_phase": 5})
+    run_scenario("cau_em_mr", w1, ["CAU"], synth.SubjectGen(cau, 13).mixed(40), hap_pop_pair=True)
+
+    g4 = synth.SubjectGen(cau, 3, pops=POP4)
+    # mix subjects drawn from all four tables
+    run_scenario("pop4_mixed", w4, POP4, g4.mixed(300), {"UNK_priors": "MR"})
+    run_scenario("pop4_full", w4, POP4, synth.SubjectGen(pop_rows["AFA"], 4, pops=POP4).mixed(150, amb=0.0, miss=0.0, recomb=0.0),
+                 {"UNK_priors": "MR"})
+    run_scenario("pop4_sr", w4, POP4, synth.SubjectGen(pop_rows["HIS"], 6, pops=POP4).mixed(120), {"UNK_priors": "SR"})
+    run_scenario("pop4_edge", w4, POP4, synth.edge_cases("AFA") + synth.edge_cases("UNK"), {"UNK_priors": "MR"})
+    run_scenario("pop4_em_mr", w4, POP4, synth.SubjectGen(cau, 14, pops=POP4).mixed(40), {"UNK_priors": "MR"},
+                 hap_pop_pair=True)
+
+
+if __name__ == "__main__":
+    main()

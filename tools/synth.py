@@ -1,0 +1,191 @@
+"""
+Seeded synthetic inputs for the grim.impute hot path.
+
+Used by tools/make_golden.py (fixture generation against the real reference),
+by tests/ and by bench.py.  Pure numpy; no dependency on the reference or on
+the product package.
+"""
+
+from __future__ import annotations
+
+import gzip
+import os
+
+import numpy as np
+
+LOCI = ["A", "B", "C", "DQB1", "DRB1"]
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CAU_FREQS = os.path.join(ROOT, "tests", "golden", "data", "freqs", "CAU.freqs.gz")
+
+
+def read_freqs(path):
+    """-> list of (haplotype string, count string, freq float) in file order."""
+    rows = []
+    with gzip.open(path, "rt") as fh:
+        for line in fh:
+            line = line.strip()
+            if not line:
+                continue
+            hap, cnt, fr = line.split(",")
+            if hap == "Haplo":
+                continue
+            rows.append((hap, cnt, float(fr)))
+    return rows
+
+
+def hap_alleles(hap):
+    """'A*01:01g~C*..~B*..' -> dict locus -> allele (trailing g stripped)."""
+    out = {}
+    for a in hap.split("~"):
+        if a.endswith("g"):
+            a = a[:-1]
+        out[a.split("*")[0]] = a
+    return out
+
+
+def synth_population(rows, rng, drop=0.35):
+    """copy rows, drop each w.p. `drop`, scale freq by exp(N(0,1)),
+    6 significant digits.  Draw order per row: uniform then normal."""
+    out = []
+    for hap, cnt, fr in rows:
+        u = rng.random()
+        z = rng.normal()
+        if u < drop:
+            continue
+        out.append((hap, cnt, float("%.6g" % (fr * float(np.exp(z))))))
+    return out
+
+
+def write_freqs(path, rows):
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with gzip.open(path, "wt") as fh:
+        for hap, cnt, fr in rows:
+            fh.write("%s,%s,%r\n" % (hap, cnt, fr))
+
+
+class SubjectGen:
+    """Draws subjects from a haplotype frequency table."""
+
+    def __init__(self, rows, seed, pops=("CAU",)):
+        self.rng = np.random.default_rng(seed)
+        self.haps = [hap_alleles(h) for h, _, _ in rows]
+        f = np.array([r[2] for r in rows], dtype=np.float64)
+        self.p = f / f.sum()
+        self.pops = list(pops)
+        self.by_locus = {l: sorted({h[l] for h in self.haps}) for l in LOCI}
+
+    def draw_hap(self):
+        return self.haps[int(self.rng.choice(len(self.haps), p=self.p))]
+
+    def _side(self, allele, locus, amb):
+        if amb > 0 and self.rng.random() < amb:
+            k = int(self.rng.integers(1, 4))
+            pool = [a for a in self.by_locus[locus] if a != allele]
+            extra = list(self.rng.choice(pool, size=min(k, len(pool)), replace=False))
+            return "/".join(sorted([allele] + [str(e) for e in extra]))
+        return allele
+
+    def gl(self, h1, h2, amb=0.0, miss=0.0):
+        parts = []
+        for l in LOCI:
+            if miss > 0 and self.rng.random() < miss:
+                continue
+            parts.append(self._side(h1[l], l, amb) + "+" + self._side(h2[l], l, amb))
+        if not parts:  # keep at least one locus
+            l = LOCI[int(self.rng.integers(0, 5))]
+            parts.append(h1[l] + "+" + h2[l])
+        return "^".join(parts)
+
+    def races(self):
+        if len(self.pops) == 1:
+            return self.pops[0], self.pops[0]
+        u = self.rng.random()
+        pick = lambda: self.pops[int(self.rng.integers(0, len(self.pops)))]
+        if u < 0.5:
+            return pick(), pick()
+        if u < 0.7:
+            return (pick(), "UNK") if self.rng.random() < 0.5 else ("UNK", pick())
+        if u < 0.8:
+            return "UNK", "UNK"
+        return pick() + ";" + pick(), pick() + ";" + pick()
+
+    def recombinant(self):
+        a, b = self.draw_hap(), self.draw_hap()
+        h = dict(a)
+        h["DQB1"], h["DRB1"] = b["DQB1"], b["DRB1"]
+        if self.rng.random() < 0.3:
+            h["A"] = self.draw_hap()["A"]
+        return h
+
+    # ---- line generators ------------------------------------------------------
+    def full(self, n, prefix="S"):
+        """config 2/3: fully typed, unambiguous, races = first pop."""
+        out = []
+        for i in range(n):
+            h1, h2 = self.draw_hap(), self.draw_hap()
+            out.append("%s%d,%s,%s,%s" % (prefix, i, self.gl(h1, h2), self.pops[0], self.pops[0]))
+        return out
+
+    def mixed(self, n, amb=0.3, miss=0.15, recomb=0.3, prefix="M"):
+        """config 4 style: ambiguity, missing loci, recombinants, mixed race columns."""
+        out = []
+        for i in range(n):
+            if self.rng.random() < recomb:
+                h1, h2 = self.recombinant(), self.draw_hap()
+            else:
+                h1, h2 = self.draw_hap(), self.draw_hap()
+            r1, r2 = self.races()
+            out.append("%s%d,%s,%s,%s" % (prefix, i, self.gl(h1, h2, amb, miss), r1, r2))
+        return out
+
+    def high_ambiguity(self, n, width=8, prefix="H"):
+        """config 5 style: `width` alternatives per locus per side."""
+        out = []
+        for i in range(n):
+            h1, h2 = self.draw_hap(), self.draw_hap()
+            parts = []
+            for l in LOCI:
+                sides = []
+                for h in (h1, h2):
+                    pool = [a for a in self.by_locus[l] if a != h[l]]
+                    k = min(width - 1, len(pool))
+                    extra = [str(e) for e in self.rng.choice(pool, size=k, replace=False)]
+                    sides.append("/".join(sorted([h[l]] + extra)))
+                parts.append("+".join(sides))
+            out.append("%s%d,%s,%s,%s" % (prefix, i, "^".join(parts), self.pops[0], self.pops[0]))
+        return out
+
+
+def edge_cases(pop="CAU"):
+    """Hand-written edge cases (SURVEY appendix A.6 + a few more)."""
+    return [
+        # allele absent from the graph at one locus
+        "E0,A*99:99+A*02:01^B*15:01+B*07:02^C*03:03+C*07:02^DQB1*03:02+DQB1*06:02^DRB1*04:01+DRB1*15:01,%s,%s" % (pop, pop),
+        # single allele locus (no '+') -> .problem idx,id
+        "E1,A*01:01^B*08:01+B*07:02,%s,%s" % (pop, pop),
+        # UUUU locus is dropped by clean_up_gl
+        "E2,A*01:01+A*02:01^B*UUUU+B*UUUU^C*07:01+C*07:02,%s,%s" % (pop, pop),
+        # homozygous everywhere
+        "E3,A*01:01+A*01:01^B*08:01+B*08:01^C*07:01+C*07:01^DQB1*02:01+DQB1*02:01^DRB1*03:01+DRB1*03:01,%s,%s" % (pop, pop),
+        # no race columns
+        "E4,A*01:01+A*02:01^B*08:01+B*07:02^C*07:01+C*07:02^DQB1*02:01+DQB1*06:02^DRB1*03:01+DRB1*15:01",
+        # '%' separated record
+        "E5%A*01:01+A*02:01^B*08:01+B*44:02",
+        # unknown race names
+        "E6,A*01:01+A*03:01^B*08:01+B*07:02^C*07:01+C*07:02^DQB1*02:01+DQB1*06:02^DRB1*03:01+DRB1*15:01,XXX,YYY",
+        # only three fields -> exception -> raw line in .problem
+        "E7,A*01:01+A*02:01^B*08:01+B*07:02,%s" % pop,
+        # empty GL -> .problem idx,id
+        "E8,,%s,%s" % (pop, pop),
+        # every locus unknown to the graph
+        "E9,A*98:01+A*98:02^B*98:01+B*98:02,%s,%s" % (pop, pop),
+        # duplicated alternative inside an ambiguity list
+        "E10,A*01:01/A*01:01/A*02:01+A*02:01^B*08:01+B*07:02^C*07:01+C*07:02,%s,%s" % (pop, pop),
+        # 'g' suffixes and an 'L' suffix (both deleted anywhere in the string)
+        "E11,A*01:01g+A*02:01g^B*08:01g+B*07:02^C*07:01L+C*07:02,%s,%s" % (pop, pop),
+        # one locus only
+        "E12,DRB1*15:01+DRB1*03:01,%s,%s" % (pop, pop),
+        # the reference's sample subject
+        "D1,A*01:02+A*02:01/A*03:01^B*15:01+B*15:01,%s,%s" % (pop, pop),
+    ]
