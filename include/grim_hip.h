@@ -1,0 +1,171 @@
+/*
+ * grim_hip.h -- C-ABI of libgrim_hip.so, the MI355X (gfx950) engine for the grim.impute hot path.
+ *
+ * The reference (nmdp-bioinformatics/py-graph-imputation) has no FFI for this path -- its only
+ * native code is a 65-line Cython list helper (grim/imputation/cutils.pyx) -- so this ABI is the
+ * build's own.  Each entry point names the reference interface it replaces (file:line under the
+ * reference tree).  Plain pointers and sizes only; the library copies what it is given, owns
+ * what it returns, and never calls back into the host language.
+ *
+ * Threading: one grim_ctx per GPU, used by one host thread at a time.  Independent contexts
+ * are independent.
+ * Errors: functions return 0 on success, <0 on error (grim_last_error gives the text);
+ * constructors return NULL on error.  Per-subject outcomes (miss / needs-fallback) are DATA in
+ * grim_subject_result.status, never a call failure.
+ */
+#ifndef GRIM_HIP_H
+#define GRIM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GRIM_MAXL 5        /* loci per haplotype (A,B,C,DQB1,DRB1)                         */
+#define GRIM_ABITS 12      /* bits per locus in a 64-bit haplotype key: (allele_id+1)<<12*slot */
+#define GRIM_MAXPH 16      /* 2^(GRIM_MAXL-1) phases (impute.py:274-303)                     */
+#define GRIM_MAXPOP 64     /* populations                                                    */
+#define GRIM_TOPCAP 128    /* upper bound for max_haplotypes_number_in_phase (impute.py:436) */
+#define GRIM_MAXLADDER 64  /* epsilon ladder entries (impute.py:1665-1687)                   */
+#define GRIM_MAXROWS 8     /* Plan_B_Matrix rows                                             */
+
+typedef struct grim_ctx grim_ctx;
+typedef struct grim_graph grim_graph;
+typedef struct grim_batch grim_batch;
+
+/* ---- context ---------------------------------------------------------------------------- */
+grim_ctx *grim_create(int device_id);
+void grim_destroy(grim_ctx *ctx);
+const char *grim_last_error(grim_ctx *ctx);
+/* 1 if a HIP device is usable by this process, 0 otherwise (never raises). */
+int grim_device_count(void);
+
+/* ---- graph: replaces Graph.build_graph's in-memory product (networkx_graph.py:42-213) ----
+ * Integer-encoded: node = (label bitmask over locus slots, <=5 allele ids); a node NAME lookup
+ * (Vertices_attributes[name], networkx_graph.py:260,290) becomes a 64-bit key probe.
+ * a_start/a_nbr : plan-A CSR partial node -> full nodes, INCLUDING the reference's row-start
+ *                 quirks (networkx_graph.py:157-198); a_start has n_nodes+1 entries.
+ * b_conn        : [n_nodes][GRIM_MAXL] connector index of (child node, added locus slot), or
+ *                 0xFFFFFFFF (the "parentLabel+childName" pseudo nodes, networkx_graph.py:103-130)
+ * b_start/b_nbr : connector -> parent nodes CSR (n_conn+1 entries, quirks included).
+ * lab_start/lab_nodes : node ids grouped by label mask in id order (haps_by_label,
+ *                 networkx_graph.py:215-236); lab_start has (1<<GRIM_MAXL)+1 entries. */
+typedef struct {
+  uint32_t n_nodes, n_pops, n_loci, full_mask;
+  const uint64_t *node_key;  /* [n_nodes] */
+  const uint8_t *node_mask;  /* [n_nodes] */
+  const double *freq;        /* [n_nodes][n_pops] */
+  const uint32_t *a_start;   /* [n_nodes+1] */
+  const uint32_t *a_nbr;     /* [n_a_nbr] */
+  uint64_t n_a_nbr;
+  const uint32_t *b_conn;    /* [n_nodes*GRIM_MAXL] */
+  const uint32_t *b_start;   /* [n_conn+1] */
+  const uint32_t *b_nbr;     /* [n_b_nbr] */
+  uint32_t n_conn;
+  uint64_t n_b_nbr;
+  const uint32_t *lab_start; /* [(1<<GRIM_MAXL)+1] */
+  const uint32_t *lab_nodes; /* [n_nodes] */
+} grim_graph_desc;
+
+grim_graph *grim_graph_upload(grim_ctx *ctx, const grim_graph_desc *desc);
+void grim_graph_free(grim_graph *g);
+uint64_t grim_graph_device_bytes(const grim_graph *g);
+
+/* ---- run parameters: the conf keys of run_impute_def.py:63-129 that reach the hot path ------ */
+typedef struct {
+  double ladder[GRIM_MAXLADDER]; /* eps values tried in order (impute.py:1665-1673), host-computed */
+  int32_t n_ladder;
+  uint32_t top_n;          /* max_haplotypes_number_in_phase */
+  uint64_t opt_threshold;  /* number_of_options_threshold    */
+  uint32_t n_results;      /* number_of_results              */
+  uint32_t n_pop_results;  /* number_of_pop_results          */
+  uint8_t out_muug, out_haps, planb, em_mr;
+  uint8_t pop_rank[GRIM_MAXPOP]; /* rank of each population NAME in sorted order (impute.py:535) */
+  double factor_missing;   /* factor_missing_data */
+  /* Plan_B_Matrix: row r has planb_nblk[r] blocks; block b is a locus-slot bitmask */
+  uint8_t planb_rows;
+  uint8_t planb_nblk[GRIM_MAXROWS];
+  uint8_t planb_blk[GRIM_MAXROWS][GRIM_MAXL];
+} grim_params;
+
+/* ---- subjects: the tokenised form of one input line (impute.py:2022-2036, 105-118, 246-272) --
+ * Position k (0..n_loci-1) is the k-th locus in the subject's sorted order; slot[k] is its locus
+ * slot.  tokens[tok_off ...] holds, for k = 0.., side 0 then side 1, cnt[k][side] allele ids
+ * (first occurrences only; wid[k][side] keeps the original '/'-list length that the
+ * number_of_options_threshold test uses, impute.py:926-932). */
+typedef struct {
+  uint32_t tok_off;
+  uint16_t prior_idx; /* index into the batch's prior matrices (impute.py:1956-1975) */
+  uint8_t n_loci;
+  uint8_t flags;
+  uint8_t slot[GRIM_MAXL];
+  uint8_t pad[3];
+  uint16_t cnt[GRIM_MAXL][2];
+  uint16_t wid[GRIM_MAXL][2];
+  uint32_t reserved[2];
+} grim_subject; /* 64 bytes */
+
+typedef struct {
+  uint32_t n_subjects;
+  const grim_subject *subjects;
+  const uint16_t *tokens;
+  uint64_t n_tokens;
+  const double *priors; /* [n_priors][n_pops][n_pops] */
+  uint32_t n_priors;
+} grim_batch_desc;
+
+/* status values */
+enum {
+  GRIM_ST_OK = 0,         /* results present                                                    */
+  GRIM_ST_MISS = 1,       /* nothing found on any plan  (-> .miss, impute.py:2065-2068)          */
+  GRIM_ST_UNSUPPORTED = 2 /* needs a reference path this build does not run on device yet       */
+};
+
+/* one output row: a/b are 64-bit haplotype keys (genotype and haplotype-pair tables) or
+ * population indices (population tables); popa/popb are set for pair rows. */
+typedef struct {
+  uint64_t a, b;
+  double prob;
+  uint32_t popa, popb;
+} grim_row; /* 32 bytes */
+
+/* table ids inside grim_subject_result */
+enum { GRIM_T_UMUG = 0, GRIM_T_UMUG_POPS = 1, GRIM_T_PMUG = 2, GRIM_T_PMUG_POPS = 3, GRIM_T_COUNT = 4 };
+
+typedef struct {
+  uint8_t status;
+  uint8_t plan;           /* 'a', 'b' or 'c' as in impute.py:216,1638,1702 */
+  uint8_t reason;         /* for GRIM_ST_UNSUPPORTED */
+  uint8_t pad;
+  uint32_t n_pairs;       /* len(res_haps["Haps"])  (impute.py:2074-2078) */
+  uint32_t n_genotypes;   /* len(res_muugs["Haps"]) (impute.py:2108-2112) */
+  uint32_t row_off[GRIM_T_COUNT];
+  uint32_t n_rows[GRIM_T_COUNT];
+  double max_prob;
+} grim_subject_result; /* 56 bytes */
+
+/* grim_batch_upload copies subjects/tokens/priors to HBM and allocates result + scratch buffers.
+ * grim_batch_run enqueues the kernels on the context's stream and waits; it may be called
+ * repeatedly on the same resident batch (bench.py does).  Replaces the per-subject loop
+ * impute_file -> impute_one -> comp_cand -> call_comp_phase_prob (impute.py:2019-2059,
+ * 1584-1724) for every subject of the batch at once. */
+grim_batch *grim_batch_upload(grim_ctx *ctx, const grim_graph *g, const grim_params *p,
+                              const grim_batch_desc *d);
+int grim_batch_run(grim_batch *b);
+/* device time of the last grim_batch_run, from hipEvents on the launch stream:
+ * which = 0 total, 1 plan-A kernel, 2 plan-B/C kernel */
+double grim_batch_kernel_ms(const grim_batch *b, int which);
+/* algorithmic byte counters of the last run: [0] probes, [1] CSR neighbour ids,
+ * [2] frequency vectors gathered, [3] output rows */
+int grim_batch_counters(const grim_batch *b, uint64_t out[4]);
+uint32_t grim_batch_total_rows(const grim_batch *b);
+/* copy results to host: res[n_subjects], rows[grim_batch_total_rows] */
+int grim_batch_results(grim_batch *b, grim_subject_result *res, grim_row *rows);
+void grim_batch_free(grim_batch *b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

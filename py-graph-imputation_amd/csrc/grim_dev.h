@@ -1,0 +1,324 @@
+// grim_dev.h -- device-side primitives shared by the plan-A and plan-B/C kernels (gfx950, wave64).
+//
+// Everything here is integer indexing + fp64 scalar arithmetic: no MFMA.  fp64 products are
+// written exactly as the reference writes them and the file is compiled with -ffp-contract=off,
+// so every probability is bit-identical to CPython's IEEE double arithmetic.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/grim_hip.h"
+
+#define GRIM_WG 256
+#define GRIM_NWAVE 4
+#define GRIM_NONE 0xFFFFFFFFu
+#define GRIM_VALID 0x8000000000000000ull
+#define GRIM_SIDES (2 * GRIM_MAXPH)
+
+// ---- graph as the kernels see it --------------------------------------------------------------
+struct DevGraph {
+  const uint64_t *node_key;
+  const uint8_t *node_mask;
+  const double *freq;
+  const uint32_t *a_start, *a_nbr;
+  const uint32_t *b_conn, *b_start, *b_nbr;
+  const uint32_t *lab_start, *lab_nodes;
+  const uint64_t *ht_key;
+  const uint32_t *ht_val;
+  uint32_t n_nodes, P, full_mask, ht_mask, n_conn, n_loci;
+};
+
+// ---- per-workgroup scratch slot in HBM (offsets in bytes, filled by the host) -------------------
+struct SlotLayout {
+  uint64_t Tp, Tm, Te;                 // top lists: prob, prefix-min prob, entity   [GRIM_SIDES][GRIM_TOPCAP]
+  uint64_t k0, k1, tmin, tgid;         // hash table columns [tab_cap]
+  uint64_t Useq, Uprob, Uslot;         // accepted unique pairs [pair_cap]
+  uint64_t ska, skb, sva, svb;         // radix ping-pong [pair_cap]
+  uint64_t gsum, ghead, gstart, gcnt;  // groups [pair_cap(+1)]
+  uint64_t qsum, qfirst;               // population-pair cells [P*P]
+  uint64_t bset;                       // plan-B block sets (node ids) [GRIM_NWAVE][GRIM_MAXL][bset_cap]
+  uint64_t comp;                       // plan-B composite haplotype keys [GRIM_SIDES*GRIM_TOPCAP]
+  uint64_t stride;                     // bytes per slot
+};
+
+struct DevArgs {
+  DevGraph g;
+  grim_params prm;
+  const grim_subject *subj;
+  const uint16_t *tok;
+  const double *priors;
+  const uint32_t *order;  // subject indices this launch works on
+  uint32_t n_work;
+  uint32_t *queue;        // dynamic work counter
+  grim_subject_result *res;
+  grim_row *rows;
+  uint32_t *row_head;
+  uint32_t row_cap;
+  uint8_t *scratch;
+  SlotLayout lay;
+  uint32_t pair_cap, tab_cap, bset_cap;
+  unsigned long long *counters;  // [0] probes [1] nbr ids [2] freq vectors [3] rows [4] overflow flag
+  uint32_t *next_list;           // subjects handed to the next kernel (plan B)
+  uint32_t *next_count;
+};
+
+// ---- small helpers ------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+  x ^= x >> 33;
+  x *= 0xff51afd7ed558ccdULL;
+  x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ULL;
+  x ^= x >> 33;
+  return x;
+}
+
+// order-preserving map double -> uint64 (bigger double <=> bigger integer)
+__device__ __forceinline__ uint64_t f64_ord(double x) {
+  uint64_t b = (uint64_t)__double_as_longlong(x);
+  return (b & GRIM_VALID) ? ~b : (b | GRIM_VALID);
+}
+
+#define ALOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define ASTORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+
+// LDS traffic between lanes of ONE wave: DS ops of a wave are processed in order; this only has to
+// stop the compiler from moving them.
+#define WAVE_SYNC()                                          \
+  do {                                                       \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   \
+    __builtin_amdgcn_wave_barrier();                         \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   \
+  } while (0)
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+  int lane = lane_id();
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t t = __shfl_up(v, d);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+// exclusive scan over the workgroup; `tmp` is LDS [GRIM_NWAVE]; two barriers
+__device__ __forceinline__ uint32_t wg_excl_scan(uint32_t v, uint32_t *tmp, uint32_t &total) {
+  uint32_t inc = wave_incl_scan(v);
+  if (lane_id() == 63) tmp[wave_id()] = inc;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < GRIM_NWAVE; ++w) {
+    uint32_t t = tmp[w];
+    if (w < wave_id()) base += t;
+    tot += t;
+  }
+  __syncthreads();
+  total = tot;
+  return base + inc - v;
+}
+
+// ---- exact-name lookup: 64-bit key -> node id (networkx_graph.py:260,290,315) ----------------------
+__device__ __forceinline__ uint32_t graph_lookup(const DevGraph &g, uint64_t key) {
+  uint32_t h = (uint32_t)mix64(key) & g.ht_mask;
+  for (;;) {
+    uint64_t k = g.ht_key[h];
+    if (k == key) return g.ht_val[h];
+    if (k == 0) return GRIM_NONE;
+    h = (h + 1) & g.ht_mask;
+  }
+}
+
+// plan-A neighbour range of a partial node, with the reference's sentinel quirk: the range is
+// range(start[i], start[i+1]) and is EMPTY when start[i+1] <= start[i] (networkx_graph.py:195,267-272)
+__device__ __forceinline__ uint32_t nbr_count(const uint32_t *start, uint32_t i) {
+  uint32_t a = start[i], b = start[i + 1];
+  return b > a ? b - a : 0;
+}
+
+// ---- per-slot hash table over 64- or 128-bit keys (open addressing, insert-only) -----------------
+// k0 == 0 marks an empty slot, so callers OR GRIM_VALID into k0 (and into k1 when WIDE).
+template <bool WIDE>
+__device__ __forceinline__ uint32_t tab_insert(uint64_t *k0, uint64_t *k1, uint32_t mask, uint64_t a, uint64_t b) {
+  uint32_t s = (uint32_t)mix64(a ^ (b * 0x9E3779B97F4A7C15ull)) & mask;
+  for (;;) {
+    uint64_t c0 = ALOAD(&k0[s]);
+    if (c0 == 0) {
+      uint64_t old = atomicCAS((unsigned long long *)&k0[s], 0ull, (unsigned long long)a);
+      if (old == 0) {
+        if (WIDE) ASTORE(&k1[s], b);
+        return s;
+      }
+      c0 = old;
+    }
+    if (c0 == a) {
+      if (!WIDE) return s;
+      uint64_t c1 = ALOAD(&k1[s]);
+      if (c1 == 0) continue;  // claimed a moment ago, second word not published yet: look again
+      if (c1 == b) return s;
+    }
+    s = (s + 1) & mask;
+  }
+}
+
+// ---- wave-level running top-K with stable ties (impute.py:424-442) ---------------------------------
+// Records live in LDS, one set per wave: [0,nrun) is the sorted running list, [nrun,nrun+nbuf) the
+// not yet merged newcomers.  Order: bigger sort key first, then smaller `tie` (= stream position).
+struct WaveTop {
+  uint64_t sk[256];
+  uint64_t tie[256];
+  double p[256];
+  uint32_t hap[256];
+  uint32_t cstart[66];
+  uint32_t cnode[64];
+};
+
+struct TopState {
+  int nrun, nbuf, K;
+  bool full;
+  uint64_t thr;
+};
+
+__device__ __forceinline__ void wave_sort(WaveTop &L, int N) {
+  int lane = lane_id();
+  for (int k = 2; k <= N; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int q = lane; q < (N >> 1); q += 64) {
+        int lo = ((q & ~(j - 1)) << 1) | (q & (j - 1));
+        int hi = lo + j;
+        bool up = ((lo & k) == 0);
+        uint64_t a = L.sk[lo], b = L.sk[hi], ta = L.tie[lo], tb = L.tie[hi];
+        bool b_first = (b > a) || (b == a && tb < ta);
+        bool a_first = (a > b) || (a == b && ta < tb);
+        if (up ? b_first : a_first) {
+          L.sk[lo] = b; L.sk[hi] = a;
+          L.tie[lo] = tb; L.tie[hi] = ta;
+          double pa = L.p[lo]; L.p[lo] = L.p[hi]; L.p[hi] = pa;
+          uint32_t ha = L.hap[lo]; L.hap[lo] = L.hap[hi]; L.hap[hi] = ha;
+        }
+      }
+      WAVE_SYNC();
+    }
+  }
+}
+
+__device__ __forceinline__ void top_flush(WaveTop &L, TopState &st) {
+  int lane = lane_id();
+  int total = st.nrun + st.nbuf;
+  if (st.nbuf > 0 && total > 1) {
+    int N = 2;
+    while (N < total) N <<= 1;
+    for (int r = total + lane; r < N; r += 64) {
+      L.sk[r] = 0;
+      L.tie[r] = ~0ull;
+    }
+    WAVE_SYNC();
+    wave_sort(L, N);
+  }
+  st.nrun = total < st.K ? total : st.K;
+  st.nbuf = 0;
+  WAVE_SYNC();
+  if (st.nrun == st.K) {
+    st.full = true;
+    st.thr = L.sk[st.K - 1];
+  }
+}
+
+// push one candidate entry per lane (active = this lane has one); wave-uniform control flow
+__device__ __forceinline__ void top_push(WaveTop &L, TopState &st, bool active, double p, double key, uint64_t tie,
+                                         uint32_t hap) {
+  uint64_t ord = f64_ord(key);
+  bool adm = active && (!st.full || ord > st.thr);
+  uint64_t m = __ballot(adm);
+  if (m == 0) return;
+  if (adm) {
+    int pos = st.nrun + st.nbuf + __popcll(m & ((1ull << lane_id()) - 1ull));
+    L.sk[pos] = ord;
+    L.tie[pos] = tie;
+    L.p[pos] = p;
+    L.hap[pos] = hap;
+  }
+  st.nbuf += __popcll(m);
+  WAVE_SYNC();
+  if (st.nrun + st.nbuf > 192) top_flush(L, st);
+}
+
+// ---- stable LSD radix sort (4 bits/pass) of n (key,value) records by one workgroup ------------------
+// Records sit in HBM scratch (L2 resident); each thread owns a contiguous block so that equal
+// digits keep their order.  hist: LDS [16*256]; tmp: LDS [GRIM_NWAVE+20].
+// Returns 0 if the result is in (ka,va), 1 if in (kb,vb).
+__device__ inline int wg_radix_sort(uint64_t *ka, uint32_t *va, uint64_t *kb, uint32_t *vb, uint32_t n, int nbits,
+                                    uint32_t *hist, uint32_t *tmp) {
+  const int tid = threadIdx.x;
+  int cur = 0;
+  if (n <= 1) return 0;
+  uint32_t per = (n + GRIM_WG - 1) / GRIM_WG;
+  uint32_t b0 = tid * per, b1 = b0 + per;
+  if (b0 > n) b0 = n;
+  if (b1 > n) b1 = n;
+  for (int sh = 0; sh < nbits; sh += 4) {
+    uint64_t *sk = cur ? kb : ka, *dk = cur ? ka : kb;
+    uint32_t *sv = cur ? vb : va, *dv = cur ? va : vb;
+    for (int d = 0; d < 16; ++d) hist[d * GRIM_WG + tid] = 0;
+    for (uint32_t i = b0; i < b1; ++i) hist[((sk[i] >> sh) & 15) * GRIM_WG + tid]++;
+    __syncthreads();
+    // thread t owns flattened entries [16t,16t+16): digit t/16, threads (t%16)*16..
+    uint32_t part = 0;
+    for (int e = 0; e < 16; ++e) part += hist[tid * 16 + e];
+    // a digit that holds everything makes the pass a no-op
+    uint32_t *dtot = tmp + GRIM_NWAVE;  // [16] + flag at [16]
+    if (tid < 17) dtot[tid] = 0;
+    __syncthreads();
+    atomicAdd(&dtot[tid >> 4], part);
+    __syncthreads();
+    if (tid < 16 && dtot[tid] == n) dtot[16] = 1;
+    __syncthreads();
+    bool skip = dtot[16] != 0;
+    __syncthreads();
+    if (skip) continue;
+    uint32_t total;
+    uint32_t base = wg_excl_scan(part, tmp, total);
+    for (int e = 0; e < 16; ++e) {
+      uint32_t c = hist[tid * 16 + e];
+      hist[tid * 16 + e] = base;
+      base += c;
+    }
+    __syncthreads();
+    for (uint32_t i = b0; i < b1; ++i) {
+      uint64_t k = sk[i];
+      uint32_t pos = hist[((k >> sh) & 15) * GRIM_WG + tid]++;
+      dk[pos] = k;
+      dv[pos] = sv[i];
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  return cur;
+}
+
+// exclusive scan in place over a u32 array in HBM scratch, result has n+1 entries (arr[n] = total)
+__device__ inline void wg_scan_array(uint32_t *arr, uint32_t n, uint32_t *tmp) {
+  const int tid = threadIdx.x;
+  uint32_t per = (n + GRIM_WG - 1) / GRIM_WG;
+  uint32_t b0 = tid * per, b1 = b0 + per;
+  if (b0 > n) b0 = n;
+  if (b1 > n) b1 = n;
+  uint32_t s = 0;
+  for (uint32_t i = b0; i < b1; ++i) s += arr[i];
+  uint32_t total;
+  uint32_t base = wg_excl_scan(s, tmp, total);
+  for (uint32_t i = b0; i < b1; ++i) {
+    uint32_t c = arr[i];
+    arr[i] = base;
+    base += c;
+  }
+  if (tid == 0) arr[n] = total;
+  __syncthreads();
+}
+
+__device__ __forceinline__ int bits_for(uint32_t n) {  // bits needed to hold values < n
+  int b = 1;
+  while (b < 32 && (1u << b) < n) ++b;
+  return b;
+}

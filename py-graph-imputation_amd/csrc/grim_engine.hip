@@ -1,0 +1,424 @@
+// grim_engine.hip -- libgrim_hip.so: kernels + the C-ABI of include/grim_hip.h (gfx950 only).
+//
+// Build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -shared grim_engine.hip -o libgrim_hip.so
+// (-ffp-contract=off is REQUIRED: an fma in P1*P2*prior would change the last bit and with it
+//  rankings that the reference decides on exact ties).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "grim_plan_a.h"
+#include "grim_plan_b.h"
+
+// =================================================================================================
+// Plan-A kernel: one workgroup per subject, pulled from a work counter.  Waves build the phase
+// sides (one wave per side, wave64 ballots/prefix scans, LDS-staged running top-K); the whole
+// workgroup then scores haplotype pairs, dedups, sums and ranks.
+// =================================================================================================
+__global__ __launch_bounds__(GRIM_WG) void grim_plan_a_kernel(DevArgs A) {
+  __shared__ WgShared sh;
+  __shared__ WaveTop wt[GRIM_NWAVE];
+  const int tid = threadIdx.x;
+  const int P = A.g.P;
+  Slot S = make_slot(A, blockIdx.x);
+  if (tid < GRIM_NWAVE * 4) ((unsigned long long *)sh.wctr)[tid] = 0;
+  __syncthreads();
+  for (;;) {
+    if (tid == 0) sh.bc[3] = atomicAdd(A.queue, 1u);
+    __syncthreads();
+    const uint32_t w = sh.bc[3];
+    if (w >= A.n_work) break;
+    const uint32_t si = A.order[w];
+    if (tid < 16) ((uint32_t *)&sh.subj)[tid] = ((const uint32_t *)&A.subj[si])[tid];
+    if (tid < GRIM_SIDES) {
+      sh.Tn[tid] = 0;
+      sh.cand_any[tid] = 0;
+    }
+    if (tid < (int)(sizeof(grim_subject_result) / 4)) ((uint32_t *)&sh.out)[tid] = 0;
+    __syncthreads();
+    enumerate_phases(sh);
+    const double *prior = A.priors + (uint64_t)sh.subj.prior_idx * P * P;
+    const int nph = sh.nph;
+    for (int s = wave_id(); s < 2 * nph; s += GRIM_NWAVE) build_side_plan_a(A, sh, S, prior, wt[wave_id()], s >> 1, s & 1, s);
+    __syncthreads();
+    bool kept = false;
+    for (int i = 0; i < nph; ++i) kept |= (sh.cand_any[2 * i] && sh.cand_any[2 * i + 1]);
+    uint8_t status = GRIM_ST_MISS, reason = 0, plan = 'a';
+    if (!kept) {
+      // open_phases returned nothing: the reference now rewrites the GL (reduce_phase_to_valid_allels /
+      // _commons_alleles, impute.py:1620-1627).  Not on device yet.
+      status = GRIM_ST_UNSUPPORTED;
+      reason = 1;
+    } else {
+      const uint32_t np = pair_offsets(sh);
+      int e = A.prm.n_ladder;
+      if (np > 0) e = ladder_first(A, sh, S, prior, np);
+      uint32_t nU = 0;
+      double mx = 0.0;
+      if (e < A.prm.n_ladder) {
+        double eps = A.prm.ladder[e];
+        if (eps > 0.0) {
+          pair_pass(A, sh, S, prior, np, eps, false, &mx);
+          eps = mx / 100000.0;  // impute.py:1685
+        }
+        nU = pair_pass(A, sh, S, prior, np, eps, true, &mx);
+      }
+      if (nU > 0) {
+        emit_tables(A, sh, S, nU, sh.out);
+        status = GRIM_ST_OK;
+        if (tid == 0) sh.out.max_prob = mx;
+      } else if (A.prm.planb) {
+        status = GRIM_ST_UNSUPPORTED;  // replaced by the plan-B kernel's verdict when it runs
+        reason = 2;
+        if (tid == 0 && A.next_list) A.next_list[atomicAdd(A.next_count, 1u)] = si;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      sh.out.status = status;
+      sh.out.reason = reason;
+      sh.out.plan = plan;
+      A.res[si] = sh.out;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    unsigned long long c0 = 0, c1 = 0, c2 = 0;
+    for (int wv = 0; wv < GRIM_NWAVE; ++wv) {
+      c0 += sh.wctr[wv][0];
+      c1 += sh.wctr[wv][1];
+      c2 += sh.wctr[wv][2];
+    }
+    atomicAdd(&A.counters[0], c0);
+    atomicAdd(&A.counters[1], c1);
+    atomicAdd(&A.counters[2], c2);
+  }
+}
+
+// =================================================================================================
+// host side
+// =================================================================================================
+struct grim_ctx {
+  int device;
+  hipStream_t stream;
+  std::string err;
+  int n_cu;
+};
+
+struct grim_graph {
+  grim_ctx *ctx;
+  DevGraph d;
+  std::vector<void *> bufs;
+  uint64_t bytes;
+  uint32_t max_label;
+};
+
+struct grim_batch {
+  grim_ctx *ctx;
+  const grim_graph *g;
+  DevArgs a;
+  std::vector<void *> bufs;
+  uint32_t n_subj, n_slots;
+  hipEvent_t ev[4];
+  float ms_a, ms_b;
+  uint32_t rows_used;
+  unsigned long long counters[8];
+};
+
+static thread_local std::string g_err;
+
+#define HIPCHK(call, ctxp, ret)                                                        \
+  do {                                                                                 \
+    hipError_t e_ = (call);                                                            \
+    if (e_ != hipSuccess) {                                                            \
+      std::string m_ = std::string(#call) + ": " + hipGetErrorString(e_);             \
+      if (ctxp) (ctxp)->err = m_;                                                      \
+      g_err = m_;                                                                      \
+      return ret;                                                                      \
+    }                                                                                  \
+  } while (0)
+
+extern "C" int grim_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+extern "C" grim_ctx *grim_create(int device_id) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    g_err = "grim_create: no HIP device visible";
+    return nullptr;
+  }
+  if (device_id < 0 || device_id >= n) {
+    g_err = "grim_create: device id out of range";
+    return nullptr;
+  }
+  grim_ctx *c = new grim_ctx();
+  c->device = device_id;
+  if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
+    g_err = "grim_create: cannot initialise device";
+    delete c;
+    return nullptr;
+  }
+  hipDeviceProp_t prop;
+  c->n_cu = 256;
+  if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->n_cu = prop.multiProcessorCount;
+  return c;
+}
+
+extern "C" void grim_destroy(grim_ctx *c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" const char *grim_last_error(grim_ctx *c) { return c ? c->err.c_str() : g_err.c_str(); }
+
+template <typename T>
+static T *upload(grim_ctx *c, std::vector<void *> &bufs, const T *src, size_t n, uint64_t *bytes) {
+  void *p = nullptr;
+  size_t sz = (n ? n : 1) * sizeof(T);
+  if (hipMalloc(&p, sz) != hipSuccess) return nullptr;
+  bufs.push_back(p);
+  if (n && src && hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  if (bytes) *bytes += sz;
+  return (T *)p;
+}
+
+static uint64_t host_mix64(uint64_t x) {
+  x ^= x >> 33;
+  x *= 0xff51afd7ed558ccdULL;
+  x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ULL;
+  x ^= x >> 33;
+  return x;
+}
+
+extern "C" grim_graph *grim_graph_upload(grim_ctx *c, const grim_graph_desc *d) {
+  if (!c || !d) return nullptr;
+  hipSetDevice(c->device);
+  if (d->n_pops == 0 || d->n_pops > GRIM_MAXPOP) { c->err = "grim_graph_upload: population count out of range"; return nullptr; }
+  if (d->n_loci == 0 || d->n_loci > GRIM_MAXL) { c->err = "grim_graph_upload: locus count out of range"; return nullptr; }
+  if (d->n_nodes >= (1u << 23)) { c->err = "grim_graph_upload: more than 2^23 nodes"; return nullptr; }
+  grim_graph *g = new grim_graph();
+  g->ctx = c;
+  g->bytes = 0;
+  // exact-name index: open addressing over the 64-bit node keys
+  uint32_t cap = 64;
+  while (cap < 2 * (uint64_t)d->n_nodes) cap <<= 1;
+  std::vector<uint64_t> hk(cap, 0);
+  std::vector<uint32_t> hv(cap, 0);
+  for (uint32_t i = 0; i < d->n_nodes; ++i) {
+    uint64_t k = d->node_key[i];
+    if (k == 0) { c->err = "grim_graph_upload: node with empty key"; delete g; return nullptr; }
+    uint32_t h = (uint32_t)host_mix64(k) & (cap - 1);
+    while (hk[h] != 0 && hk[h] != k) h = (h + 1) & (cap - 1);
+    hk[h] = k;  // a repeated name keeps the later row, like dict assignment (networkx_graph.py:53)
+    hv[h] = i;
+  }
+  uint32_t maxlab = 0;
+  for (uint32_t m = 0; m < (1u << GRIM_MAXL); ++m) {
+    uint32_t n = d->lab_start[m + 1] - d->lab_start[m];
+    if (n > maxlab) maxlab = n;
+  }
+  g->max_label = maxlab;
+  DevGraph &D = g->d;
+  D.n_nodes = d->n_nodes;
+  D.P = d->n_pops;
+  D.n_loci = d->n_loci;
+  D.full_mask = d->full_mask;
+  D.ht_mask = cap - 1;
+  D.n_conn = d->n_conn;
+  D.node_key = upload(c, g->bufs, d->node_key, d->n_nodes, &g->bytes);
+  D.node_mask = upload(c, g->bufs, d->node_mask, d->n_nodes, &g->bytes);
+  D.freq = upload(c, g->bufs, d->freq, (size_t)d->n_nodes * d->n_pops, &g->bytes);
+  D.a_start = upload(c, g->bufs, d->a_start, (size_t)d->n_nodes + 1, &g->bytes);
+  D.a_nbr = upload(c, g->bufs, d->a_nbr, d->n_a_nbr, &g->bytes);
+  D.b_conn = upload(c, g->bufs, d->b_conn, (size_t)d->n_nodes * GRIM_MAXL, &g->bytes);
+  D.b_start = upload(c, g->bufs, d->b_start, (size_t)d->n_conn + 1, &g->bytes);
+  D.b_nbr = upload(c, g->bufs, d->b_nbr, d->n_b_nbr, &g->bytes);
+  D.lab_start = upload(c, g->bufs, d->lab_start, (1u << GRIM_MAXL) + 1, &g->bytes);
+  D.lab_nodes = upload(c, g->bufs, d->lab_nodes, d->n_nodes, &g->bytes);
+  D.ht_key = upload(c, g->bufs, hk.data(), cap, &g->bytes);
+  D.ht_val = upload(c, g->bufs, hv.data(), cap, &g->bytes);
+  if (!D.node_key || !D.node_mask || !D.freq || !D.a_start || !D.a_nbr || !D.b_conn || !D.b_start || !D.b_nbr ||
+      !D.lab_start || !D.lab_nodes || !D.ht_key || !D.ht_val) {
+    c->err = "grim_graph_upload: device allocation or copy failed";
+    for (void *p : g->bufs) hipFree(p);
+    delete g;
+    return nullptr;
+  }
+  return g;
+}
+
+extern "C" void grim_graph_free(grim_graph *g) {
+  if (!g) return;
+  hipSetDevice(g->ctx->device);
+  for (void *p : g->bufs) hipFree(p);
+  delete g;
+}
+
+extern "C" uint64_t grim_graph_device_bytes(const grim_graph *g) { return g ? g->bytes : 0; }
+
+static uint64_t align256(uint64_t x) { return (x + 255) & ~255ull; }
+
+extern "C" grim_batch *grim_batch_upload(grim_ctx *c, const grim_graph *g, const grim_params *p, const grim_batch_desc *d) {
+  if (!c || !g || !p || !d) return nullptr;
+  hipSetDevice(c->device);
+  if (p->top_n == 0 || p->top_n > GRIM_TOPCAP) { c->err = "grim_batch_upload: max_haplotypes_number_in_phase must be 1..128"; return nullptr; }
+  if (p->n_ladder < 0 || p->n_ladder > GRIM_MAXLADDER) { c->err = "grim_batch_upload: epsilon ladder too long"; return nullptr; }
+  grim_batch *b = new grim_batch();
+  b->ctx = c;
+  b->g = g;
+  b->n_subj = d->n_subjects;
+  b->ms_a = b->ms_b = 0;
+  b->rows_used = 0;
+  memset(b->counters, 0, sizeof(b->counters));
+  DevArgs &A = b->a;
+  memset(&A, 0, sizeof(A));
+  A.g = g->d;
+  A.prm = *p;
+  const uint32_t P = g->d.P;
+  uint64_t bytes = 0;
+  A.subj = upload(c, b->bufs, d->subjects, d->n_subjects, &bytes);
+  A.tok = upload(c, b->bufs, d->tokens, d->n_tokens, &bytes);
+  A.priors = upload(c, b->bufs, d->priors, (size_t)d->n_priors * P * P, &bytes);
+  std::vector<uint32_t> order(d->n_subjects);
+  for (uint32_t i = 0; i < d->n_subjects; ++i) order[i] = i;
+  A.order = upload(c, b->bufs, order.data(), d->n_subjects, &bytes);
+  A.n_work = d->n_subjects;
+  A.queue = upload<uint32_t>(c, b->bufs, nullptr, 4, &bytes);
+  A.row_head = A.queue + 1;
+  A.next_count = A.queue + 2;
+  A.next_list = upload<uint32_t>(c, b->bufs, nullptr, d->n_subjects, &bytes);
+  A.res = upload<grim_subject_result>(c, b->bufs, nullptr, d->n_subjects, &bytes);
+  A.counters = upload<unsigned long long>(c, b->bufs, nullptr, 8, &bytes);
+  // rows: enough for every subject to fill all four tables
+  uint64_t per = 2ull * p->n_results + 2ull * (p->n_pop_results < (uint64_t)P * P ? p->n_pop_results : (uint64_t)P * P);
+  uint64_t want = per * d->n_subjects + 1024;
+  const char *env_rows = getenv("GRIM_ROW_CAP");
+  if (env_rows) want = strtoull(env_rows, nullptr, 10);
+  if (want > 0x7FFFFFF0ull) want = 0x7FFFFFF0ull;
+  A.row_cap = (uint32_t)want;
+  A.rows = upload<grim_row>(c, b->bufs, nullptr, A.row_cap, &bytes);
+  // scratch slots
+  uint32_t slots = (uint32_t)c->n_cu * 2;
+  const char *env_slots = getenv("GRIM_SLOTS");
+  if (env_slots) slots = (uint32_t)atoi(env_slots);
+  if (slots > d->n_subjects) slots = d->n_subjects;
+  if (slots == 0) slots = 1;
+  b->n_slots = slots;
+  A.pair_cap = GRIM_MAXPH * p->top_n * p->top_n;
+  uint32_t tab = 64;
+  while (tab < 2 * A.pair_cap) tab <<= 1;
+  A.tab_cap = tab;
+  A.bset_cap = g->max_label;
+  SlotLayout &L = A.lay;
+  uint64_t o = 0;
+  auto take = [&](uint64_t n) { uint64_t r = o; o = align256(o + n); return r; };
+  L.Tp = take(8ull * GRIM_SIDES * GRIM_TOPCAP);
+  L.Tm = take(8ull * GRIM_SIDES * GRIM_TOPCAP);
+  L.Te = take(4ull * GRIM_SIDES * GRIM_TOPCAP);
+  L.k0 = take(8ull * tab);
+  L.k1 = take(8ull * tab);
+  L.tmin = take(4ull * tab);
+  L.tgid = take(4ull * tab);
+  L.Useq = take(4ull * A.pair_cap);
+  L.Uprob = take(8ull * A.pair_cap);
+  L.Uslot = take(4ull * A.pair_cap);
+  L.ska = take(8ull * A.pair_cap);
+  L.skb = take(8ull * A.pair_cap);
+  L.sva = take(4ull * A.pair_cap);
+  L.svb = take(4ull * A.pair_cap);
+  L.gsum = take(8ull * A.pair_cap);
+  L.ghead = take(4ull * A.pair_cap);
+  L.gstart = take(4ull * (A.pair_cap + 1));
+  L.gcnt = take(4ull * (A.pair_cap > P * P ? A.pair_cap : P * P));
+  L.qsum = take(8ull * P * P);
+  L.qfirst = take(4ull * P * P);
+  L.bset = take(4ull * GRIM_NWAVE * GRIM_MAXL * (uint64_t)A.bset_cap);
+  L.comp = take(8ull * GRIM_SIDES * GRIM_TOPCAP);
+  L.stride = align256(o);
+  A.scratch = upload<uint8_t>(c, b->bufs, nullptr, (size_t)L.stride * slots, &bytes);
+  bool ok = A.subj && A.tok && A.priors && A.order && A.queue && A.next_list && A.res && A.counters && A.rows && A.scratch;
+  for (int i = 0; i < 4 && ok; ++i) ok = hipEventCreate(&b->ev[i]) == hipSuccess;
+  if (!ok) {
+    c->err = "grim_batch_upload: device allocation or copy failed (" + std::to_string((unsigned long long)(L.stride * slots >> 20)) + " MiB scratch)";
+    for (void *q : b->bufs) hipFree(q);
+    delete b;
+    return nullptr;
+  }
+  return b;
+}
+
+extern "C" int grim_batch_run(grim_batch *b) {
+  if (!b) return -1;
+  grim_ctx *c = b->ctx;
+  hipSetDevice(c->device);
+  DevArgs &A = b->a;
+  HIPCHK(hipMemsetAsync(A.queue, 0, 16, c->stream), c, -1);
+  HIPCHK(hipMemsetAsync(A.counters, 0, 64, c->stream), c, -1);
+  HIPCHK(hipEventRecord(b->ev[0], c->stream), c, -1);
+  if (b->n_subj) {
+    hipLaunchKernelGGL(grim_plan_a_kernel, dim3(b->n_slots), dim3(GRIM_WG), 0, c->stream, A);
+    HIPCHK(hipGetLastError(), c, -1);
+  }
+  HIPCHK(hipEventRecord(b->ev[1], c->stream), c, -1);
+  if (A.prm.planb && b->n_subj) {
+    int rc = grim_launch_plan_b(A, b->n_slots, c->stream);
+    if (rc != 0) { c->err = "plan-B launch failed"; return -1; }
+  }
+  HIPCHK(hipEventRecord(b->ev[2], c->stream), c, -1);
+  HIPCHK(hipStreamSynchronize(c->stream), c, -1);
+  HIPCHK(hipEventElapsedTime(&b->ms_a, b->ev[0], b->ev[1]), c, -1);
+  HIPCHK(hipEventElapsedTime(&b->ms_b, b->ev[1], b->ev[2]), c, -1);
+  uint32_t head[4];
+  HIPCHK(hipMemcpy(head, A.queue, 16, hipMemcpyDeviceToHost), c, -1);
+  HIPCHK(hipMemcpy(b->counters, A.counters, 64, hipMemcpyDeviceToHost), c, -1);
+  b->rows_used = head[1];
+  if (b->counters[4] != 0 || head[1] > A.row_cap) {
+    c->err = "grim_batch_run: output row pool exhausted (raise GRIM_ROW_CAP or lower the batch size)";
+    return -2;
+  }
+  return 0;
+}
+
+extern "C" double grim_batch_kernel_ms(const grim_batch *b, int which) {
+  if (!b) return 0.0;
+  if (which == 1) return b->ms_a;
+  if (which == 2) return b->ms_b;
+  return (double)b->ms_a + (double)b->ms_b;
+}
+
+extern "C" int grim_batch_counters(const grim_batch *b, uint64_t out[4]) {
+  if (!b) return -1;
+  out[0] = b->counters[0];
+  out[1] = b->counters[1];
+  out[2] = b->counters[2];
+  out[3] = b->rows_used;
+  return 0;
+}
+
+extern "C" uint32_t grim_batch_total_rows(const grim_batch *b) { return b ? b->rows_used : 0; }
+
+extern "C" int grim_batch_results(grim_batch *b, grim_subject_result *res, grim_row *rows) {
+  if (!b) return -1;
+  grim_ctx *c = b->ctx;
+  hipSetDevice(c->device);
+  if (b->n_subj) HIPCHK(hipMemcpy(res, b->a.res, sizeof(grim_subject_result) * (size_t)b->n_subj, hipMemcpyDeviceToHost), c, -1);
+  if (b->rows_used) HIPCHK(hipMemcpy(rows, b->a.rows, sizeof(grim_row) * (size_t)b->rows_used, hipMemcpyDeviceToHost), c, -1);
+  return 0;
+}
+
+extern "C" void grim_batch_free(grim_batch *b) {
+  if (!b) return;
+  hipSetDevice(b->ctx->device);
+  for (int i = 0; i < 4; ++i) hipEventDestroy(b->ev[i]);
+  for (void *p : b->bufs) hipFree(p);
+  delete b;
+}

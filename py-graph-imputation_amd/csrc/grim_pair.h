@@ -1,0 +1,561 @@
+// grim_pair.h -- haplotype-pair scoring, first-wins dedup, ordered accumulation and ranking for one
+// subject by one workgroup.  Restates calc_haps_pairs / calc_haps_pairs_haplotype
+// (impute.py:444-548, 550-658), the epsilon ladder of call_comp_phase_prob (impute.py:1658-1693) and
+// the writers' ranking (impute.py:24-76) on integer-encoded top lists.
+//
+// Order fidelity: every accepted pair carries its sequence number f = position in the
+// reference's (phase, h, k) loop nest; dedup keeps the smallest f per unordered
+// {(hap,pop),(hap,pop)}; sums add probabilities in increasing f; ranking is a stable sort by
+// probability, first-seen order breaking ties.
+#pragma once
+#include "grim_dev.h"
+
+// LDS block shared by the kernels
+struct WgShared {
+  grim_subject subj;
+  uint32_t toff[GRIM_MAXL][2];
+  uint32_t Tn[GRIM_SIDES];
+  uint8_t cand_any[GRIM_SIDES];
+  uint8_t ph_pat[GRIM_MAXPH];
+  int nph;
+  uint32_t poff[GRIM_MAXPH + 1];
+  uint32_t tmp[GRIM_NWAVE + 24];
+  double dtmp[GRIM_NWAVE];
+  uint32_t bc[8];
+  unsigned long long wctr[GRIM_NWAVE][4];
+  grim_subject_result out;
+  uint32_t hist[16 * GRIM_WG];
+  // staging for the population-cell walk
+  double qprob[1024];
+  uint16_t qcell[1024];
+};
+
+struct Slot {
+  double *Tp, *Tm;
+  uint32_t *Te;
+  uint64_t *k0, *k1;
+  uint32_t *tmin, *tgid;
+  uint32_t *Useq, *Uslot;
+  double *Uprob;
+  uint64_t *ska, *skb;
+  uint32_t *sva, *svb;
+  double *gsum;
+  uint32_t *ghead, *gstart, *gcnt;
+  double *qsum;
+  uint32_t *qfirst;
+  uint32_t *bset;
+  uint64_t *comp;
+};
+
+__device__ __forceinline__ Slot make_slot(const DevArgs &A, uint32_t slot_idx) {
+  uint8_t *b = A.scratch + (uint64_t)slot_idx * A.lay.stride;
+  Slot s;
+  s.Tp = (double *)(b + A.lay.Tp);
+  s.Tm = (double *)(b + A.lay.Tm);
+  s.Te = (uint32_t *)(b + A.lay.Te);
+  s.k0 = (uint64_t *)(b + A.lay.k0);
+  s.k1 = (uint64_t *)(b + A.lay.k1);
+  s.tmin = (uint32_t *)(b + A.lay.tmin);
+  s.tgid = (uint32_t *)(b + A.lay.tgid);
+  s.Useq = (uint32_t *)(b + A.lay.Useq);
+  s.Uslot = (uint32_t *)(b + A.lay.Uslot);
+  s.Uprob = (double *)(b + A.lay.Uprob);
+  s.ska = (uint64_t *)(b + A.lay.ska);
+  s.skb = (uint64_t *)(b + A.lay.skb);
+  s.sva = (uint32_t *)(b + A.lay.sva);
+  s.svb = (uint32_t *)(b + A.lay.svb);
+  s.gsum = (double *)(b + A.lay.gsum);
+  s.ghead = (uint32_t *)(b + A.lay.ghead);
+  s.gstart = (uint32_t *)(b + A.lay.gstart);
+  s.gcnt = (uint32_t *)(b + A.lay.gcnt);
+  s.qsum = (double *)(b + A.lay.qsum);
+  s.qfirst = (uint32_t *)(b + A.lay.qfirst);
+  s.bset = (uint32_t *)(b + A.lay.bset);
+  s.comp = (uint64_t *)(b + A.lay.comp);
+  return s;
+}
+
+// An entity is (hap id : 24 bits | pop : 8 bits).  Hap ids below 2^23 are graph node ids, ids with
+// bit 23 set index the slot's composite-haplotype table (plan B/C).
+#define ENT_HAP(e) ((e) & 0xFFFFFFu)
+#define ENT_POP(e) ((e) >> 24)
+#define HAP_COMPOSITE 0x800000u
+
+__device__ __forceinline__ uint64_t hap_key(const DevGraph &g, const Slot &S, uint32_t hap) {
+  return (hap & HAP_COMPOSITE) ? S.comp[hap & 0x7FFFFFu] : g.node_key[hap];
+}
+
+struct PairRef {
+  double p1, p2, m2;
+  uint32_t e1, e2;
+};
+
+// pair number f -> (phase, h, k) -> the two top-list entries.  Phase i uses top-list rows 2i, 2i+1.
+__device__ __forceinline__ PairRef pair_ref(const WgShared &sh, const Slot &S, uint32_t f) {
+  int i = 0;
+  while (f >= sh.poff[i + 1]) ++i;
+  uint32_t r = f - sh.poff[i];
+  uint32_t n2 = sh.Tn[2 * i + 1];
+  uint32_t h = r / n2, k = r - h * n2;
+  PairRef pr;
+  pr.p1 = S.Tp[(2 * i) * GRIM_TOPCAP + h];
+  pr.e1 = S.Te[(2 * i) * GRIM_TOPCAP + h];
+  pr.p2 = S.Tp[(2 * i + 1) * GRIM_TOPCAP + k];
+  pr.m2 = S.Tm[(2 * i + 1) * GRIM_TOPCAP + k];
+  pr.e2 = S.Te[(2 * i + 1) * GRIM_TOPCAP + k];
+  return pr;
+}
+
+// the literal acceptance test of impute.py:457-491: x = eps / P1; loop over k BREAKS at the first
+// P2 < x (so k is reachable iff min(P2[0..k]) >= x); prior > 0; prior*P2 >= x (2x when hap1 == hap2)
+__device__ __forceinline__ bool pair_accept(double eps, const PairRef &pr, double w) {
+  double x = eps / pr.p1;
+  if (!(pr.m2 >= x)) return false;
+  if (!(w > 0.0)) return false;
+  double thr = (ENT_HAP(pr.e1) == ENT_HAP(pr.e2)) ? x * 2.0 : x;
+  return w * pr.p2 >= thr;
+}
+
+__device__ __forceinline__ double pair_prob(const PairRef &pr, double w) {
+  double prob = pr.p1 * pr.p2 * w;  // (P1*P2)*prior, impute.py:515-521
+  if (ENT_HAP(pr.e1) != ENT_HAP(pr.e2)) prob = prob * 2.0;
+  return prob;
+}
+
+// number of pairs of all phases; fills sh.poff.  All threads call.
+__device__ inline uint32_t pair_offsets(WgShared &sh) {
+  if (threadIdx.x == 0) {
+    uint32_t acc = 0;
+    for (int i = 0; i < sh.nph; ++i) {
+      sh.poff[i] = acc;
+      acc += sh.Tn[2 * i] * sh.Tn[2 * i + 1];
+    }
+    for (int i = sh.nph; i <= GRIM_MAXPH; ++i) sh.poff[i] = acc;
+  }
+  __syncthreads();
+  return sh.poff[GRIM_MAXPH];
+}
+
+// first ladder index at which ANY pair is accepted (n_ladder if none).  Equals the reference's
+// "decrease epsilon until the pass returns something" loop (impute.py:1665-1687).
+__device__ inline int ladder_first(const DevArgs &A, WgShared &sh, const Slot &S, const double *prior, uint32_t np) {
+  const int P = A.g.P;
+  int best = A.prm.n_ladder;
+  for (uint32_t f = threadIdx.x; f < np && best > 0; f += GRIM_WG) {
+    PairRef pr = pair_ref(sh, S, f);
+    double w = prior[ENT_POP(pr.e1) * P + ENT_POP(pr.e2)];
+    for (int idx = 0; idx < best; ++idx) {
+      if (pair_accept(A.prm.ladder[idx], pr, w)) {
+        best = idx;
+        break;
+      }
+    }
+  }
+  if (threadIdx.x == 0) sh.bc[0] = (uint32_t)A.prm.n_ladder;
+  __syncthreads();
+  atomicMin(&sh.bc[0], (uint32_t)best);
+  __syncthreads();
+  int r = (int)sh.bc[0];
+  __syncthreads();
+  return r;
+}
+
+// One full pass at `eps`: dedup (first f wins), MaxProb over winners, optionally the ordered list
+// U of winners.  Returns the number of winners; *maxp gets MaxProb.  (impute.py:512-527)
+__device__ inline uint32_t pair_pass(const DevArgs &A, WgShared &sh, const Slot &S, const double *prior, uint32_t np,
+                                     double eps, bool emit, double *maxp) {
+  const int P = A.g.P;
+  const int tid = threadIdx.x;
+  uint32_t cap = 64;
+  while (cap < 2 * np) cap <<= 1;
+  if (cap > A.tab_cap) cap = A.tab_cap;
+  const uint32_t mask = cap - 1;
+  for (uint32_t s = tid; s < cap; s += GRIM_WG) {
+    S.k0[s] = 0;
+    S.tmin[s] = GRIM_NONE;
+  }
+  __syncthreads();
+  for (uint32_t f = tid; f < np; f += GRIM_WG) {
+    PairRef pr = pair_ref(sh, S, f);
+    double w = prior[ENT_POP(pr.e1) * P + ENT_POP(pr.e2)];
+    if (pair_accept(eps, pr, w)) {
+      uint32_t lo = pr.e1 < pr.e2 ? pr.e1 : pr.e2, hi = pr.e1 < pr.e2 ? pr.e2 : pr.e1;
+      uint64_t key = ((uint64_t)lo << 32) | hi | GRIM_VALID;
+      uint32_t s = tab_insert<false>(S.k0, S.k1, mask, key, 0);
+      atomicMin(&S.tmin[s], f);
+    }
+  }
+  __syncthreads();
+  uint32_t nU = 0;
+  double mx = 0.0;
+  for (uint32_t f0 = 0; f0 < np; f0 += GRIM_WG) {
+    uint32_t f = f0 + tid;
+    bool win = false;
+    double prob = 0.0;
+    if (f < np) {
+      PairRef pr = pair_ref(sh, S, f);
+      double w = prior[ENT_POP(pr.e1) * P + ENT_POP(pr.e2)];
+      if (pair_accept(eps, pr, w)) {
+        uint32_t lo = pr.e1 < pr.e2 ? pr.e1 : pr.e2, hi = pr.e1 < pr.e2 ? pr.e2 : pr.e1;
+        uint64_t key = ((uint64_t)lo << 32) | hi | GRIM_VALID;
+        uint32_t s = tab_insert<false>(S.k0, S.k1, mask, key, 0);
+        win = (ALOAD(&S.tmin[s]) == f);
+        if (win) {
+          prob = pair_prob(pr, w);
+          if (prob > mx) mx = prob;
+        }
+      }
+    }
+    if (emit) {
+      uint64_t m = __ballot(win);
+      uint32_t wc = (uint32_t)__popcll(m);
+      if (lane_id() == 0) sh.tmp[wave_id()] = wc;
+      __syncthreads();
+      uint32_t base = nU, tot = 0;
+      for (int w2 = 0; w2 < GRIM_NWAVE; ++w2) {
+        uint32_t t = sh.tmp[w2];
+        if (w2 < wave_id()) base += t;
+        tot += t;
+      }
+      if (win) {
+        uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
+        if (pos < A.pair_cap) {
+          S.Useq[pos] = f;
+          S.Uprob[pos] = prob;
+        }
+      }
+      nU += tot;
+      __syncthreads();
+    } else {
+      nU += win ? 1u : 0u;
+    }
+  }
+  // MaxProb
+  for (int d = 32; d > 0; d >>= 1) {
+    double o = __shfl_xor(mx, d);
+    if (o > mx) mx = o;
+  }
+  if (lane_id() == 0) sh.dtmp[wave_id()] = mx;
+  if (!emit) {
+    // count winners across the workgroup
+    uint32_t c = nU;
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
+    if (lane_id() == 0) sh.tmp[wave_id()] = c;
+  }
+  __syncthreads();
+  mx = sh.dtmp[0];
+  for (int w2 = 1; w2 < GRIM_NWAVE; ++w2)
+    if (sh.dtmp[w2] > mx) mx = sh.dtmp[w2];
+  if (!emit) {
+    nU = 0;
+    for (int w2 = 0; w2 < GRIM_NWAVE; ++w2) nU += sh.tmp[w2];
+  }
+  __syncthreads();
+  *maxp = mx;
+  return nU;
+}
+
+// ---- grouping of U by a 64/128-bit key, ordered sums, stable ranking -------------------------------
+// kind: 0 = genotype (impute.py:497-504), 1 = unordered haplotype pair (write_best_prob, impute.py:24-39),
+//       2 = every pair its own group (write_best_hap_race_pairs, impute.py:79-85)
+// On return: ng groups; rank order in sva/svb (group ids, best first) -> *order_buf; gsum/ghead filled.
+__device__ inline uint32_t group_and_rank(const DevArgs &A, WgShared &sh, const Slot &S, uint32_t nU, int kind,
+                                          uint32_t **order_out) {
+  const int tid = threadIdx.x;
+  uint32_t ng = 0;
+  if (kind == 2) {
+    ng = nU;
+    for (uint32_t u = tid; u < nU; u += GRIM_WG) {
+      S.gsum[u] = S.Uprob[u];
+      S.ghead[u] = u;
+    }
+    __syncthreads();
+  } else {
+    uint32_t cap = 64;
+    while (cap < 2 * nU) cap <<= 1;
+    if (cap > A.tab_cap) cap = A.tab_cap;
+    const uint32_t mask = cap - 1;
+    for (uint32_t s = tid; s < cap; s += GRIM_WG) {
+      S.k0[s] = 0;
+      S.k1[s] = 0;
+      S.tmin[s] = GRIM_NONE;
+    }
+    __syncthreads();
+    for (uint32_t u = tid; u < nU; u += GRIM_WG) {
+      PairRef pr = pair_ref(sh, S, S.Useq[u]);
+      uint32_t h1 = ENT_HAP(pr.e1), h2 = ENT_HAP(pr.e2);
+      uint32_t s;
+      if (kind == 1) {
+        uint32_t lo = h1 < h2 ? h1 : h2, hi = h1 < h2 ? h2 : h1;
+        s = tab_insert<false>(S.k0, S.k1, mask, (((uint64_t)lo << 32) | hi) | GRIM_VALID, 0);
+      } else {
+        uint64_t a = hap_key(A.g, S, h1), b = hap_key(A.g, S, h2);
+        uint64_t lo = 0, hi = 0;
+#pragma unroll
+        for (int l = 0; l < GRIM_MAXL; ++l) {
+          uint64_t x = (a >> (GRIM_ABITS * l)) & 0xFFF, y = (b >> (GRIM_ABITS * l)) & 0xFFF;
+          lo |= (x < y ? x : y) << (GRIM_ABITS * l);
+          hi |= (x < y ? y : x) << (GRIM_ABITS * l);
+        }
+        s = tab_insert<true>(S.k0, S.k1, mask, lo | GRIM_VALID, hi | GRIM_VALID);
+      }
+      S.Uslot[u] = s;
+      atomicMin(&S.tmin[s], u);
+    }
+    __syncthreads();
+    // heads in first-seen order -> dense group ids
+    for (uint32_t u0 = 0; u0 < nU; u0 += GRIM_WG) {
+      uint32_t u = u0 + tid;
+      bool head = false;
+      uint32_t s = 0;
+      if (u < nU) {
+        s = S.Uslot[u];
+        head = (ALOAD(&S.tmin[s]) == u);
+      }
+      uint64_t m = __ballot(head);
+      if (lane_id() == 0) sh.tmp[wave_id()] = (uint32_t)__popcll(m);
+      __syncthreads();
+      uint32_t base = ng, tot = 0;
+      for (int w2 = 0; w2 < GRIM_NWAVE; ++w2) {
+        uint32_t t = sh.tmp[w2];
+        if (w2 < wave_id()) base += t;
+        tot += t;
+      }
+      if (head) {
+        uint32_t gid = base + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
+        S.tgid[s] = gid;
+        S.ghead[gid] = u;
+        S.gcnt[gid] = 0;
+      }
+      ng += tot;
+      __syncthreads();
+    }
+    // stable sort of u by group id, then per-group left-to-right sums
+    for (uint32_t u = tid; u < nU; u += GRIM_WG) {
+      uint32_t gid = S.tgid[S.Uslot[u]];
+      S.ska[u] = gid;
+      S.sva[u] = u;
+      atomicAdd(&S.gcnt[gid], 1u);
+    }
+    __syncthreads();
+    for (uint32_t g = tid; g < ng; g += GRIM_WG) S.gstart[g] = S.gcnt[g];
+    __syncthreads();
+    wg_scan_array(S.gstart, ng, sh.tmp);
+    int w = wg_radix_sort(S.ska, S.sva, S.skb, S.svb, nU, bits_for(ng), sh.hist, sh.tmp);
+    const uint32_t *sorted = w ? S.svb : S.sva;
+    for (uint32_t g = tid; g < ng; g += GRIM_WG) {
+      uint32_t a = S.gstart[g], b = S.gstart[g + 1];
+      double s = S.Uprob[sorted[a]];
+      for (uint32_t r = a + 1; r < b; ++r) s = s + S.Uprob[sorted[r]];
+      S.gsum[g] = s;
+    }
+    __syncthreads();
+  }
+  // ranking: stable sort by probability, bigger first; input order = first-seen order
+  if (ng <= 512) {
+    // small: rank by counting, sums staged in LDS (the radix histogram area is free here)
+    double *ls = (double *)sh.hist;
+    for (uint32_t g = tid; g < ng; g += GRIM_WG) ls[g] = S.gsum[g];
+    __syncthreads();
+    for (uint32_t g = tid; g < ng; g += GRIM_WG) {
+      double s = ls[g];
+      uint32_t rank = 0;
+      for (uint32_t g2 = 0; g2 < ng; ++g2) {
+        double s2 = ls[g2];
+        rank += (s2 > s || (s2 == s && g2 < g)) ? 1u : 0u;
+      }
+      S.sva[rank] = g;
+    }
+    __syncthreads();
+    *order_out = S.sva;
+    return ng;
+  }
+  for (uint32_t g = tid; g < ng; g += GRIM_WG) {
+    S.ska[g] = ~f64_ord(S.gsum[g]);
+    S.sva[g] = g;
+  }
+  __syncthreads();
+  int w = wg_radix_sort(S.ska, S.sva, S.skb, S.svb, ng, 64, sh.hist, sh.tmp);
+  *order_out = w ? S.svb : S.sva;
+  return ng;
+}
+
+__device__ inline uint32_t alloc_rows(const DevArgs &A, WgShared &sh, uint32_t n) {
+  if (threadIdx.x == 0) {
+    uint32_t off = n ? atomicAdd(A.row_head, n) : 0;
+    if (n && off + n > A.row_cap) {
+      atomicExch(&A.counters[4], 1ull);
+      off = GRIM_NONE;
+    }
+    sh.bc[1] = off;
+  }
+  __syncthreads();
+  uint32_t off = sh.bc[1];
+  __syncthreads();
+  return off;
+}
+
+// population-pair table: one lane per unordered cell walks U in order (sums are left-to-right,
+// impute.py:535-543 and 24-39); both display orientations come from the same sums.
+__device__ inline void pop_tables(const DevArgs &A, WgShared &sh, const Slot &S, uint32_t nU, grim_subject_result &out,
+                                  bool plan_c) {
+  const int tid = threadIdx.x;
+  const int P = A.g.P;
+  const int ncell = P * P;
+  for (int c = tid; c < ncell; c += GRIM_WG) {
+    S.qsum[c] = 0.0;
+    S.qfirst[c] = GRIM_NONE;
+  }
+  __syncthreads();
+  for (uint32_t u0 = 0; u0 < nU; u0 += 1024) {
+    uint32_t cnt = nU - u0 < 1024 ? nU - u0 : 1024;
+    for (uint32_t r = tid; r < cnt; r += GRIM_WG) {
+      PairRef pr = pair_ref(sh, S, S.Useq[u0 + r]);
+      uint32_t a = ENT_POP(pr.e1), b = ENT_POP(pr.e2);
+      uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+      sh.qcell[r] = (uint16_t)(lo * P + hi);
+      sh.qprob[r] = S.Uprob[u0 + r];
+    }
+    __syncthreads();
+    for (int c = tid; c < ncell; c += GRIM_WG) {
+      if ((c / P) > (c % P)) continue;
+      double s = S.qsum[c];
+      uint32_t first = S.qfirst[c];
+      for (uint32_t r = 0; r < cnt; ++r) {
+        if (sh.qcell[r] == c) {
+          if (first == GRIM_NONE) {
+            first = u0 + r;
+            s = sh.qprob[r];
+          } else {
+            s = s + sh.qprob[r];
+          }
+        }
+      }
+      S.qsum[c] = s;
+      S.qfirst[c] = first;
+    }
+    __syncthreads();
+  }
+  // rank the non-empty cells: bigger sum first, earlier first-seen breaks ties
+  uint32_t nq = 0;
+  // compact non-empty cells in first-seen order is not needed: rank by counting
+  for (int c = tid; c < ncell; c += GRIM_WG) {
+    uint32_t first = S.qfirst[c];
+    if (first == GRIM_NONE) continue;
+    double s = S.qsum[c];
+    uint32_t rank = 0;
+    for (int c2 = 0; c2 < ncell; ++c2) {
+      uint32_t f2 = S.qfirst[c2];
+      if (f2 == GRIM_NONE || c2 == c) continue;
+      double s2 = S.qsum[c2];
+      if (s2 > s || (s2 == s && f2 < first)) ++rank;
+    }
+    S.gcnt[c] = rank;
+    atomicAdd(&sh.bc[2], 1u);
+  }
+  __syncthreads();
+  nq = sh.bc[2];
+  __syncthreads();
+  uint32_t nrow = nq < A.prm.n_pop_results ? nq : A.prm.n_pop_results;
+  if (A.prm.em_mr) {
+    // hap_pop_pair mode writes only the single best population pair to the phased pops file
+    // (impute.py:2088) and leaves the MUUG pops file as usual
+  }
+  for (int t = 0; t < 2; ++t) {
+    int table = t == 0 ? GRIM_T_UMUG_POPS : GRIM_T_PMUG_POPS;
+    bool on = t == 0 ? A.prm.out_muug : A.prm.out_haps;
+    uint32_t want = nrow;
+    if (t == 1 && A.prm.em_mr) want = nq < 1 ? nq : 1;
+    if (!on) want = 0;
+    uint32_t off = alloc_rows(A, sh, want);
+    if (tid == 0) {
+      out.row_off[table] = off == GRIM_NONE ? 0 : off;
+      out.n_rows[table] = off == GRIM_NONE ? 0 : want;
+    }
+    if (off == GRIM_NONE || want == 0) continue;
+    for (int c = tid; c < ncell; c += GRIM_WG) {
+      uint32_t first = S.qfirst[c];
+      if (first == GRIM_NONE) continue;
+      uint32_t rank = S.gcnt[c];
+      if (rank >= want) continue;
+      PairRef pr = pair_ref(sh, S, S.Useq[first]);
+      uint32_t a = ENT_POP(pr.e1), b = ENT_POP(pr.e2);
+      if (t == 0 && A.prm.pop_rank[a] > A.prm.pop_rank[b]) {
+        uint32_t x = a;
+        a = b;
+        b = x;
+      }
+      grim_row r;
+      r.a = a;
+      r.b = b;
+      r.prob = S.qsum[c];
+      r.popa = a;
+      r.popb = b;
+      A.rows[off + rank] = r;
+    }
+  }
+  __syncthreads();
+}
+
+// Everything after the final pass: the four output tables of one subject.
+__device__ inline void emit_tables(const DevArgs &A, WgShared &sh, const Slot &S, uint32_t nU, grim_subject_result &out) {
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    sh.bc[2] = 0;
+    out.n_pairs = nU;
+  }
+  __syncthreads();
+  pop_tables(A, sh, S, nU, out, false);
+  // genotype table (.umug)
+  {
+    uint32_t *order = nullptr;
+    uint32_t ng = group_and_rank(A, sh, S, nU, 0, &order);
+    uint32_t want = A.prm.out_muug ? (ng < A.prm.n_results ? ng : A.prm.n_results) : 0;
+    uint32_t off = alloc_rows(A, sh, want);
+    if (tid == 0) {
+      out.n_genotypes = ng;
+      out.row_off[GRIM_T_UMUG] = off == GRIM_NONE ? 0 : off;
+      out.n_rows[GRIM_T_UMUG] = off == GRIM_NONE ? 0 : want;
+    }
+    if (off != GRIM_NONE)
+      for (uint32_t r = tid; r < want; r += GRIM_WG) {
+        uint32_t g = order[r];
+        PairRef pr = pair_ref(sh, S, S.Useq[S.ghead[g]]);
+        grim_row row;
+        row.a = hap_key(A.g, S, ENT_HAP(pr.e1));
+        row.b = hap_key(A.g, S, ENT_HAP(pr.e2));
+        row.prob = S.gsum[g];
+        row.popa = ENT_POP(pr.e1);
+        row.popb = ENT_POP(pr.e2);
+        A.rows[off + r] = row;
+      }
+    __syncthreads();
+  }
+  // haplotype-pair table (.pmug)
+  {
+    uint32_t *order = nullptr;
+    uint32_t ng = 0, want = 0;
+    if (A.prm.out_haps) {
+      ng = group_and_rank(A, sh, S, nU, A.prm.em_mr ? 2 : 1, &order);
+      want = ng < A.prm.n_results ? ng : A.prm.n_results;
+    }
+    uint32_t off = alloc_rows(A, sh, want);
+    if (tid == 0) {
+      out.row_off[GRIM_T_PMUG] = off == GRIM_NONE ? 0 : off;
+      out.n_rows[GRIM_T_PMUG] = off == GRIM_NONE ? 0 : want;
+    }
+    if (off != GRIM_NONE)
+      for (uint32_t r = tid; r < want; r += GRIM_WG) {
+        uint32_t g = order[r];
+        PairRef pr = pair_ref(sh, S, S.Useq[S.ghead[g]]);
+        grim_row row;
+        row.a = hap_key(A.g, S, ENT_HAP(pr.e1));
+        row.b = hap_key(A.g, S, ENT_HAP(pr.e2));
+        row.prob = S.gsum[g];
+        row.popa = ENT_POP(pr.e1);
+        row.popb = ENT_POP(pr.e2);
+        A.rows[off + r] = row;
+      }
+    __syncthreads();
+  }
+}

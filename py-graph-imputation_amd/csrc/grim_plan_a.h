@@ -1,0 +1,196 @@
+// grim_plan_a.h -- Plan A for one subject: phase enumeration, candidate enumeration per phase side,
+// exact-name lookup + top-link (CSR) neighbour gather, running top-K.
+//   gen_phases            impute.py:274-303
+//   open_phases           impute.py:914-989  (cutils.pyx:4-51: cartesian opening / label filter)
+//   get_haplo_freqs       impute.py:393-397  -> Graph.adjs_query networkx_graph.py:253-278
+//   convert_list_to_one_dim impute.py:424-442
+#pragma once
+#include "grim_pair.h"
+
+// phases kept by gen_phases: pattern bit l set = position l takes side-2's allele list for H1.
+// same_mask bit l set = the two side STRINGS of position l are identical (flipping is a no-op).
+__device__ inline void enumerate_phases(WgShared &sh) {
+  if (threadIdx.x == 0) {
+    int n = sh.subj.n_loci;
+    uint32_t same = sh.subj.pad[0];
+    uint32_t het = ((1u << n) - 1u) & ~same;
+    uint32_t seen = 0;
+    int cnt = 0;
+    for (uint32_t i = 0; i < (1u << (n - 1)); ++i) {
+      uint32_t p = i & het;
+      if (!((seen >> p) & 1u)) {
+        seen |= (1u << p) | (1u << (p ^ het));
+        sh.ph_pat[cnt++] = (uint8_t)p;
+      }
+    }
+    sh.nph = cnt;
+    uint32_t acc = 0;
+    for (int l = 0; l < n; ++l)
+      for (int s = 0; s < 2; ++s) {
+        sh.toff[l][s] = acc;
+        acc += sh.subj.cnt[l][s];
+      }
+  }
+  __syncthreads();
+}
+
+// Expand the chunk of <=64 found nodes held one per lane (GRIM_NONE = nothing) into (hap, pop)
+// entries and push them through the running top-K.  `full_nodes`: the nodes are full haplotypes
+// themselves (no neighbour gather).
+__device__ __forceinline__ void expand_chunk(const DevArgs &A, const double *prior, WaveTop &L, TopState &st, uint32_t node,
+                                             bool full_nodes, uint64_t &item_base, uint64_t &c_nbr, uint64_t &c_freq) {
+  const DevGraph &g = A.g;
+  const int lane = lane_id();
+  const int P = g.P;
+  uint32_t cnt = 0;
+  if (node != GRIM_NONE) cnt = full_nodes ? 1u : nbr_count(g.a_start, node);
+  uint32_t inc = wave_incl_scan(cnt);
+  uint32_t total = __shfl(inc, 63);
+  if (total == 0) return;
+  L.cstart[lane] = inc - cnt;
+  L.cnode[lane] = node;
+  if (lane == 0) L.cstart[64] = total;
+  WAVE_SYNC();
+  for (uint32_t t0 = 0; t0 < total; t0 += 64) {
+    uint32_t t = t0 + lane;
+    bool valid = t < total;
+    uint32_t hap = 0;
+    if (valid) {
+      // owner lane: last l with cstart[l] <= t
+      int lo = 0, hi = 63;
+      while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (L.cstart[mid] <= t) lo = mid; else hi = mid - 1;
+      }
+      uint32_t nd = L.cnode[lo];
+      hap = full_nodes ? nd : g.a_nbr[g.a_start[nd] + (t - L.cstart[lo])];
+    }
+    for (int j = 0; j < P; ++j) {
+      double p = valid ? g.freq[(uint64_t)hap * P + j] : 0.0;
+      bool act = valid && p > 0.0;
+      double key = p * prior[j * P + j];
+      uint64_t tie = (((item_base + t) * (uint64_t)P + (uint64_t)j) << 8) | (uint64_t)j;
+      top_push(L, st, act, p, key, tie, hap);
+    }
+  }
+  item_base += total;
+  if (!full_nodes) c_nbr += total;
+  c_freq += total;
+  WAVE_SYNC();
+}
+
+// write the finished list of one side: probabilities, prefix-min, entities
+__device__ __forceinline__ void store_top(const Slot &S, WgShared &sh, WaveTop &L, TopState &st, int row) {
+  const int lane = lane_id();
+  top_flush(L, st);
+  int n = st.nrun;
+  // prefix-min of p over the list order (the pair loop's `break`, impute.py:463-464,545-546)
+  double carry = __longlong_as_double(0x7FF0000000000000ll);
+  for (int r0 = 0; r0 < n; r0 += 64) {
+    int r = r0 + lane;
+    double v = r < n ? L.p[r] : __longlong_as_double(0x7FF0000000000000ll);
+    for (int d = 1; d < 64; d <<= 1) {
+      double o = __shfl_up(v, d);
+      if (lane >= d && o < v) v = o;
+    }
+    if (carry < v) v = carry;
+    if (r < n) {
+      S.Tp[row * GRIM_TOPCAP + r] = L.p[r];
+      S.Tm[row * GRIM_TOPCAP + r] = v;
+      S.Te[row * GRIM_TOPCAP + r] = L.hap[r] | ((uint32_t)(L.tie[r] & 0xFF) << 24);
+    }
+    carry = __shfl(v, 63);
+  }
+  if (lane == 0) sh.Tn[row] = (uint32_t)n;
+  WAVE_SYNC();
+}
+
+// Build the top list of phase `ph` (index into sh.ph_pat), side `side` into list row `row`.
+__device__ inline void build_side_plan_a(const DevArgs &A, WgShared &sh, const Slot &S, const double *prior, WaveTop &L,
+                                         int ph, int side, int row) {
+  const DevGraph &g = A.g;
+  const grim_subject &sj = sh.subj;
+  const uint16_t *tok = A.tok + sj.tok_off;
+  const int lane = lane_id();
+  const int n = sj.n_loci;
+  const uint32_t pat = sh.ph_pat[ph];
+  TopState st;
+  st.nrun = 0; st.nbuf = 0; st.K = (int)A.prm.top_n; st.full = false; st.thr = 0;
+  uint32_t cn[GRIM_MAXL], to[GRIM_MAXL], sl[GRIM_MAXL];
+  uint64_t options = 1;
+  uint32_t ncand = 1, mask = 0;
+#pragma unroll
+  for (int l = 0; l < GRIM_MAXL; ++l) {
+    cn[l] = 1; to[l] = 0; sl[l] = 0;
+    if (l < n) {
+      int c = (int)((pat >> l) & 1u) ^ side;
+      cn[l] = sj.cnt[l][c];
+      to[l] = sh.toff[l][c];
+      sl[l] = sj.slot[l];
+      uint64_t w = sj.wid[l][c];
+      options = options * w;
+      if (options > 0xFFFFFFFFFFFFull) options = 0xFFFFFFFFFFFFull;
+      ncand *= cn[l];
+      mask |= 1u << sl[l];
+    }
+  }
+  uint64_t item_base = 0, c_probe = 0, c_nbr = 0, c_freq = 0;
+  bool any_cand = false;
+  if (options < A.prm.opt_threshold) {
+    // cartesian opening, position 0 most significant (cutils.pyx:21-29 applied locus by locus)
+    any_cand = true;
+    const bool full_nodes = (mask == g.full_mask);
+    for (uint32_t c0 = 0; c0 < ncand; c0 += 64) {
+      uint32_t c = c0 + lane;
+      uint32_t node = GRIM_NONE;
+      if (c < ncand) {
+        uint64_t key = 0;
+        uint32_t rem = c;
+#pragma unroll
+        for (int l = GRIM_MAXL - 1; l >= 0; --l) {
+          if (l < n) {
+            uint32_t d = rem % cn[l];
+            rem /= cn[l];
+            key |= (uint64_t)(tok[to[l] + d] + 1u) << (GRIM_ABITS * sl[l]);
+          }
+        }
+        node = graph_lookup(g, key);
+      }
+      c_probe += (ncand - c0) < 64 ? (ncand - c0) : 64;
+      expand_chunk(A, prior, L, st, node, full_nodes, item_base, c_nbr, c_freq);
+    }
+  } else {
+    // label scan: every node of the typed-loci label whose alleles all belong to this side's
+    // alternatives, in node-id order (impute.py:947-981, cutils.pyx:33-51)
+    const bool full_nodes = (mask == g.full_mask);
+    uint32_t a = g.lab_start[mask], b = g.lab_start[mask + 1];
+    for (uint32_t i0 = a; i0 < b; i0 += 64) {
+      uint32_t i = i0 + lane;
+      uint32_t node = GRIM_NONE;
+      if (i < b) {
+        uint32_t nd = g.lab_nodes[i];
+        uint64_t key = g.node_key[nd];
+        bool ok = true;
+#pragma unroll
+        for (int l = 0; l < GRIM_MAXL; ++l) {
+          if (l < n && ok) {
+            uint32_t al = (uint32_t)((key >> (GRIM_ABITS * sl[l])) & 0xFFF) - 1u;
+            bool hit = false;
+            for (uint32_t t = 0; t < cn[l]; ++t) hit |= (tok[to[l] + t] == al);
+            ok = hit;
+          }
+        }
+        if (ok) node = nd;
+      }
+      if (__ballot(node != GRIM_NONE)) any_cand = true;
+      expand_chunk(A, prior, L, st, node, full_nodes, item_base, c_nbr, c_freq);
+    }
+  }
+  store_top(S, sh, L, st, row);
+  if (lane == 0) {
+    sh.cand_any[row] = any_cand ? 1 : 0;
+    sh.wctr[wave_id()][0] += c_probe;
+    sh.wctr[wave_id()][1] += c_nbr;
+    sh.wctr[wave_id()][2] += c_freq;
+  }
+}

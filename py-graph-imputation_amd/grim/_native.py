@@ -1,0 +1,258 @@
+"""
+ctypes binding of libgrim_hip.so (include/grim_hip.h).  There is no CPU fallback: if the
+library is missing or no HIP device is visible, every compute entry point raises.
+"""
+
+import ctypes as C
+import os
+
+import numpy as np
+
+MAXL = 5
+ABITS = 12
+MAXPH = 16
+MAXPOP = 64
+TOPCAP = 128
+MAXLADDER = 64
+MAXROWS = 8
+
+ST_OK, ST_MISS, ST_UNSUPPORTED = 0, 1, 2
+T_UMUG, T_UMUG_POPS, T_PMUG, T_PMUG_POPS = 0, 1, 2, 3
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libgrim_hip.so")
+
+
+class GraphDesc(C.Structure):
+    _fields_ = [
+        ("n_nodes", C.c_uint32), ("n_pops", C.c_uint32), ("n_loci", C.c_uint32), ("full_mask", C.c_uint32),
+        ("node_key", C.c_void_p), ("node_mask", C.c_void_p), ("freq", C.c_void_p),
+        ("a_start", C.c_void_p), ("a_nbr", C.c_void_p), ("n_a_nbr", C.c_uint64),
+        ("b_conn", C.c_void_p), ("b_start", C.c_void_p), ("b_nbr", C.c_void_p),
+        ("n_conn", C.c_uint32), ("n_b_nbr", C.c_uint64),
+        ("lab_start", C.c_void_p), ("lab_nodes", C.c_void_p),
+    ]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("ladder", C.c_double * MAXLADDER), ("n_ladder", C.c_int32), ("top_n", C.c_uint32),
+        ("opt_threshold", C.c_uint64), ("n_results", C.c_uint32), ("n_pop_results", C.c_uint32),
+        ("out_muug", C.c_uint8), ("out_haps", C.c_uint8), ("planb", C.c_uint8), ("em_mr", C.c_uint8),
+        ("pop_rank", C.c_uint8 * MAXPOP), ("factor_missing", C.c_double),
+        ("planb_rows", C.c_uint8), ("planb_nblk", C.c_uint8 * MAXROWS),
+        ("planb_blk", (C.c_uint8 * MAXL) * MAXROWS),
+    ]
+
+
+class BatchDesc(C.Structure):
+    _fields_ = [
+        ("n_subjects", C.c_uint32), ("subjects", C.c_void_p), ("tokens", C.c_void_p), ("n_tokens", C.c_uint64),
+        ("priors", C.c_void_p), ("n_priors", C.c_uint32),
+    ]
+
+
+# numpy mirrors of the plain-data structs
+SUBJECT_DT = np.dtype([
+    ("tok_off", "<u4"), ("prior_idx", "<u2"), ("n_loci", "u1"), ("flags", "u1"),
+    ("slot", "u1", (MAXL,)), ("pad", "u1", (3,)),
+    ("cnt", "<u2", (MAXL, 2)), ("wid", "<u2", (MAXL, 2)), ("reserved", "<u4", (2,)),
+], align=False)
+assert SUBJECT_DT.itemsize == 64
+
+RESULT_DT = np.dtype([
+    ("status", "u1"), ("plan", "u1"), ("reason", "u1"), ("pad", "u1"),
+    ("n_pairs", "<u4"), ("n_genotypes", "<u4"),
+    ("row_off", "<u4", (4,)), ("n_rows", "<u4", (4,)), ("pad2", "<u4"), ("max_prob", "<f8"),
+], align=False)
+assert RESULT_DT.itemsize == 56
+
+ROW_DT = np.dtype([("a", "<u8"), ("b", "<u8"), ("prob", "<f8"), ("popa", "<u4"), ("popb", "<u4")])
+assert ROW_DT.itemsize == 32
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the shared library (once).  Raises NativeError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeError(
+            "libgrim_hip.so not found at %s -- build it with `python __graft_entry__.py` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.grim_create.restype = C.c_void_p
+    L.grim_create.argtypes = [C.c_int]
+    L.grim_destroy.argtypes = [C.c_void_p]
+    L.grim_last_error.restype = C.c_char_p
+    L.grim_last_error.argtypes = [C.c_void_p]
+    L.grim_device_count.restype = C.c_int
+    L.grim_graph_upload.restype = C.c_void_p
+    L.grim_graph_upload.argtypes = [C.c_void_p, C.POINTER(GraphDesc)]
+    L.grim_graph_free.argtypes = [C.c_void_p]
+    L.grim_graph_device_bytes.restype = C.c_uint64
+    L.grim_graph_device_bytes.argtypes = [C.c_void_p]
+    L.grim_batch_upload.restype = C.c_void_p
+    L.grim_batch_upload.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Params), C.POINTER(BatchDesc)]
+    L.grim_batch_run.restype = C.c_int
+    L.grim_batch_run.argtypes = [C.c_void_p]
+    L.grim_batch_kernel_ms.restype = C.c_double
+    L.grim_batch_kernel_ms.argtypes = [C.c_void_p, C.c_int]
+    L.grim_batch_counters.restype = C.c_int
+    L.grim_batch_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.grim_batch_total_rows.restype = C.c_uint32
+    L.grim_batch_total_rows.argtypes = [C.c_void_p]
+    L.grim_batch_results.restype = C.c_int
+    L.grim_batch_results.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.grim_batch_free.argtypes = [C.c_void_p]
+    _lib = L
+    return L
+
+
+EXPORTS = [
+    "grim_create", "grim_destroy", "grim_last_error", "grim_device_count", "grim_graph_upload", "grim_graph_free",
+    "grim_graph_device_bytes", "grim_batch_upload", "grim_batch_run", "grim_batch_kernel_ms", "grim_batch_counters",
+    "grim_batch_total_rows", "grim_batch_results", "grim_batch_free",
+]
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One per GPU (grim_ctx)."""
+
+    def __init__(self, device=0):
+        L = lib()
+        self.device = device
+        self.h = L.grim_create(device)
+        if not self.h:
+            raise NativeError("grim_create(%d) failed: %s" % (device, L.grim_last_error(None).decode()))
+
+    def error(self):
+        return lib().grim_last_error(self.h).decode()
+
+    def close(self):
+        if self.h:
+            lib().grim_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_contexts = {}
+
+
+def default_context(device=None):
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0")) if os.environ.get("GRIM_DEVICE") is None else int(os.environ["GRIM_DEVICE"])
+        n = lib().grim_device_count()
+        if n > 0:
+            device %= n
+    if device not in _contexts:
+        _contexts[device] = Context(device)
+    return _contexts[device]
+
+
+class DeviceGraph:
+    """Device-resident graph (grim_graph)."""
+
+    def __init__(self, ctx, arrays):
+        L = lib()
+        self.ctx = ctx
+        d = GraphDesc()
+        self._keep = arrays  # host arrays must outlive the upload call only, kept for debugging
+        d.n_nodes = arrays["n_nodes"]
+        d.n_pops = arrays["n_pops"]
+        d.n_loci = arrays["n_loci"]
+        d.full_mask = arrays["full_mask"]
+        for k in ("node_key", "node_mask", "freq", "a_start", "a_nbr", "b_conn", "b_start", "b_nbr", "lab_start", "lab_nodes"):
+            setattr(d, k, _ptr(arrays[k]))
+        d.n_a_nbr = arrays["a_nbr"].shape[0]
+        d.n_conn = arrays["b_start"].shape[0] - 1
+        d.n_b_nbr = arrays["b_nbr"].shape[0]
+        self.h = L.grim_graph_upload(ctx.h, C.byref(d))
+        if not self.h:
+            raise NativeError("grim_graph_upload failed: " + ctx.error())
+
+    def device_bytes(self):
+        return int(lib().grim_graph_device_bytes(self.h))
+
+    def close(self):
+        if self.h:
+            lib().grim_graph_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceBatch:
+    """Subjects resident in HBM + result/scratch buffers (grim_batch)."""
+
+    def __init__(self, ctx, dgraph, params, subjects, tokens, priors):
+        L = lib()
+        self.ctx = ctx
+        self.n = int(subjects.shape[0])
+        d = BatchDesc()
+        tokens = np.ascontiguousarray(tokens, dtype=np.uint16)
+        priors = np.ascontiguousarray(priors, dtype=np.float64)
+        subjects = np.ascontiguousarray(subjects)
+        d.n_subjects = self.n
+        d.subjects = _ptr(subjects)
+        d.tokens = _ptr(tokens)
+        d.n_tokens = tokens.shape[0]
+        d.priors = _ptr(priors)
+        d.n_priors = priors.shape[0]
+        self._keep = (subjects, tokens, priors)
+        self.h = L.grim_batch_upload(ctx.h, dgraph.h, C.byref(params), C.byref(d))
+        if not self.h:
+            raise NativeError("grim_batch_upload failed: " + ctx.error())
+
+    def run(self):
+        rc = lib().grim_batch_run(self.h)
+        if rc != 0:
+            raise NativeError("grim_batch_run failed (%d): %s" % (rc, self.ctx.error()))
+
+    def kernel_ms(self, which=0):
+        return float(lib().grim_batch_kernel_ms(self.h, which))
+
+    def counters(self):
+        out = (C.c_uint64 * 4)()
+        lib().grim_batch_counters(self.h, out)
+        return [int(x) for x in out]
+
+    def results(self):
+        L = lib()
+        nrows = int(L.grim_batch_total_rows(self.h))
+        res = np.zeros(self.n, dtype=RESULT_DT)
+        rows = np.zeros(max(nrows, 1), dtype=ROW_DT)
+        rc = L.grim_batch_results(self.h, _ptr(res), _ptr(rows))
+        if rc != 0:
+            raise NativeError("grim_batch_results failed: " + self.ctx.error())
+        return res, rows[:nrows]
+
+    def close(self):
+        if self.h:
+            lib().grim_batch_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

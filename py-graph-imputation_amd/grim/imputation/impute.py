@@ -1,0 +1,467 @@
+"""
+Imputation driver for the MI355X engine.
+
+Mirrors the reference's operator interface for this path (grim/imputation/impute.py):
+`Imputation(net, config, count_by_prob)`, `impute_file(config, planb, em_mr, em)`,
+`impute_one(...)`, the module functions `clean_up_gl`, `write_best_prob*` -- same argument meaning,
+same six output files, same `.miss` / `.problem` rules -- but the per-subject work
+(impute.py:1584-1724: candidate enumeration, graph look-ups, top-100, pair scoring, epsilon
+ladder, ranking) runs as HIP kernels over the whole batch.  The host side only tokenises GL
+strings to integers, builds the per-race prior matrices, and formats result rows.
+
+There is no CPU fallback: without libgrim_hip.so and a HIP device `impute_file` raises.
+"""
+
+import logging
+import os
+import timeit
+
+import numpy as np
+
+from .. import _native as nat
+
+# outcome of tokenising one input line
+_DEV, _PROBLEM_ID, _PROBLEM_RAW, _MISS_NO_DEVICE = 0, 1, 2, 3
+
+REASONS = {
+    1: "open_phases found no candidate in any phase (reduce_phase_to_* rewrite, impute.py:1620-1627)",
+    2: "Plan B / Plan C fallback (impute.py:1392-1570, 1313-1389)",
+}
+
+
+def clean_up_gl(gl):
+    """impute.py:105-118: every 'g' and 'L' character is deleted, loci whose text starts or ends
+    with 'U' (the UUUU placeholders) are dropped."""
+    gl = gl.replace("g", "").replace("L", "")
+    return "^".join(part for part in gl.split("^") if part.strip("U") == part)
+
+
+class UnsupportedSubjects(NotImplementedError):
+    def __init__(self, items):
+        self.items = items
+        kinds = sorted({r for _, _, r in items})
+        msg = "%d subject(s) need a reference path this build does not run on the GPU yet: %s (first ids: %s)" % (
+            len(items), "; ".join(REASONS.get(k, str(k)) for k in kinds), ", ".join(str(s) for _, s, _ in items[:5]))
+        super().__init__(msg)
+
+
+class Imputation(object):
+    def __init__(self, net=None, config=None, count_by_prob=None, verbose=False, device=None):
+        self.logger = logging.getLogger("Logger." + __name__)
+        self.verbose = verbose
+        self.netGraph = net
+        self.device = device
+        self.quiet = bool(int(os.environ.get("GRIM_QUIET", "0")))
+        self.on_unsupported = os.environ.get("GRIM_ON_UNSUPPORTED", "raise")
+        self.unsupported = []
+        self.last_stats = {}
+        if config is None:
+            return
+        self.config = config
+        self.populations = config["pops"]
+        P = len(self.populations)
+        if P > nat.MAXPOP:
+            raise NotImplementedError("more than %d populations" % nat.MAXPOP)
+        self.unk_priors = config["UNK_priors"]
+        self.full_loci = config["full_loci"]
+        self.index_dict = dict(config["loci_map"])
+        if config.get("nodes_for_plan_A"):
+            raise NotImplementedError("Plan_A_Matrix is not supported by this build")
+        if config.get("save_mode"):
+            raise NotImplementedError("save_space_mode is not supported by this build")
+        if count_by_prob is None:  # impute.py:205-212
+            self.count_by_prob = np.ones(P)
+            if config["use_pops_count_file"]:
+                with open(config["pops_count_file"]) as fh:
+                    for i, line in enumerate(fh):
+                        self.count_by_prob[i] = float(line.strip().split(",")[2])
+        else:
+            self.count_by_prob = count_by_prob
+        self.plan = "a"
+        self.option_1 = 0
+        self.option_2 = 0
+        self._prior_cache = {}
+        self._priors = []
+
+    # ---- prior matrix: impute.py:1844-1924, evaluated once per distinct race pair -----------------
+    def _prior_matrix(self, race1, race2, priority):
+        P = len(self.populations)
+        base = np.ones((P, P)) if self.unk_priors == "MR" else np.identity(P)
+        if not (race1 or race2):
+            return base
+        list1 = race1.split(";")
+        list2 = race2.split(";")
+        known = False
+        for lst in (list1, list2):
+            for i, r in enumerate(lst):
+                if r in self.populations:
+                    known = True
+                else:
+                    lst[i] = ""
+        if not known:
+            return base
+        acc = np.zeros((P, P))
+        eye = np.identity(P)
+        g, al, de = priority["gamma"], priority["alpha"], priority["delta"]
+        for ra in list1:
+            for rb in list2:
+                if ra == "" and rb == "":
+                    continue
+                t = np.zeros((P, P))
+                if ra == "" or rb == "":
+                    r = self.populations.index(rb if ra == "" else ra)
+                    t[r, :] = t[r, :] + g * 2
+                    t = t + t.T
+                    t[r, r] -= g * 2
+                else:
+                    a, b = self.populations.index(ra), self.populations.index(rb)
+                    for i in range(P):  # row and column may overlap at (a,b): keep the scalar order
+                        t[a, i] = t[a, i] + g
+                        t[i, b] = t[i, b] + g
+                    t[a, b] -= g
+                    t[a, b] = t[a, b] + al
+                    if a != b:
+                        t = t + t.T
+                        t[a, a] -= g
+                        t[b, b] -= g
+                    t[a, a] += de
+                    if a != b:
+                        t[b, b] += de
+                t = priority["eta"] * np.ones((P, P)) + t + priority["beta"] * eye
+                acc += t
+        total = 0
+        for i in range(P):
+            for j in range(P):
+                acc[i][j] = acc[i][j] * self.count_by_prob[i] * self.count_by_prob[j]
+                total += acc[i][j]
+        return acc / total
+
+    def _prior_index(self, race1, race2, priority):
+        key = (race1, race2)
+        idx = self._prior_cache.get(key)
+        if idx is None:
+            m = self._prior_matrix(race1, race2, priority)
+            idx = len(self._priors)
+            if idx >= 65535:
+                raise OverflowError("more than 65535 distinct race pairs in one batch")
+            self._priors.append(np.ascontiguousarray(m, dtype=np.float64))
+            self._prior_cache[key] = idx
+        return idx
+
+    # ---- GL string -> integer tokens (impute.py:105-118, 246-272) ----------------------------------
+    def _tokenise(self, gl, planb):
+        """-> (kind, payload).  payload for _DEV: (n_loci, slots, same_mask, [(ids0, w0, ids1, w1)...])."""
+        g = self.netGraph
+        cleaned = clean_up_gl(gl)
+        if not gl:
+            return _PROBLEM_ID, None
+        if cleaned == "" or cleaned == " ":
+            return _PROBLEM_ID, None
+        side1, side2, blanks = [], [], 0
+        parts = cleaned.split("^")
+        for p in parts:
+            if p[0] == "+":  # IndexError for an empty entry -> caller's except -> raw line
+                p = p[1:]
+            two = p.split("+")
+            if len(two) == 1:
+                if two == [""]:
+                    blanks += 1
+                    continue
+                return _PROBLEM_ID, None
+            side1.append(two[0])
+            side2.append(two[1])
+        n = len(parts) - blanks
+        side1.sort()
+        side2.sort()
+        if n != len(side1) or n < 1 or n > len(self.full_loci):
+            raise ValueError("irregular GL string")
+        slots, same, pos, unknown_locus = [], 0, [], False
+        for k in range(n):
+            alts1, alts2 = side1[k].split("/"), side2[k].split("/")
+            loci = {a.split("*")[0] for a in alts1} | {a.split("*")[0] for a in alts2}
+            if len(loci) != 1:
+                raise ValueError("irregular GL string: mixed loci in one entry")
+            locus = loci.pop()
+            if locus not in g.locus_slot:
+                unknown_locus = True
+                continue
+            s = g.locus_slot[locus]
+            if s in slots:
+                raise ValueError("irregular GL string: locus given twice")
+            slots.append(s)
+            if side1[k] == side2[k]:
+                same |= 1 << k
+            ent = []
+            for alts in (alts1, alts2):
+                seen, ids = set(), []
+                for a in alts:
+                    if a not in seen:
+                        seen.add(a)
+                        ids.append(g.allele_id(s, a))
+                ent.append((ids, min(len(alts), 65535)))
+            pos.append(ent)
+        if unknown_locus:
+            # a locus name outside loci_map: Plan A cannot match, Plan B dies with KeyError in
+            # check_if_alleles_exist (impute.py:1218-1222) -> bare except -> raw line in .problem;
+            # without Plan B the subject is a plain miss.
+            if planb:
+                raise KeyError("locus not in loci_map")
+            return _MISS_NO_DEVICE, None
+        return _DEV, (n, slots, same, pos)
+
+    # ---- parameters ---------------------------------------------------------------------------------
+    def _params(self, config, planb, em_mr):
+        p = nat.Params()
+        eps = config["epsilon"]
+        ladder = []
+        while eps > 0:  # impute.py:1665-1673
+            eps /= 10
+            if eps < 1.0e-9:
+                eps = 0.0
+            ladder.append(eps)
+            if len(ladder) > nat.MAXLADDER:
+                raise NotImplementedError("epsilon ladder longer than %d steps" % nat.MAXLADDER)
+        for i, e in enumerate(ladder):
+            p.ladder[i] = e
+        p.n_ladder = len(ladder)
+        p.top_n = int(config["max_haplotypes_number_in_phase"])
+        if p.top_n > nat.TOPCAP:
+            raise NotImplementedError("max_haplotypes_number_in_phase > %d" % nat.TOPCAP)
+        p.opt_threshold = int(config["number_of_options_threshold"])
+        p.n_results = int(config["number_of_results"])
+        p.n_pop_results = int(config["number_of_pop_results"])
+        p.out_muug = 1 if config["output_MUUG"] else 0
+        p.out_haps = 1 if config["output_haplotypes"] else 0
+        p.planb = 1 if planb else 0
+        p.em_mr = 1 if em_mr else 0
+        order = sorted(range(len(self.populations)), key=lambda i: self.populations[i])
+        for rank, i in enumerate(order):
+            p.pop_rank[i] = rank
+        p.factor_missing = float(config["factor_missing_data"])
+        rows = config["matrix_planb"]
+        if len(rows) > nat.MAXROWS:
+            raise NotImplementedError("Plan_B_Matrix with more than %d rows" % nat.MAXROWS)
+        p.planb_rows = len(rows)
+        for r, row in enumerate(rows):
+            if len(row) > nat.MAXL:
+                raise NotImplementedError("Plan_B_Matrix row with more than %d blocks" % nat.MAXL)
+            p.planb_nblk[r] = len(row)
+            for b, blk in enumerate(row):
+                m = 0
+                for idx in blk:
+                    m |= 1 << self.full_loci.index(str(idx))
+                p.planb_blk[r][b] = m
+        return p
+
+    # ---- batch on the device --------------------------------------------------------------------------
+    def run_batch(self, records, config, planb, em_mr=False, keep=False):
+        """records: list of (n_loci, slots, same_mask, positions, prior_idx).  Returns (res, rows)."""
+        n = len(records)
+        subj = np.zeros(n, dtype=nat.SUBJECT_DT)
+        toks = []
+        off = 0
+        for i, (nl, slots, same, pos, pidx) in enumerate(records):
+            s = subj[i]
+            s["tok_off"] = off
+            s["prior_idx"] = pidx
+            s["n_loci"] = nl
+            s["pad"][0] = same
+            for k in range(nl):
+                s["slot"][k] = slots[k]
+                for side in range(2):
+                    ids, wid = pos[k][side]
+                    s["cnt"][k][side] = len(ids)
+                    s["wid"][k][side] = wid
+                    toks.extend(ids)
+                    off += len(ids)
+        tokens = np.array(toks if toks else [0], dtype=np.uint16)
+        priors = np.stack(self._priors) if self._priors else np.ones((1, len(self.populations), len(self.populations)))
+        ctx = nat.default_context(self.device)
+        dgraph = self.netGraph.device(ctx)
+        params = self._params(config, planb, em_mr)
+        batch = nat.DeviceBatch(ctx, dgraph, params, subj, tokens, priors)
+        t0 = timeit.default_timer()
+        batch.run()
+        t1 = timeit.default_timer()
+        res, rows = batch.results()
+        self.last_stats = {
+            "n": n, "run_s": t1 - t0, "kernel_ms": batch.kernel_ms(0), "kernel_a_ms": batch.kernel_ms(1),
+            "kernel_b_ms": batch.kernel_ms(2), "counters": batch.counters(),
+        }
+        if keep:
+            return res, rows, batch
+        batch.close()
+        return res, rows
+
+    # ---- formatting ------------------------------------------------------------------------------------
+    def _genotype(self, key_a, key_b):
+        """MUUG text of a haplotype pair (impute.py:497-504)."""
+        g = self.netGraph
+        a = sorted(x for x in g.key_alleles(key_a) if x)
+        b = sorted(x for x in g.key_alleles(key_b) if x)
+        return "^".join("+".join(sorted(z)) for z in zip(a, b))
+
+    def _hap_name(self, key):
+        return "~".join(sorted(x for x in self.netGraph.key_alleles(key) if x))
+
+    def _pop_name(self, idx, plan):
+        return "all_pops" if plan == ord("c") else self.populations[int(idx)]
+
+    # ---- reference-shaped per-subject API (impute.py:1940-1983) -----------------------------------------
+    def impute_one(self, subject_id, gl, binary, race1, race2, priority, epsilon, n, MUUG_output, haps_output,
+                   planb, em):
+        """Runs ONE subject through the device (a batch of one).  Returns (id, res_muugs, res_haps) in
+        the reference's dict shapes.  `number_of_results` style truncation is NOT applied here; the
+        dicts carry at most config['number_of_results'] best entries per table (the device ranks)."""
+        cfg = dict(self.config)
+        cfg["epsilon"] = epsilon
+        cfg["output_MUUG"] = MUUG_output
+        cfg["output_haplotypes"] = haps_output
+        self._prior_cache, self._priors = {}, []
+        kind, payload = self._tokenise(gl, planb)
+        if kind == _PROBLEM_ID:
+            return subject_id, None, None
+        res_m = {"MaxProb": 0, "Haps": {}, "Pops": {}}
+        res_h = {"Haps": [], "Probs": [], "Pops": []}
+        if kind == _MISS_NO_DEVICE:
+            return subject_id, res_m, res_h
+        pidx = self._prior_index(race1 or "", race2 or "", priority)
+        res, rows = self.run_batch([payload + (pidx,)], cfg, planb)
+        r = res[0]
+        if r["status"] == nat.ST_UNSUPPORTED:
+            raise UnsupportedSubjects([(0, subject_id, int(r["reason"]))])
+        plan = int(r["plan"])
+        self.plan = chr(plan) if plan else "a"
+        if MUUG_output:
+            res_m["MaxProb"] = float(r["max_prob"])
+            for row in rows[r["row_off"][nat.T_UMUG]: r["row_off"][nat.T_UMUG] + r["n_rows"][nat.T_UMUG]]:
+                res_m["Haps"][self._genotype(row["a"], row["b"])] = float(row["prob"])
+            for row in rows[r["row_off"][nat.T_UMUG_POPS]: r["row_off"][nat.T_UMUG_POPS] + r["n_rows"][nat.T_UMUG_POPS]]:
+                res_m["Pops"][self._pop_name(row["a"], plan) + "," + self._pop_name(row["b"], plan)] = float(row["prob"])
+        if haps_output:
+            res_h["MaxProb"] = float(r["max_prob"])
+            for row in rows[r["row_off"][nat.T_PMUG]: r["row_off"][nat.T_PMUG] + r["n_rows"][nat.T_PMUG]]:
+                res_h["Haps"].append([self._hap_name(row["a"]), self._hap_name(row["b"])])
+                res_h["Probs"].append(float(row["prob"]))
+                res_h["Pops"].append([self._pop_name(row["popa"], plan), self._pop_name(row["popb"], plan)])
+        return subject_id, res_m, res_h
+
+    # ---- file driver (impute.py:1985-2155) ---------------------------------------------------------------
+    def impute_file(self, config, planb=None, em_mr=False, em=False):
+        priority = config["priority"]
+        muug_on = config["output_MUUG"]
+        haps_on = config["output_haplotypes"]
+        if planb is None:
+            planb = config["planb"]
+        if os.path.isfile(config["bin_imputation_input_file"]):
+            raise NotImplementedError("bin_imputation_in_file (phase masks) is not supported by this build")
+        if not config["epsilon"] > 0:
+            raise NotImplementedError("epsilon <= 0: the reference returns its 'NaN' sentinel and fails every subject")
+        self._prior_cache, self._priors = {}, []
+        self.unsupported = []
+
+        with open(config["imputation_input_file"], "r") as fh:
+            lines = fh.readlines()
+
+        outcome = []  # per line: (kind, subject_id, raw line, device index)
+        records = []
+        for i, raw in enumerate(lines):
+            line = raw.rstrip()
+            sid = None
+            try:
+                parts = line.split(",") if "," in line else line.split("%")
+                sid = parts[0]
+                gl = parts[1]
+                race1 = race2 = None
+                if len(parts) > 2:
+                    race1, race2 = parts[2], parts[3]
+                pidx = self._prior_index(race1 or "", race2 or "", priority) if (race1 or race2) else self._prior_index("", "", priority)
+                kind, payload = self._tokenise(gl, planb)
+                if kind == _DEV:
+                    outcome.append((_DEV, sid, line, len(records)))
+                    records.append(payload + (pidx,))
+                else:
+                    outcome.append((kind, sid, line, -1))
+            except Exception:  # the reference's bare except (impute.py:2141-2144)
+                outcome.append((_PROBLEM_RAW, sid, line, -1))
+
+        start = timeit.default_timer()
+        if records:
+            res, rows = self.run_batch(records, config, planb, em_mr)
+        else:
+            res, rows = np.zeros(0, dtype=nat.RESULT_DT), np.zeros(0, dtype=nat.ROW_DT)
+        per_subject = (timeit.default_timer() - start) / max(1, len(records))
+
+        bad = [(i, outcome[i][1], int(res[outcome[i][3]]["reason"])) for i in range(len(outcome))
+               if outcome[i][0] == _DEV and res[outcome[i][3]]["status"] == nat.ST_UNSUPPORTED]
+        self.unsupported = bad
+        if bad and self.on_unsupported == "raise":
+            raise UnsupportedSubjects(bad)
+        skip = {i for i, _, _ in bad}
+
+        out = {}
+        if muug_on:
+            out["umug"] = open(config["imputation_out_umug_freq_file"], "w")
+            out["umug_pops"] = open(config["imputation_out_umug_pops_file"], "w")
+        if haps_on:
+            out["pmug"] = open(config["imputation_out_hap_freq_file"], "w")
+            out["pmug_pops"] = open(config["imputation_out_hap_pops_file"], "w")
+        miss = open(config["imputation_out_miss_file"], "w")
+        problem = open(config["imputation_out_problem_file"], "w")
+        say = (lambda *a: None) if self.quiet else print
+        try:
+            for i, (kind, sid, line, di) in enumerate(outcome):
+                if i in skip:
+                    continue
+                if kind == _PROBLEM_RAW:
+                    say(f"{i} Subject: {sid} - Exception")
+                    problem.write(str(line) + "\n")
+                    continue
+                if kind == _PROBLEM_ID:
+                    problem.write(str(i) + "," + str(sid) + "\n")
+                    continue
+                if kind == _MISS_NO_DEVICE:
+                    n_pairs = n_geno = 0
+                    r = None
+                else:
+                    r = res[di]
+                    n_pairs = int(r["n_pairs"]) if haps_on else 0
+                    n_geno = int(r["n_genotypes"]) if muug_on else 0
+                # impute.py:2065-2068 -- with output_haplotypes off res_haps["Haps"] is the 3-char
+                # placeholder "Nan", whose len() is not 0, so .miss is never written then
+                if haps_on and n_pairs == 0 and n_geno == 0:
+                    miss.write(str(i) + "," + str(sid) + "\n")
+                plan = int(r["plan"]) if r is not None else ord("a")
+                if haps_on:
+                    say("{index} Subject: {id} {hap_length} haplotypes".format(index=i, id=sid, hap_length=n_pairs))
+                    if r is not None:
+                        self._write_rows(out["pmug"], sid, rows, r, nat.T_PMUG, plan, em_mr)
+                        self._write_rows(out["pmug_pops"], sid, rows, r, nat.T_PMUG_POPS, plan, em_mr)
+                if muug_on:
+                    say("{index} Subject: {id} {hap_length} haplotypes".format(index=i, id=sid, hap_length=n_geno))
+                    if r is not None:
+                        self._write_rows(out["umug"], sid, rows, r, nat.T_UMUG, plan, em_mr)
+                        self._write_rows(out["umug_pops"], sid, rows, r, nat.T_UMUG_POPS, plan, em_mr)
+                say(per_subject)
+        finally:
+            for fh in out.values():
+                fh.close()
+            miss.close()
+            problem.close()
+
+    def _write_rows(self, fh, sid, rows, r, table, plan, em_mr):
+        a0 = int(r["row_off"][table])
+        for k in range(int(r["n_rows"][table])):
+            row = rows[a0 + k]
+            prob = float(row["prob"])
+            if table == nat.T_UMUG:
+                text = self._genotype(row["a"], row["b"])
+            elif table == nat.T_PMUG:
+                if em_mr:  # write_best_hap_race_pairs, impute.py:79-99
+                    text = (self._hap_name(row["a"]) + ";" + self._pop_name(row["popa"], plan) + "," +
+                            self._hap_name(row["b"]) + ";" + self._pop_name(row["popb"], plan))
+                else:
+                    text = self._hap_name(row["a"]) + "+" + self._hap_name(row["b"])
+            else:
+                text = self._pop_name(row["a"], plan) + "," + self._pop_name(row["b"], plan)
+            fh.write(sid + "," + text + "," + str(prob) + "," + str(k) + "\n")

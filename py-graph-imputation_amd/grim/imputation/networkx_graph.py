@@ -1,0 +1,216 @@
+"""
+Graph store for the MI355X engine: nodes.csv / top_links.csv / edges.csv -> integer-encoded CSR
+arrays that live in HBM.
+
+Same public surface as the reference's grim/imputation/networkx_graph.py (`Graph(config)`,
+`build_graph(nodes, top_links, edges)`), different representation:
+
+  reference (networkx_graph.py)                          here
+  ---------------------------------------------------   -----------------------------------------
+  Vertices_attributes[name] -> (label, freqs, id) :53   64-bit key = sum((allele_id+1) << 12*slot),
+                                                         open-addressing index built by the library
+  Edges / Neighbors_start (plan A)             :136-207  a_nbr / a_start   (uint32 CSR)
+  Whole_* with "label+name" connector nodes    :91-130   b_conn[node][added slot] -> connector,
+                                                         b_start / b_nbr   (uint32 CSR)
+  haps_by_label (O(V) scan, memoised)          :215-236  lab_start / lab_nodes (nodes grouped by label)
+
+The reference's row-start construction is reproduced exactly, including its two quirks
+(:157-198): vertices without out-edges copy the previous row start, and the closing sentinel is
+the vertex count instead of the edge count (so the highest-numbered vertex loses its neighbours).
+"""
+
+import csv
+
+import numpy as np
+
+from .. import _native as nat
+
+
+def _row_starts(src_sorted, n_vertices):
+    """Vectorised restatement of networkx_graph.py:157-198 (see module docstring)."""
+    uniq, first = np.unique(src_sorted, return_index=True)
+    starts = np.zeros(n_vertices + 1, dtype=np.int64)
+    if len(uniq) == 0 or int(uniq[-1]) != n_vertices - 1:
+        # the reference indexes past the end of `unique_values` here and dies with IndexError
+        raise IndexError("graph: the highest-numbered vertex has no out-edges (reference cannot load this graph either)")
+    has = np.zeros(n_vertices, dtype=bool)
+    has[uniq] = True
+    val = np.zeros(n_vertices, dtype=np.int64)
+    val[uniq] = first
+    # forward fill: a vertex without out-edges takes the previous vertex's start (0 at the front)
+    idx = np.where(has, np.arange(n_vertices), -1)
+    idx = np.maximum.accumulate(idx)
+    starts[:n_vertices] = np.where(idx >= 0, val[np.maximum(idx, 0)], 0)
+    starts[n_vertices] = n_vertices  # QUIRK: sentinel = len(Vertices)
+    return starts.astype(np.uint32)
+
+
+class Graph(object):
+    def __init__(self, config):
+        self.full_loci = config["full_loci"]
+        if config.get("nodes_for_plan_A"):
+            raise NotImplementedError("Plan_A_Matrix (reduced-label graphs) is not supported by this build")
+        loci_map = config["loci_map"]
+        # locus name -> slot; slot s <-> label character full_loci[s]
+        self.locus_slot = {}
+        for name, val in loci_map.items():
+            self.locus_slot[name] = self.full_loci.index(str(val))
+        self.slot_locus = [None] * len(self.full_loci)
+        for name, s in self.locus_slot.items():
+            self.slot_locus[s] = name
+        if len(self.full_loci) > nat.MAXL:
+            raise NotImplementedError("more than %d loci" % nat.MAXL)
+        # Candidate names are built from the subject's alleles in sorted STRING order
+        # (impute.py:271) while graph names are in loci_map index order; they only ever match when
+        # the two orders agree.  This build requires that.
+        by_name = sorted(self.locus_slot, key=lambda n: n + "*")
+        if [self.locus_slot[n] for n in by_name] != sorted(self.locus_slot.values()):
+            raise NotImplementedError(
+                "loci_map order differs from the alphabetical locus order; the reference finds no "
+                "haplotypes in that configuration and this build refuses it")
+        self.allele_ids = [dict() for _ in self.full_loci]  # per slot: allele string -> id
+        self.allele_names = [list() for _ in self.full_loci]
+        self.arrays = None
+        self._dev = {}
+
+    # ------------------------------------------------------------------------------------------
+    def allele_id(self, slot, allele, create=True):
+        d = self.allele_ids[slot]
+        i = d.get(allele)
+        if i is None and create:
+            i = len(self.allele_names[slot])
+            if i >= (1 << nat.ABITS) - 2:
+                raise OverflowError("more than %d alleles at locus %s" % ((1 << nat.ABITS) - 2, self.slot_locus[slot]))
+            d[allele] = i
+            self.allele_names[slot].append(allele)
+        return i
+
+    def key_to_name(self, key):
+        parts = []
+        for s in range(len(self.full_loci)):
+            a = (int(key) >> (nat.ABITS * s)) & 0xFFF
+            if a:
+                parts.append(self.allele_names[s][a - 1])
+        return "~".join(parts)
+
+    def key_alleles(self, key):
+        out = []
+        for s in range(len(self.full_loci)):
+            a = (int(key) >> (nat.ABITS * s)) & 0xFFF
+            out.append(self.allele_names[s][a - 1] if a else None)
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    def build_graph(self, nodesFile, edgesFile, allEdgesFile):
+        """nodesFile = nodes.csv, edgesFile = top_links.csv, allEdgesFile = edges.csv
+        (argument names as in networkx_graph.py:42)."""
+        nl = len(self.full_loci)
+        ids, keys, masks, freqs = [], [], [], []
+        id_to_row = {}
+        with open(nodesFile) as fh:
+            rd = csv.reader(fh)
+            next(rd)
+            for row in rd:
+                if not row:
+                    continue
+                key = 0
+                mask = 0
+                for al in row[1].split("~"):
+                    s = self.locus_slot[al.split("*")[0]]
+                    key |= (self.allele_id(s, al) + 1) << (nat.ABITS * s)
+                lab_mask = 0
+                for ch in row[2]:
+                    lab_mask |= 1 << self.full_loci.index(ch)
+                for s in range(nl):
+                    if (key >> (nat.ABITS * s)) & 0xFFF:
+                        mask |= 1 << s
+                if mask != lab_mask:
+                    raise ValueError("node %s: alleles do not match its label %s" % (row[1], row[2]))
+                id_to_row[row[0]] = len(keys)
+                keys.append(key)
+                masks.append(mask)
+                freqs.append([float(x) for x in row[3].split(";")])
+        V = len(keys)
+        node_key = np.array(keys, dtype=np.uint64)
+        node_mask = np.array(masks, dtype=np.uint8)
+        freq = np.ascontiguousarray(np.array(freqs, dtype=np.float64))
+        P = freq.shape[1]
+        full_mask = (1 << nl) - 1
+        nbits = np.array([bin(m).count("1") for m in range(1 << nl)], dtype=np.int64)
+
+        def read_pairs(path):
+            a, b = [], []
+            with open(path) as fh:
+                rd = csv.reader(fh)
+                next(rd)
+                for row in rd:
+                    if row:
+                        a.append(id_to_row[row[0]])
+                        b.append(id_to_row[row[1]])
+            return np.array(a, dtype=np.int64), np.array(b, dtype=np.int64)
+
+        # plan A: partial -> full (networkx_graph.py:71-88)
+        n1, n2 = read_pairs(edgesFile)
+        flip = node_mask[n1] == full_mask
+        src = np.where(flip, n2, n1)
+        dst = np.where(flip, n1, n2)
+        order = np.lexsort((dst, src))
+        src, dst = src[order], dst[order]
+        a_start = _row_starts(src, V)
+        a_nbr = dst.astype(np.uint32)
+
+        # plan B: child -> connector(parent label, child) -> parents (networkx_graph.py:91-130)
+        n1, n2 = read_pairs(allEdgesFile)
+        first_is_child = nbits[node_mask[n1]] < nbits[node_mask[n2]]
+        child = np.where(first_is_child, n1, n2)
+        parent = np.where(first_is_child, n2, n1)
+        pmask = node_mask[parent].astype(np.int64)
+        conn_key = child * 64 + pmask
+        # connector ids in order of first appearance, after the V real vertices
+        uniq, first_pos, inv = np.unique(conn_key, return_index=True, return_inverse=True)
+        rank = np.empty(len(uniq), dtype=np.int64)
+        rank[np.argsort(first_pos, kind="stable")] = np.arange(len(uniq))
+        conn = rank[inv]
+        ncon = len(uniq)
+        w_src = np.concatenate([child, V + conn])
+        w_dst = np.concatenate([V + conn, parent])
+        w = np.unique(np.stack([w_src, w_dst], axis=1), axis=0)  # drop_duplicates + lexsort
+        w_start = _row_starts(w[:, 0], V + ncon)
+        b_start = np.ascontiguousarray(w_start[V:])
+        b_nbr = w[:, 1].astype(np.uint32)
+        added = pmask & ~node_mask[child].astype(np.int64)
+        if np.any(nbits[added] != 1):
+            raise NotImplementedError("edges.csv holds a parent that is not exactly one locus larger than its child")
+        slot_added = np.log2(added).astype(np.int64)
+        b_conn = np.full(V * nat.MAXL, 0xFFFFFFFF, dtype=np.uint32)
+        b_conn[child * nat.MAXL + slot_added] = conn.astype(np.uint32)
+
+        lab_order = np.argsort(node_mask, kind="stable").astype(np.uint32)
+        counts = np.bincount(node_mask, minlength=1 << nat.MAXL)[: 1 << nat.MAXL]
+        lab_start = np.zeros((1 << nat.MAXL) + 1, dtype=np.uint32)
+        lab_start[1:] = np.cumsum(counts)
+
+        self.arrays = {
+            "n_nodes": V, "n_pops": P, "n_loci": nl, "full_mask": full_mask,
+            "node_key": node_key, "node_mask": node_mask, "freq": freq,
+            "a_start": a_start, "a_nbr": a_nbr,
+            "b_conn": b_conn, "b_start": b_start, "b_nbr": b_nbr,
+            "lab_start": lab_start, "lab_nodes": lab_order,
+        }
+        self.n_graph_alleles = [len(x) for x in self.allele_names]
+        self._dev = {}
+        return self
+
+    # ------------------------------------------------------------------------------------------
+    def device(self, ctx):
+        """Upload once per context; the handle keeps the HBM copy alive."""
+        if self.arrays is None:
+            raise RuntimeError("Graph.build_graph has not been called")
+        dg = self._dev.get(id(ctx))
+        if dg is None:
+            dg = nat.DeviceGraph(ctx, self.arrays)
+            self._dev[id(ctx)] = dg
+        return dg
+
+    def host_bytes(self):
+        return sum(v.nbytes for v in self.arrays.values() if isinstance(v, np.ndarray))
