@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""
+bench.py -- imputed subjects/sec on the CAU 5-locus graph (BASELINE.json metric).
+
+A step = one pass of the grim.impute hot path (plan A kernel, plan B/C kernel when subjects need
+it) over one batch of synthetic subjects that is already resident in HBM.  N=1 workload:
+BASELINE.json configs[1] -- 10k fully typed synthetic subjects, seed 0.  N>1: weak scaling, every
+rank owns its own 10k-subject batch (seed = rank), graph replicated per GPU, no data-path
+collective; the timed region is bracketed by barrier + device sync and the max over ranks counts.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--subjects", type=int, default=10000, help="subjects per GPU (config 2: 10000)")
+    ap.add_argument("--workload", default="full", choices=["full", "mixed"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ["GRIM_QUIET"] = "1"
+
+    import __graft_entry__ as ge
+    ge.build()
+    import harness
+    import synth
+    from grim import _native as nat
+    from grim.imputation.impute import Imputation, _DEV
+    from grim.imputation.networkx_graph import Graph
+    from grim.run_impute_def import load_config
+
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        have_gpu = nat.lib().grim_device_count() > 0
+        if have_gpu:
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl" if have_gpu else "gloo")
+
+    # ---- graph + subjects (host work, outside the timed region) -----------------------------------
+    if rank == 0:
+        work = harness.ensure_graph("cau")
+    if dist is not None:
+        dist.barrier()
+    work = harness.ensure_graph("cau")
+    conf = harness.base_conf(["CAU"])
+    cpath = os.path.join(work, "conf_bench_%d.json" % rank)
+    json.dump(conf, open(cpath, "w"))
+    os.chdir(work)
+    cfg, _ = load_config(cpath)
+    graph = Graph(cfg).build_graph(cfg["node_file"], cfg["top_links_file"], cfg["edges_file"])
+    rows = synth.read_freqs(synth.CAU_FREQS)
+    gen = synth.SubjectGen(rows, rank)  # seed 0 on rank 0 = config 2
+    lines = gen.full(args.subjects) if args.workload == "full" else gen.mixed(args.subjects)
+    imp = Imputation(graph, cfg, device=local_rank)
+    records, n_tok = [], 0
+    for line in lines:
+        parts = line.split(",")
+        pidx = imp._prior_index(parts[2], parts[3], cfg["priority"])
+        kind, payload = imp._tokenise(parts[1], cfg["planb"])
+        assert kind == _DEV
+        records.append(payload + (pidx,))
+        n_tok += sum(len(ids) for pos in payload[3] for ids, _ in pos)
+    res, rows_out, batch = imp.run_batch(records, cfg, cfg["planb"], keep=True)  # upload + first run
+    n_ok = int((res["status"] == nat.ST_OK).sum())
+
+    def sync_barrier():
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        batch.run()
+    sync_barrier()
+    t0 = time.perf_counter()
+    k_ms = []
+    for _ in range(args.steps):
+        batch.run()  # enqueues the kernels and waits for the stream (device sync)
+        k_ms.append(batch.kernel_ms(0))
+    sync_barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    ctr = batch.counters()  # probes, CSR neighbour ids, frequency vectors gathered, output rows
+    P = len(cfg["pops"])
+    # B_subj = B_in + sum_sides(16 q + 4 nbr + 8 P c) + 24 B_rows ; B_in = 4 + 2/token + 4
+    algo_bytes = (8 * len(records) + 2 * n_tok) + 16 * ctr[0] + 4 * ctr[1] + 8 * P * ctr[2] + 24 * ctr[3]
+    avg_ms = sum(k_ms) / len(k_ms)
+    achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "imputed subjects/sec (whole node), 5-locus CAU graph",
+            "value": world * len(records) * args.steps / elapsed,
+            "unit": "subjects/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "CAU 5-locus graph, %d synthetic %s subjects per GPU, seed=rank (BASELINE configs[1])"
+                            % (args.subjects, "fully-typed" if args.workload == "full" else "mixed"),
+                "subjects_per_gpu": len(records), "subjects_with_results": n_ok,
+                "graph_nodes": int(graph.arrays["n_nodes"]), "populations": P,
+                "inputs": "tokenised subjects resident in HBM; results left in HBM",
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "grim_plan_a_kernel", "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": algo_bytes,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            sample = lines + synth.SubjectGen(rows, 1000).full(args.subjects if args.workload == "full" else 0)
+            if args.workload != "full":
+                sample = lines[: min(len(lines), 2000)]
+            t1 = time.perf_counter()
+            harness.run_oracle("cau", conf, sample, tag="bench_cpu")
+            dt = time.perf_counter() - t1
+            out["cpu_baseline"] = {
+                "value": len(sample) / dt, "unit": "subjects/s", "cores": 1, "kind": "port",
+                "sample": "%d subjects of the same generator through oracle/grim_oracle.py (single-thread Python "
+                          "restatement of the reference), %.1f s" % (len(sample), dt),
+            }
+        print(json.dumps(out))
+    batch.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

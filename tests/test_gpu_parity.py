@@ -1,0 +1,116 @@
+"""GPU parity: the HIP path (through the C-ABI) against the reference's golden outputs, against the
+oracle on seeded inputs, and through size-independent properties at BASELINE.json's full size."""
+import os
+
+import numpy as np
+import pytest
+
+import harness
+import synth
+
+pytestmark = pytest.mark.gpu
+
+# probabilities: bit-exact is the target and what is asserted (string equality of repr());
+# BASELINE.json's tolerance is 1e-6 relative, ids and ranking exact.
+STRICT = os.environ.get("GRIM_ON_UNSUPPORTED", "raise") == "raise"
+
+
+def _run(gname, conf, lines, tag, em=False):
+    mode = "raise" if STRICT else "skip"
+    got, glog, imp = harness.run_product(gname, conf, lines, tag=tag, em_mr=em, on_unsupported=mode)
+    return got, glog, imp
+
+
+@pytest.mark.parametrize("scenario", harness.scenarios())
+def test_golden_scenarios(scenario):
+    gname, conf, lines, exp, elog, em = harness.golden(scenario)
+    got, glog, imp = _run(gname, conf, lines, "t_" + scenario, em)
+    skipped = [sid for _, sid, _ in imp.unsupported]
+    exp = harness.drop_subjects(exp, skipped)
+    for k in exp:
+        assert got[k] == exp[k], "%s: %s differs from the reference output" % (scenario, k)
+    if not skipped:
+        assert glog == elog
+
+
+def _against_oracle(gname, conf, lines, tag):
+    got, glog, imp = _run(gname, conf, lines, tag)
+    exp, elog = harness.run_oracle(gname, conf, lines, tag=tag + "_orc")
+    skipped = [sid for _, sid, _ in imp.unsupported]
+    exp = harness.drop_subjects(exp, skipped)
+    for k in exp:
+        assert got[k] == exp[k], "%s: %s differs from the oracle" % (tag, k)
+    return imp
+
+
+def test_seeded_full_vs_oracle():
+    rows = synth.read_freqs(synth.CAU_FREQS)
+    _against_oracle("cau", harness.base_conf(["CAU"]), synth.SubjectGen(rows, 21).full(3000), "r_full")
+
+
+def test_seeded_mixed_vs_oracle():
+    rows = synth.read_freqs(synth.CAU_FREQS)
+    _against_oracle("cau", harness.base_conf(["CAU"]), synth.SubjectGen(rows, 22).mixed(500), "r_mixed")
+
+
+def test_seeded_pop4_vs_oracle():
+    rows = synth.read_freqs(synth.CAU_FREQS)
+    conf = harness.base_conf(harness.POPS["pop4"])
+    conf["UNK_priors"] = "MR"
+    _against_oracle("pop4", conf, synth.SubjectGen(rows, 23, pops=harness.POPS["pop4"]).mixed(500), "r_pop4")
+
+
+def test_high_ambiguity_both_branches_vs_oracle():
+    rows = synth.read_freqs(synth.CAU_FREQS)
+    lines = synth.SubjectGen(rows, 24).high_ambiguity(6, width=5)
+    conf = harness.base_conf(["CAU"])
+    _against_oracle("cau", conf, lines, "r_amb_open")           # 5^5 < 1e5: cartesian opening
+    conf2 = dict(conf, number_of_options_threshold=500)
+    _against_oracle("cau", conf2, lines, "r_amb_filter")        # label scan
+
+
+def test_config2_full_size_properties():
+    """BASELINE config 2: 10k fully typed subjects.  Size-independent properties."""
+    rows = synth.read_freqs(synth.CAU_FREQS)
+    lines = synth.SubjectGen(rows, 0).full(10000)
+    conf = harness.base_conf(["CAU"])
+    got, glog, imp = _run("cau", conf, lines, "c2")
+    assert got["miss"] == "" and got["problem"] == ""
+    umug = [l.split(",") for l in got["umug"].splitlines()]
+    pmug = [l.split(",") for l in got["pmug"].splitlines()]
+    ids = [l.split(",")[0] for l in lines]
+    assert [u[0] for u in umug] == ids                       # exactly one MUUG per subject, input order
+    assert all(u[3] == "0" for u in umug)
+    by = {}
+    for p in pmug:
+        by.setdefault(p[0], []).append(float(p[2]))
+    for u in umug:
+        ps = by[u[0]]
+        assert ps == sorted(ps, reverse=True)                # ranked
+        if len(ps) < 10:                                     # all phased pairs listed: they add up to the MUUG
+            assert abs(sum(ps) - float(u[2])) <= 1e-12 * float(u[2])
+    # idempotence and order independence
+    perm = np.random.default_rng(5).permutation(len(lines))
+    got2, _, _ = _run("cau", conf, [lines[i] for i in perm], "c2p")
+    a = sorted(got["umug"].splitlines())
+    b = sorted(got2["umug"].splitlines())
+    assert a == b
+    assert sorted(got["pmug"].splitlines()) == sorted(got2["pmug"].splitlines())
+    # a 2000-subject slice against the oracle
+    exp, _ = harness.run_oracle("cau", conf, lines[:2000], tag="c2_orc")
+    n_u = len(exp["umug"].splitlines())
+    assert got["umug"].splitlines()[:n_u] == exp["umug"].splitlines()
+
+
+def test_reference_shaped_impute_one():
+    from grim.imputation.impute import Imputation
+
+    work = harness.ensure_graph("cau")
+    conf = harness.base_conf(["CAU"])
+    got, glog, imp = _run("cau", conf, ["S0,A*01:01+A*02:01^B*08:01+B*07:02^C*07:01+C*07:02^DQB1*02:01+DQB1*06:02^DRB1*03:01+DRB1*15:01,CAU,CAU"], "one")
+    cfg = imp.config
+    sid, res_m, res_h = imp.impute_one("S0", "A*01:01+A*02:01^B*08:01+B*07:02^C*07:01+C*07:02^DQB1*02:01+DQB1*06:02^DRB1*03:01+DRB1*15:01",
+                                       [1, 1, 1, 1], "CAU", "CAU", cfg["priority"], cfg["epsilon"], 1000, True, True, True, False)
+    line = got["umug"].splitlines()[0].split(",")
+    assert list(res_m["Haps"].keys())[0] == line[1] and str(list(res_m["Haps"].values())[0]) == line[2]
+    assert len(res_h["Haps"]) == len(got["pmug"].splitlines())
