@@ -83,7 +83,8 @@ typedef struct {
   uint32_t n_pop_results;  /* number_of_pop_results          */
   uint8_t out_muug, out_haps, planb, em_mr;
   uint8_t pop_rank[GRIM_MAXPOP]; /* rank of each population NAME in sorted order (impute.py:535) */
-  double factor_missing;   /* factor_missing_data */
+  double factor_missing_pow[GRIM_MAXL + 1]; /* factor_missing_data ** k for k = 0..5, evaluated by the
+                                               host exactly as the reference does (impute.py:1168) */
   /* Plan_B_Matrix: row r has planb_nblk[r] blocks; block b is a locus-slot bitmask */
   uint8_t planb_rows;
   uint8_t planb_nblk[GRIM_MAXROWS];

@@ -13,6 +13,7 @@
 #define GRIM_NONE 0xFFFFFFFFu
 #define GRIM_VALID 0x8000000000000000ull
 #define GRIM_SIDES (2 * GRIM_MAXPH)
+#define GRIM_COMP_CAP 8192  // >= 2 * GRIM_SIDES * GRIM_TOPCAP
 
 // ---- graph as the kernels see it --------------------------------------------------------------
 struct DevGraph {
@@ -36,7 +37,7 @@ struct SlotLayout {
   uint64_t gsum, ghead, gstart, gcnt;  // groups [pair_cap(+1)]
   uint64_t qsum, qfirst;               // population-pair cells [P*P]
   uint64_t bset;                       // plan-B block sets (node ids) [GRIM_NWAVE][GRIM_MAXL][bset_cap]
-  uint64_t comp;                       // plan-B composite haplotype keys [GRIM_SIDES*GRIM_TOPCAP]
+  uint64_t comp;                       // plan-B/C canonical haplotype table: open-addressing keys [GRIM_COMP_CAP]
   uint64_t stride;                     // bytes per slot
 };
 
@@ -46,6 +47,7 @@ struct DevArgs {
   const grim_subject *subj;
   const uint16_t *tok;
   const double *priors;
+  uint32_t ones_prior;    // index of the all-ones prior matrix (impute.py:1696-1700)
   const uint32_t *order;  // subject indices this launch works on
   uint32_t n_work;
   uint32_t *queue;        // dynamic work counter
@@ -169,9 +171,11 @@ struct WaveTop {
   uint64_t sk[256];
   uint64_t tie[256];
   double p[256];
+  uint64_t aux[256];  // 60-bit haplotype key of the entry (plan B/C: composite haplotypes)
   uint32_t hap[256];
   uint32_t cstart[66];
   uint32_t cnode[64];
+  uint64_t caux[64];
 };
 
 struct TopState {
@@ -196,6 +200,7 @@ __device__ __forceinline__ void wave_sort(WaveTop &L, int N) {
           L.tie[lo] = tb; L.tie[hi] = ta;
           double pa = L.p[lo]; L.p[lo] = L.p[hi]; L.p[hi] = pa;
           uint32_t ha = L.hap[lo]; L.hap[lo] = L.hap[hi]; L.hap[hi] = ha;
+          uint64_t xa = L.aux[lo]; L.aux[lo] = L.aux[hi]; L.aux[hi] = xa;
         }
       }
       WAVE_SYNC();
@@ -227,7 +232,7 @@ __device__ __forceinline__ void top_flush(WaveTop &L, TopState &st) {
 
 // push one candidate entry per lane (active = this lane has one); wave-uniform control flow
 __device__ __forceinline__ void top_push(WaveTop &L, TopState &st, bool active, double p, double key, uint64_t tie,
-                                         uint32_t hap) {
+                                         uint32_t hap, uint64_t aux = 0) {
   uint64_t ord = f64_ord(key);
   bool adm = active && (!st.full || ord > st.thr);
   uint64_t m = __ballot(adm);
@@ -238,6 +243,7 @@ __device__ __forceinline__ void top_push(WaveTop &L, TopState &st, bool active, 
     L.tie[pos] = tie;
     L.p[pos] = p;
     L.hap[pos] = hap;
+    L.aux[pos] = aux;
   }
   st.nbuf += __popcll(m);
   WAVE_SYNC();

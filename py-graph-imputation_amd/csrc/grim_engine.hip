@@ -287,7 +287,12 @@ extern "C" grim_batch *grim_batch_upload(grim_ctx *c, const grim_graph *g, const
   uint64_t bytes = 0;
   A.subj = upload(c, b->bufs, d->subjects, d->n_subjects, &bytes);
   A.tok = upload(c, b->bufs, d->tokens, d->n_tokens, &bytes);
-  A.priors = upload(c, b->bufs, d->priors, (size_t)d->n_priors * P * P, &bytes);
+  {  // the batch's prior matrices + one all-ones matrix for Plan B's second level (impute.py:1696-1700)
+    std::vector<double> pr((size_t)(d->n_priors + 1) * P * P, 1.0);
+    if (d->n_priors) memcpy(pr.data(), d->priors, sizeof(double) * (size_t)d->n_priors * P * P);
+    A.priors = upload(c, b->bufs, pr.data(), pr.size(), &bytes);
+    A.ones_prior = d->n_priors;
+  }
   std::vector<uint32_t> order(d->n_subjects);
   for (uint32_t i = 0; i < d->n_subjects; ++i) order[i] = i;
   A.order = upload(c, b->bufs, order.data(), d->n_subjects, &bytes);
@@ -342,7 +347,7 @@ extern "C" grim_batch *grim_batch_upload(grim_ctx *c, const grim_graph *g, const
   L.qsum = take(8ull * P * P);
   L.qfirst = take(4ull * P * P);
   L.bset = take(4ull * GRIM_NWAVE * GRIM_MAXL * (uint64_t)A.bset_cap);
-  L.comp = take(8ull * GRIM_SIDES * GRIM_TOPCAP);
+  L.comp = take(8ull * GRIM_COMP_CAP);
   L.stride = align256(o);
   A.scratch = upload<uint8_t>(c, b->bufs, nullptr, (size_t)L.stride * slots, &bytes);
   bool ok = A.subj && A.tok && A.priors && A.order && A.queue && A.next_list && A.res && A.counters && A.rows && A.scratch;

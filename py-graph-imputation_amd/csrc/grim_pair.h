@@ -82,7 +82,7 @@ __device__ __forceinline__ Slot make_slot(const DevArgs &A, uint32_t slot_idx) {
 #define HAP_COMPOSITE 0x800000u
 
 __device__ __forceinline__ uint64_t hap_key(const DevGraph &g, const Slot &S, uint32_t hap) {
-  return (hap & HAP_COMPOSITE) ? S.comp[hap & 0x7FFFFFu] : g.node_key[hap];
+  return (hap & HAP_COMPOSITE) ? (S.comp[hap & 0x7FFFFFu] & ~GRIM_VALID) : g.node_key[hap];
 }
 
 struct PairRef {

@@ -34,52 +34,60 @@ __device__ inline void enumerate_phases(WgShared &sh) {
   __syncthreads();
 }
 
-// Expand the chunk of <=64 found nodes held one per lane (GRIM_NONE = nothing) into (hap, pop)
-// entries and push them through the running top-K.  `full_nodes`: the nodes are full haplotypes
-// themselves (no neighbour gather).
-__device__ __forceinline__ void expand_chunk(const DevArgs &A, const double *prior, WaveTop &L, TopState &st, uint32_t node,
-                                             bool full_nodes, uint64_t &item_base, uint64_t &c_nbr, uint64_t &c_freq) {
+// Expand the chunk of <=64 look-up hits held one per lane into (hap, pop) entries and push them
+// through the running top-K.  DIRECT: `src` is the haplotype node itself; otherwise `src` is a CSR
+// row (plan A: a partial node's top links; plan B: a connector's parents) and every neighbour is
+// a haplotype.  AUX: entries carry the 60-bit key node_key | L.caux[owner] and p is scaled.
+template <bool AUX>
+__device__ __forceinline__ void expand_chunk(const DevArgs &A, const double *prior, WaveTop &L, TopState &st, uint32_t src,
+                                             bool direct, const uint32_t *csr_start, const uint32_t *csr_nbr, double scale,
+                                             uint64_t aux_or, uint64_t &item_base, uint64_t &c_nbr, uint64_t &c_freq) {
   const DevGraph &g = A.g;
   const int lane = lane_id();
   const int P = g.P;
   uint32_t cnt = 0;
-  if (node != GRIM_NONE) cnt = full_nodes ? 1u : nbr_count(g.a_start, node);
+  if (src != GRIM_NONE) cnt = direct ? 1u : nbr_count(csr_start, src);
   uint32_t inc = wave_incl_scan(cnt);
   uint32_t total = __shfl(inc, 63);
   if (total == 0) return;
   L.cstart[lane] = inc - cnt;
-  L.cnode[lane] = node;
+  L.cnode[lane] = src;
+  if (AUX) L.caux[lane] = aux_or;
   if (lane == 0) L.cstart[64] = total;
   WAVE_SYNC();
   for (uint32_t t0 = 0; t0 < total; t0 += 64) {
     uint32_t t = t0 + lane;
     bool valid = t < total;
     uint32_t hap = 0;
+    uint64_t aux = 0;
     if (valid) {
-      // owner lane: last l with cstart[l] <= t
-      int lo = 0, hi = 63;
+      int lo = 0, hi = 63;  // owner lane: last l with cstart[l] <= t
       while (lo < hi) {
         int mid = (lo + hi + 1) >> 1;
         if (L.cstart[mid] <= t) lo = mid; else hi = mid - 1;
       }
       uint32_t nd = L.cnode[lo];
-      hap = full_nodes ? nd : g.a_nbr[g.a_start[nd] + (t - L.cstart[lo])];
+      hap = direct ? nd : csr_nbr[csr_start[nd] + (t - L.cstart[lo])];
+      if (AUX) aux = g.node_key[hap] | L.caux[lo];
     }
     for (int j = 0; j < P; ++j) {
       double p = valid ? g.freq[(uint64_t)hap * P + j] : 0.0;
+      if (AUX) p = p * scale;
       bool act = valid && p > 0.0;
       double key = p * prior[j * P + j];
       uint64_t tie = (((item_base + t) * (uint64_t)P + (uint64_t)j) << 8) | (uint64_t)j;
-      top_push(L, st, act, p, key, tie, hap);
+      top_push(L, st, act, p, key, tie, hap, aux);
     }
   }
   item_base += total;
-  if (!full_nodes) c_nbr += total;
+  if (!direct) c_nbr += total;
   c_freq += total;
   WAVE_SYNC();
 }
 
-// write the finished list of one side: probabilities, prefix-min, entities
+// write the finished list of one side: probabilities, prefix-min, entities.  COMP: haplotypes are
+// identified by their 60-bit key through the slot's canonical table (plan B/C) instead of node ids.
+template <bool COMP>
 __device__ __forceinline__ void store_top(const Slot &S, WgShared &sh, WaveTop &L, TopState &st, int row) {
   const int lane = lane_id();
   top_flush(L, st);
@@ -95,9 +103,11 @@ __device__ __forceinline__ void store_top(const Slot &S, WgShared &sh, WaveTop &
     }
     if (carry < v) v = carry;
     if (r < n) {
+      uint32_t hap = L.hap[r];
+      if (COMP) hap = HAP_COMPOSITE | tab_insert<false>(S.comp, nullptr, GRIM_COMP_CAP - 1, L.aux[r] | GRIM_VALID, 0);
       S.Tp[row * GRIM_TOPCAP + r] = L.p[r];
       S.Tm[row * GRIM_TOPCAP + r] = v;
-      S.Te[row * GRIM_TOPCAP + r] = L.hap[r] | ((uint32_t)(L.tie[r] & 0xFF) << 24);
+      S.Te[row * GRIM_TOPCAP + r] = hap | ((uint32_t)(L.tie[r] & 0xFF) << 24);
     }
     carry = __shfl(v, 63);
   }
@@ -157,7 +167,7 @@ __device__ inline void build_side_plan_a(const DevArgs &A, WgShared &sh, const S
         node = graph_lookup(g, key);
       }
       c_probe += (ncand - c0) < 64 ? (ncand - c0) : 64;
-      expand_chunk(A, prior, L, st, node, full_nodes, item_base, c_nbr, c_freq);
+      expand_chunk<false>(A, prior, L, st, node, full_nodes, g.a_start, g.a_nbr, 1.0, 0, item_base, c_nbr, c_freq);
     }
   } else {
     // label scan: every node of the typed-loci label whose alleles all belong to this side's
@@ -183,10 +193,10 @@ __device__ inline void build_side_plan_a(const DevArgs &A, WgShared &sh, const S
         if (ok) node = nd;
       }
       if (__ballot(node != GRIM_NONE)) any_cand = true;
-      expand_chunk(A, prior, L, st, node, full_nodes, item_base, c_nbr, c_freq);
+      expand_chunk<false>(A, prior, L, st, node, full_nodes, g.a_start, g.a_nbr, 1.0, 0, item_base, c_nbr, c_freq);
     }
   }
-  store_top(S, sh, L, st, row);
+  store_top<false>(S, sh, L, st, row);
   if (lane == 0) {
     sh.cand_any[row] = any_cand ? 1 : 0;
     sh.wctr[wave_id()][0] += c_probe;

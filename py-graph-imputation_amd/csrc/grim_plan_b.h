@@ -1,8 +1,419 @@
-// grim_plan_b.h -- Plan B / Plan C kernel (placeholder until the device path lands; subjects that
-// need it are reported GRIM_ST_UNSUPPORTED, never silently computed elsewhere).
+// grim_plan_b.h -- Plan B on device: locus-partition fallback for subjects whose Plan-A pass found
+// no haplotype pair.  Restates (impute.py lines in brackets):
+//   comp_phase_prob_plan_b            [1392-1570]  row loop with per-side "best row" memo + rescue loop
+//   comp_hap_prob_plan_b / find_option_freq / create_haplos_string / get_haplo_freqs_pan_b
+//                                      [1117-1123, 1072-1115, 1015-1039, 1207-1216]  block look-ups
+//   open_option_                       [1041-1069]  block cross product, freq = (f1*f2)*1e-4 per population
+//   find_option_freq_missing_data      [1142-1172]  alleles the graph has never seen
+//   check_if_alleles_in_data / _of_one_phase_in_data [1224-1258]
+//   call_comp_phase_prob levels        [1696-1722]  level 0 = subject prior, level 1 = all-ones prior
+// and Graph.adjs_query_by_color / node_probs / haps_with_probs_by_label (networkx_graph.py:238-321).
+//
+// One workgroup per subject; each wave builds phase sides (block sets -> cross product -> running
+// top-K), the workgroup then scores pairs at epsilon 0 (the only value Plan B ever runs with,
+// impute.py:1703-1711).  Haplotypes made of blocks are not graph nodes, so every haplotype is
+// identified by its 60-bit allele key through the slot's canonical table.
+//
+// Not on device (reported GRIM_ST_UNSUPPORTED, never computed elsewhere): subjects whose sides use
+// the label-scan opening (reason 3) and Plan C (reason 4).
 #pragma once
-#include "grim_pair.h"
+#include "grim_plan_a.h"
+
+#define GRIM_FACTOR_JOIN 0.0001  // impute.py:196
+
+struct SideSpec {
+  uint32_t cn[GRIM_MAXL], to[GRIM_MAXL], sl[GRIM_MAXL];
+  int n;
+  uint32_t typed_mask, ncand;
+  bool expansion;
+};
+
+__device__ __forceinline__ SideSpec side_spec(const DevArgs &A, const WgShared &sh, int ph, int side) {
+  const grim_subject &sj = sh.subj;
+  SideSpec sp;
+  sp.n = sj.n_loci;
+  sp.typed_mask = 0;
+  sp.ncand = 1;
+  uint64_t options = 1;
+  const uint32_t pat = sh.ph_pat[ph];
+#pragma unroll
+  for (int l = 0; l < GRIM_MAXL; ++l) {
+    sp.cn[l] = 1; sp.to[l] = 0; sp.sl[l] = 0;
+    if (l < sp.n) {
+      int c = (int)((pat >> l) & 1u) ^ side;
+      sp.cn[l] = sj.cnt[l][c];
+      sp.to[l] = sh.toff[l][c];
+      sp.sl[l] = sj.slot[l];
+      options *= (uint64_t)sj.wid[l][c];
+      if (options > 0xFFFFFFFFFFFFull) options = 0xFFFFFFFFFFFFull;
+      sp.ncand *= sp.cn[l];
+      sp.typed_mask |= 1u << sp.sl[l];
+    }
+  }
+  sp.expansion = options < A.prm.opt_threshold;
+  return sp;
+}
+
+__device__ __forceinline__ bool allele_known(const DevGraph &g, uint32_t slot, uint32_t id) {
+  return graph_lookup(g, (uint64_t)(id + 1u) << (GRIM_ABITS * slot)) != GRIM_NONE;
+}
+
+// positions of this phase side none of whose alleles the graph knows (impute.py:1243-1258)
+__device__ __forceinline__ uint32_t absent_positions(const DevArgs &A, const uint16_t *tok, const SideSpec &sp) {
+  uint32_t m = 0;
+#pragma unroll
+  for (int l = 0; l < GRIM_MAXL; ++l) {
+    if (l < sp.n) {
+      bool any = false;
+      for (uint32_t t = 0; t < sp.cn[l]; ++t) any |= allele_known(A.g, sp.sl[l], tok[sp.to[l] + t]);
+      if (!any) m |= 1u << l;
+    }
+  }
+  return m;
+}
+
+// Row whose first block is the full label: plain Plan-A look-up (impute.py:1118-1119).
+__device__ inline bool side_lookup_full(const DevArgs &A, WgShared &sh, const Slot &S, const double *prior, WaveTop &L,
+                                        const SideSpec &sp, const uint16_t *tok, int row) {
+  const DevGraph &g = A.g;
+  const int lane = lane_id();
+  TopState st;
+  st.nrun = 0; st.nbuf = 0; st.K = (int)A.prm.top_n; st.full = false; st.thr = 0;
+  uint64_t item_base = 0, c_nbr = 0, c_freq = 0;
+  const bool direct = (sp.typed_mask == g.full_mask);
+  for (uint32_t c0 = 0; c0 < sp.ncand; c0 += 64) {
+    uint32_t c = c0 + lane;
+    uint32_t node = GRIM_NONE;
+    if (c < sp.ncand) {
+      uint64_t key = 0;
+      uint32_t rem = c;
+#pragma unroll
+      for (int l = GRIM_MAXL - 1; l >= 0; --l) {
+        if (l < sp.n) {
+          uint32_t d = rem % sp.cn[l];
+          rem /= sp.cn[l];
+          key |= (uint64_t)(tok[sp.to[l] + d] + 1u) << (GRIM_ABITS * sp.sl[l]);
+        }
+      }
+      node = graph_lookup(g, key);
+    }
+    expand_chunk<true>(A, prior, L, st, node, direct, g.a_start, g.a_nbr, 1.0, 0, item_base, c_nbr, c_freq);
+  }
+  store_top<true>(S, sh, L, st, row);
+  return st.nrun > 0;
+}
+
+// Alleles the graph has never seen at the positions in `absent` (bit l = position l): look the rest
+// of the haplotype up towards the label "all loci but the absent ones", splice the unseen alleles
+// back in, scale by factor_missing_data ** (#absent loci)  (impute.py:1142-1172).
+__device__ inline bool side_absent(const DevArgs &A, WgShared &sh, const Slot &S, const double *prior, WaveTop &L,
+                                   const SideSpec &sp, const uint16_t *tok, uint32_t absent, int row) {
+  const DevGraph &g = A.g;
+  const int lane = lane_id();
+  TopState st;
+  st.nrun = 0; st.nbuf = 0; st.K = (int)A.prm.top_n; st.full = false; st.thr = 0;
+  uint32_t src_mask = 0, abs_mask = 0;
+#pragma unroll
+  for (int l = 0; l < GRIM_MAXL; ++l)
+    if (l < sp.n) {
+      if ((absent >> l) & 1u) abs_mask |= 1u << sp.sl[l]; else src_mask |= 1u << sp.sl[l];
+    }
+  const uint32_t target = g.full_mask & ~abs_mask;
+  const uint32_t added = target & ~src_mask;
+  const int nadd = __popc(added);
+  const double scale = A.prm.factor_missing_pow[__popc(abs_mask)];
+  uint64_t item_base = 0, c_nbr = 0, c_freq = 0;
+  if (src_mask != 0 && nadd <= 1) {
+    const bool direct = (nadd == 0);
+    const int add_slot = nadd ? (__ffs(added) - 1) : 0;
+    for (uint32_t c0 = 0; c0 < sp.ncand; c0 += 64) {
+      uint32_t c = c0 + lane;
+      uint32_t src = GRIM_NONE;
+      uint64_t outside = 0;
+      if (c < sp.ncand) {
+        uint64_t key = 0;
+        uint32_t rem = c;
+#pragma unroll
+        for (int l = GRIM_MAXL - 1; l >= 0; --l) {
+          if (l < sp.n) {
+            uint32_t d = rem % sp.cn[l];
+            rem /= sp.cn[l];
+            uint64_t a = (uint64_t)(tok[sp.to[l] + d] + 1u) << (GRIM_ABITS * sp.sl[l]);
+            if ((absent >> l) & 1u) outside |= a; else key |= a;
+          }
+        }
+        uint32_t node = graph_lookup(g, key);
+        if (node != GRIM_NONE) src = direct ? node : g.b_conn[(uint64_t)node * GRIM_MAXL + add_slot];
+      }
+      expand_chunk<true>(A, prior, L, st, src, direct, g.b_start, g.b_nbr, scale, outside, item_base, c_nbr, c_freq);
+    }
+  }
+  store_top<true>(S, sh, L, st, row);
+  return st.nrun > 0;
+}
+
+// A Plan_B_Matrix row with several blocks (impute.py:1072-1115): per block the set of graph nodes
+// reachable from the typed part of the candidates (or, for a block without any typed locus that is
+// not the first one, every node of the block's label), then the cross product, first block most
+// significant, per-population frequency ((f0*f1)*1e-4)*f2)*1e-4 ...
+__device__ inline bool side_blocks(const DevArgs &A, WgShared &sh, const Slot &S, const double *prior, WaveTop &L,
+                                   const SideSpec &sp, const uint16_t *tok, int mrow, int row) {
+  const DevGraph &g = A.g;
+  const int lane = lane_id();
+  const int P = g.P;
+  const int nb = A.prm.planb_nblk[mrow];
+  TopState st;
+  st.nrun = 0; st.nbuf = 0; st.K = (int)A.prm.top_n; st.full = false; st.thr = 0;
+  uint32_t *wset = S.bset + (uint64_t)wave_id() * GRIM_MAXL * A.bset_cap;
+  const uint32_t *setp[GRIM_MAXL];
+  uint32_t setn[GRIM_MAXL];
+  bool ok = true;
+#pragma unroll
+  for (int b = 0; b < GRIM_MAXL; ++b) {
+    setp[b] = nullptr;
+    setn[b] = 1;
+    if (b < nb && ok) {
+      const uint32_t bm = A.prm.planb_blk[mrow][b];
+      const uint32_t tb = bm & sp.typed_mask;
+      if (tb == 0) {
+        if (b == 0) {
+          ok = false;  // an empty first block yields nothing (impute.py:1079-1085)
+        } else {
+          setp[b] = g.lab_nodes + g.lab_start[bm];  // haps_with_probs_by_label (impute.py:1100-1106)
+          setn[b] = g.lab_start[bm + 1] - g.lab_start[bm];
+          if (setn[b] == 0) ok = false;
+        }
+      } else {
+        const uint32_t added = bm & ~tb;
+        const int nadd = __popc(added);
+        if (nadd > 1) {
+          ok = false;  // parents are exactly one locus larger: no connector exists
+        } else {
+          const int add_slot = nadd ? (__ffs(added) - 1) : 0;
+          uint32_t nsub = 1;
+#pragma unroll
+          for (int l = 0; l < GRIM_MAXL; ++l)
+            if (l < sp.n && ((tb >> sp.sl[l]) & 1u)) nsub *= sp.cn[l];
+          uint32_t *out = wset + (uint64_t)b * A.bset_cap;
+          uint32_t cnt = 0;
+          for (uint32_t c0 = 0; c0 < nsub; c0 += 64) {
+            uint32_t c = c0 + lane;
+            uint32_t n_out = 0, node = GRIM_NONE, base = 0;
+            if (c < nsub) {
+              uint64_t key = 0;
+              uint32_t rem = c;
+#pragma unroll
+              for (int l = GRIM_MAXL - 1; l >= 0; --l) {
+                if (l < sp.n && ((tb >> sp.sl[l]) & 1u)) {
+                  uint32_t d = rem % sp.cn[l];
+                  rem /= sp.cn[l];
+                  key |= (uint64_t)(tok[sp.to[l] + d] + 1u) << (GRIM_ABITS * sp.sl[l]);
+                }
+              }
+              node = graph_lookup(g, key);
+              if (node != GRIM_NONE) {
+                if (nadd == 0) {
+                  n_out = 1;
+                } else {
+                  uint32_t conn = g.b_conn[(uint64_t)node * GRIM_MAXL + add_slot];
+                  if (conn != GRIM_NONE) {
+                    n_out = nbr_count(g.b_start, conn);
+                    base = g.b_start[conn];
+                  }
+                }
+              }
+            }
+            uint32_t inc = wave_incl_scan(n_out);
+            uint32_t tot = __shfl(inc, 63);
+            uint32_t off = cnt + inc - n_out;
+            if (off + n_out <= A.bset_cap) {
+              if (nadd == 0) {
+                if (n_out) out[off] = node;
+              } else {
+                for (uint32_t t = 0; t < n_out; ++t) out[off + t] = g.b_nbr[base + t];
+              }
+            }
+            cnt += tot;
+          }
+          if (cnt > A.bset_cap) cnt = A.bset_cap;  // cannot happen: parents of distinct children are disjoint
+          setp[b] = out;
+          setn[b] = cnt;
+          if (cnt == 0) ok = false;
+        }
+      }
+    }
+  }
+  __threadfence_block();
+  if (ok) {
+    uint64_t total = 1;
+#pragma unroll
+    for (int b = 0; b < GRIM_MAXL; ++b)
+      if (b < nb) total *= setn[b];
+    for (uint64_t c0 = 0; c0 < total; c0 += 64) {
+      uint64_t c = c0 + lane;
+      bool valid = c < total;
+      uint32_t nd[GRIM_MAXL];
+      uint64_t key = 0;
+      uint64_t rem = valid ? c : 0;
+#pragma unroll
+      for (int b = GRIM_MAXL - 1; b >= 0; --b) {
+        nd[b] = 0;
+        if (b < nb) {
+          uint64_t d = rem % setn[b];
+          rem /= setn[b];
+          nd[b] = setp[b][d];
+          key |= g.node_key[nd[b]];
+        }
+      }
+      for (int j = 0; j < P; ++j) {
+        double acc = g.freq[(uint64_t)nd[0] * P + j];
+#pragma unroll
+        for (int b = 1; b < GRIM_MAXL; ++b)
+          if (b < nb) acc = acc * g.freq[(uint64_t)nd[b] * P + j] * GRIM_FACTOR_JOIN;
+        bool act = valid && acc > 0.0;
+        uint64_t tie = ((c * (uint64_t)P + (uint64_t)j) << 8) | (uint64_t)j;
+        top_push(L, st, act, acc, acc * prior[j * P + j], tie, 0, key);
+      }
+    }
+  }
+  store_top<true>(S, sh, L, st, row);
+  return st.nrun > 0;
+}
+
+__device__ __forceinline__ bool side_row(const DevArgs &A, WgShared &sh, const Slot &S, const double *prior, WaveTop &L,
+                                         const SideSpec &sp, const uint16_t *tok, int mrow, int row) {
+  if (A.prm.planb_blk[mrow][0] == A.g.full_mask) return side_lookup_full(A, sh, S, prior, L, sp, tok, row);
+  return side_blocks(A, sh, S, prior, L, sp, tok, mrow, row);
+}
+
+// Score the lists currently in the slot at epsilon 0 and, if anything was accepted, write the tables.
+__device__ inline bool planb_score(const DevArgs &A, WgShared &sh, const Slot &S, const double *prior, double *mx) {
+  const uint32_t np = pair_offsets(sh);
+  if (np == 0) return false;
+  uint32_t nU = pair_pass(A, sh, S, prior, np, 0.0, true, mx);
+  if (nU == 0) return false;
+  emit_tables(A, sh, S, nU, sh.out);
+  return true;
+}
+
+__global__ __launch_bounds__(GRIM_WG) void grim_plan_b_kernel(DevArgs A) {
+  __shared__ WgShared sh;
+  __shared__ WaveTop wt[GRIM_NWAVE];
+  __shared__ uint8_t memo[GRIM_SIDES];
+  __shared__ uint32_t absent_side[2];
+  __shared__ uint32_t unsupported;
+  const int tid = threadIdx.x;
+  const int P = A.g.P;
+  const uint32_t n_work = *A.next_count;
+  Slot S = make_slot(A, blockIdx.x);
+  for (;;) {
+    if (tid == 0) sh.bc[3] = atomicAdd(A.queue, 1u);
+    __syncthreads();
+    const uint32_t w = sh.bc[3];
+    if (w >= n_work) break;
+    const uint32_t si = A.next_list[w];
+    if (tid < 16) ((uint32_t *)&sh.subj)[tid] = ((const uint32_t *)&A.subj[si])[tid];
+    if (tid < (int)(sizeof(grim_subject_result) / 4)) ((uint32_t *)&sh.out)[tid] = 0;
+    if (tid == 0) unsupported = 0;
+    __syncthreads();
+    enumerate_phases(sh);
+    const int nph = sh.nph;
+    const uint16_t *tok = A.tok + sh.subj.tok_off;
+    // every side must have been opened by the cartesian branch
+    if (tid < 2 * nph) {
+      SideSpec sp = side_spec(A, sh, tid >> 1, tid & 1);
+      if (!sp.expansion) atomicOr(&unsupported, 1u);
+    }
+    // alleles of a position that the graph has never seen on ANY phase of a side (impute.py:1224-1241)
+    if (tid < 2) absent_side[tid] = 0;
+    __syncthreads();
+    if (tid < 2 * GRIM_MAXL) {
+      const int side = tid / GRIM_MAXL, l = tid % GRIM_MAXL;
+      if (l < sh.subj.n_loci) {
+        bool any = false;
+        for (int i = 0; i < nph; ++i) {
+          int c = (int)((sh.ph_pat[i] >> l) & 1u) ^ side;
+          for (uint32_t t = 0; t < sh.subj.cnt[l][c]; ++t)
+            any |= allele_known(A.g, sh.subj.slot[l], tok[sh.toff[l][c] + t]);
+        }
+        if (!any) atomicOr(&absent_side[side], 1u << l);
+      }
+    }
+    __syncthreads();
+    bool done = false;
+    double mx = 0.0;
+    uint8_t status = GRIM_ST_MISS, reason = 0;
+    if (unsupported) {
+      status = GRIM_ST_UNSUPPORTED;
+      reason = 3;
+    } else {
+      for (int level = 0; level < 2 && !done; ++level) {
+        const double *prior = A.priors + (uint64_t)(level == 0 ? sh.subj.prior_idx : A.ones_prior) * P * P;
+        if (tid < GRIM_SIDES) memo[tid] = 10;
+        __syncthreads();
+        // ---- first loop: matrix rows until something is accepted (impute.py:1414-1488) ----------
+        for (int m = 0; m < (int)A.prm.planb_rows && !done; ++m) {
+          for (int s = tid; s < GRIM_COMP_CAP; s += GRIM_WG) S.comp[s] = 0;
+          if (tid < GRIM_SIDES) sh.Tn[tid] = 0;
+          __syncthreads();
+          for (int s = wave_id(); s < 2 * nph; s += GRIM_NWAVE) {
+            SideSpec sp = side_spec(A, sh, s >> 1, s & 1);
+            const uint32_t ab = absent_side[s & 1];
+            if (ab == 0) {
+              int idx = m < (int)memo[s] ? m : (int)memo[s];
+              bool nonempty = side_row(A, sh, S, prior, wt[wave_id()], sp, tok, idx, s);
+              if (nonempty && lane_id() == 0) memo[s] = (uint8_t)idx;
+            } else {
+              side_absent(A, sh, S, prior, wt[wave_id()], sp, tok, ab, s);
+            }
+          }
+          __syncthreads();
+          done = planb_score(A, sh, S, prior, &mx);
+        }
+        // ---- rescue loop (impute.py:1490-1558): its six iterations are identical, one suffices ----
+        if (!done) {
+          for (int s = tid; s < GRIM_COMP_CAP; s += GRIM_WG) S.comp[s] = 0;
+          if (tid < GRIM_SIDES) sh.Tn[tid] = 0;
+          __syncthreads();
+          for (int s = wave_id(); s < 2 * nph; s += GRIM_NWAVE) {
+            const int mine = memo[s], other = memo[s ^ 1];
+            if ((mine == 10) == (other == 10)) continue;  // both unset: skipped; both set: stale lists, no-op
+            SideSpec sp = side_spec(A, sh, s >> 1, s & 1);
+            if (mine == 10) {
+              uint32_t ab = absent_positions(A, tok, sp);
+              // with nothing absent the reference indexes an empty list (IndexError) once a look-up
+              // succeeds; that needs all loci typed and found, which Plan A would have caught
+              side_absent(A, sh, S, prior, wt[wave_id()], sp, tok, ab, s);
+            } else {
+              side_row(A, sh, S, prior, wt[wave_id()], sp, tok, mine, s);
+            }
+          }
+          __syncthreads();
+          done = planb_score(A, sh, S, prior, &mx);
+        }
+      }
+      if (done) {
+        status = GRIM_ST_OK;
+      } else {
+        status = GRIM_ST_UNSUPPORTED;  // Plan C (impute.py:1313-1389)
+        reason = 4;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      sh.out.status = status;
+      sh.out.reason = reason;
+      sh.out.plan = 'b';
+      sh.out.max_prob = mx;
+      A.res[si] = sh.out;
+    }
+    __syncthreads();
+  }
+}
+
 static int grim_launch_plan_b(DevArgs &A, uint32_t n_slots, hipStream_t stream) {
-  (void)A; (void)n_slots; (void)stream;
-  return 0;
+  // the plan-A kernel leaves the list of subjects in next_list/next_count; restart the work counter
+  if (hipMemsetAsync(A.queue, 0, 4, stream) != hipSuccess) return -1;
+  hipLaunchKernelGGL(grim_plan_b_kernel, dim3(n_slots), dim3(GRIM_WG), 0, stream, A);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
 }

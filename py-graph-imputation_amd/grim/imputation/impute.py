@@ -237,7 +237,8 @@ class Imputation(object):
         order = sorted(range(len(self.populations)), key=lambda i: self.populations[i])
         for rank, i in enumerate(order):
             p.pop_rank[i] = rank
-        p.factor_missing = float(config["factor_missing_data"])
+        for k in range(nat.MAXL + 1):
+            p.factor_missing_pow[k] = config["factor_missing_data"] ** k
         rows = config["matrix_planb"]
         if len(rows) > nat.MAXROWS:
             raise NotImplementedError("Plan_B_Matrix with more than %d rows" % nat.MAXROWS)
