@@ -14,8 +14,9 @@
 // impute.py:1703-1711).  Haplotypes made of blocks are not graph nodes, so every haplotype is
 // identified by its 60-bit allele key through the slot's canonical table.
 //
-// Not on device (reported GRIM_ST_UNSUPPORTED, never computed elsewhere): subjects whose sides use
-// the label-scan opening (reason 3) and Plan C (reason 4).
+// Plan C (independent loci) follows in the same kernel when both Plan-B levels come back empty.
+// Not on device (reported GRIM_ST_UNSUPPORTED, never computed elsewhere): Plan B/C for subjects
+// whose sides use the label-scan opening (reason 3).
 #pragma once
 #include "grim_plan_a.h"
 
@@ -286,6 +287,114 @@ __device__ __forceinline__ bool side_row(const DevArgs &A, WgShared &sh, const S
   return side_blocks(A, sh, S, prior, L, sp, tok, mrow, row);
 }
 
+// ---- Plan C (impute.py:1313-1389, 1264-1311): loci treated as independent ------------------------
+// reduce_phase_to_commons_alleles(.., commons_number=1, planc=True) (impute.py:881-912) first
+// replaces every '/'-list that has at least one allele known to the graph by its single most
+// frequent allele (frequency summed over populations under the all-ones prior, first wins ties);
+// best[l][c] = token index of that allele inside list (l,c), 0xFFFF if none is known.
+__device__ __forceinline__ SideSpec side_spec_c(const DevArgs &A, const WgShared &sh, const uint16_t (*best)[2], int ph,
+                                                int side) {
+  SideSpec sp = side_spec(A, sh, ph, side);
+  const grim_subject &sj = sh.subj;
+  const uint32_t pat = sh.ph_pat[ph];
+  uint64_t options = 1;
+  sp.ncand = 1;
+#pragma unroll
+  for (int l = 0; l < GRIM_MAXL; ++l) {
+    if (l < sp.n) {
+      int c = (int)((pat >> l) & 1u) ^ side;
+      if (best[l][c] != 0xFFFF) {
+        sp.to[l] += best[l][c];
+        sp.cn[l] = 1;
+      } else {
+        options *= (uint64_t)sj.wid[l][c];
+        if (options > 0xFFFFFFFFFFFFull) options = 0xFFFFFFFFFFFFull;
+      }
+      sp.ncand *= sp.cn[l];
+    }
+  }
+  sp.expansion = options < A.prm.opt_threshold;
+  return sp;
+}
+
+__device__ __forceinline__ double pop_sum(const DevGraph &g, uint32_t node) {  // allel_to_SR, impute.py:1260-1262
+  double s = 0.0;
+  for (uint32_t j = 0; j < g.P; ++j) s = s + g.freq[(uint64_t)node * g.P + j];
+  return s;
+}
+
+// comp_hap_prob_plan_c: per candidate the product of its alleles' population-summed frequencies
+// ((s0*s1)*1e-4)*s2)*1e-4.., unknown alleles kept in the name and paid for with
+// factor_missing_data ** count, then joined with every node of the label of the untyped loci.
+__device__ inline bool side_plan_c(const DevArgs &A, WgShared &sh, const Slot &S, const double *prior, WaveTop &L,
+                                   const SideSpec &sp, const uint16_t *tok, int row) {
+  const DevGraph &g = A.g;
+  const int lane = lane_id();
+  const int P = g.P;
+  TopState st;
+  st.nrun = 0; st.nbuf = 0; st.K = (int)A.prm.top_n; st.full = false; st.thr = 0;
+  const uint32_t miss = g.full_mask & ~sp.typed_mask;
+  const uint32_t r0 = miss ? g.lab_start[miss] : 0, rn = miss ? (g.lab_start[miss + 1] - g.lab_start[miss]) : 1;
+  const uint64_t total = (uint64_t)sp.ncand * rn;
+  for (uint64_t i0 = 0; i0 < total; i0 += 64) {
+    uint64_t i = i0 + lane;
+    bool valid = i < total;
+    double p = 0.0;
+    uint64_t key = 0;
+    if (valid) {
+      uint32_t c = (uint32_t)(i / rn), r = (uint32_t)(i % rn);
+      uint32_t rem = c;
+      uint32_t al[GRIM_MAXL];
+#pragma unroll
+      for (int l = GRIM_MAXL - 1; l >= 0; --l) {
+        al[l] = 0;
+        if (l < sp.n) {
+          uint32_t d = rem % sp.cn[l];
+          rem /= sp.cn[l];
+          al[l] = tok[sp.to[l] + d];
+        }
+      }
+      bool have = false, dead = false;
+      int n_abs = 0;
+      double cur = 0.0;
+#pragma unroll
+      for (int l = 0; l < GRIM_MAXL; ++l) {
+        if (l < sp.n && !dead) {
+          uint64_t k1 = (uint64_t)(al[l] + 1u) << (GRIM_ABITS * sp.sl[l]);
+          key |= k1;
+          uint32_t node = graph_lookup(g, k1);
+          if (node == GRIM_NONE) {
+            ++n_abs;
+          } else {
+            double s = pop_sum(g, node);
+            if (!have) {
+              cur = s;
+              have = true;
+            } else {
+              cur = cur * s * GRIM_FACTOR_JOIN;
+              if (!(cur > 0.0)) dead = true;
+            }
+          }
+        }
+      }
+      if (have && !dead) {
+        if (n_abs) cur = cur * A.prm.factor_missing_pow[n_abs];
+        if (miss) {
+          uint32_t rn_node = g.lab_nodes[r0 + r];
+          cur = cur * pop_sum(g, rn_node) * GRIM_FACTOR_JOIN;
+          key |= g.node_key[rn_node];
+        }
+        p = cur;
+      }
+    }
+    bool act = valid && p > 0.0;
+    uint64_t tie = ((i * (uint64_t)P) << 8);
+    top_push(L, st, act, p, p * prior[0], tie, 0, key);
+  }
+  store_top<true>(S, sh, L, st, row);
+  return st.nrun > 0;
+}
+
 // Score the lists currently in the slot at epsilon 0 and, if anything was accepted, write the tables.
 __device__ inline bool planb_score(const DevArgs &A, WgShared &sh, const Slot &S, const double *prior, double *mx) {
   const uint32_t np = pair_offsets(sh);
@@ -302,6 +411,7 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_b_kernel(DevArgs A) {
   __shared__ uint8_t memo[GRIM_SIDES];
   __shared__ uint32_t absent_side[2];
   __shared__ uint32_t unsupported;
+  __shared__ uint16_t bestc[GRIM_MAXL][2];
   const int tid = threadIdx.x;
   const int P = A.g.P;
   const uint32_t n_work = *A.next_count;
@@ -342,7 +452,7 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_b_kernel(DevArgs A) {
     __syncthreads();
     bool done = false;
     double mx = 0.0;
-    uint8_t status = GRIM_ST_MISS, reason = 0;
+    uint8_t status = GRIM_ST_MISS, reason = 0, plan = 'b';
     if (unsupported) {
       status = GRIM_ST_UNSUPPORTED;
       reason = 3;
@@ -392,18 +502,60 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_b_kernel(DevArgs A) {
           done = planb_score(A, sh, S, prior, &mx);
         }
       }
-      if (done) {
-        status = GRIM_ST_OK;
+      if (!done) {
+        // ---- Plan C under the all-ones prior left behind by level 1 (impute.py:1637-1643, 1649-1654).
+        // The phased pass re-runs Plan A and B on the reduced phases first; their candidates are a
+        // subset of the ones that just failed, so it ends here as well.
+        plan = 'c';
+        const double *prior = A.priors + (uint64_t)A.ones_prior * P * P;
+        if (tid < 2 * GRIM_MAXL) {
+          const int l = tid >> 1, c = tid & 1;
+          uint16_t b = 0xFFFF;
+          if (l < sh.subj.n_loci) {
+            double bs = 0.0;
+            for (uint32_t t = 0; t < sh.subj.cnt[l][c]; ++t) {
+              uint32_t node = graph_lookup(A.g, (uint64_t)(tok[sh.toff[l][c] + t] + 1u) << (GRIM_ABITS * sh.subj.slot[l]));
+              if (node == GRIM_NONE) continue;
+              double sc = 0.0;
+              for (int j = 0; j < P; ++j) sc = sc + A.g.freq[(uint64_t)node * P + j] * prior[j * P + j];
+              if (b == 0xFFFF || sc > bs) {
+                b = (uint16_t)t;
+                bs = sc;
+              }
+            }
+          }
+          bestc[l][c] = b;
+        }
+        for (int s = tid; s < GRIM_COMP_CAP; s += GRIM_WG) S.comp[s] = 0;
+        if (tid < GRIM_SIDES) sh.Tn[tid] = 0;
+        if (tid == 0) unsupported = 0;
+        __syncthreads();
+        if (tid < 2 * nph) {
+          SideSpec sp = side_spec_c(A, sh, bestc, tid >> 1, tid & 1);
+          if (!sp.expansion) atomicOr(&unsupported, 1u);
+        }
+        __syncthreads();
+        if (unsupported) {
+          status = GRIM_ST_UNSUPPORTED;
+          reason = 3;
+        } else {
+          for (int s = wave_id(); s < 2 * nph; s += GRIM_NWAVE) {
+            SideSpec sp = side_spec_c(A, sh, bestc, s >> 1, s & 1);
+            side_plan_c(A, sh, S, prior, wt[wave_id()], sp, tok, s);
+          }
+          __syncthreads();
+          done = planb_score(A, sh, S, prior, &mx);
+          status = done ? GRIM_ST_OK : GRIM_ST_MISS;
+        }
       } else {
-        status = GRIM_ST_UNSUPPORTED;  // Plan C (impute.py:1313-1389)
-        reason = 4;
+        status = GRIM_ST_OK;
       }
     }
     __syncthreads();
     if (tid == 0) {
       sh.out.status = status;
       sh.out.reason = reason;
-      sh.out.plan = 'b';
+      sh.out.plan = plan;
       sh.out.max_prob = mx;
       A.res[si] = sh.out;
     }

@@ -443,6 +443,10 @@ class Imputation(object):
                     if r is not None:
                         self._write_rows(out["umug"], sid, rows, r, nat.T_UMUG, plan, em_mr)
                         self._write_rows(out["umug_pops"], sid, rows, r, nat.T_UMUG_POPS, plan, em_mr)
+                        if plan == ord("c") and int(r["n_rows"][nat.T_UMUG_POPS]) == 0:
+                            # Plan C always reports {"all_pops,all_pops": sum(...)}, an integer 0 when it
+                            # found nothing (impute.py:1375-1378)
+                            out["umug_pops"].write(sid + ",all_pops,all_pops,0,0\n")
                 say(per_subject)
         finally:
             for fh in out.values():

@@ -221,6 +221,7 @@ def main():
     run_scenario("cau_top5", w1, ["CAU"], synth.SubjectGen(cau, 12).mixed(60, amb=0.4, miss=0.3),
                  {"max_haplotypes_number_in_phase": 5})
     run_scenario("cau_em_mr", w1, ["CAU"], synth.SubjectGen(cau, 13).mixed(40), hap_pop_pair=True)
+    run_scenario("cau_planc", w1, ["CAU"], synth.plan_c_cases("CAU"))
 
     g4 = synth.SubjectGen(cau, 3, pops=POP4)
     # mix subjects drawn from all four tables
@@ -229,6 +230,8 @@ def main():
                  {"UNK_priors": "MR"})
     run_scenario("pop4_sr", w4, POP4, synth.SubjectGen(pop_rows["HIS"], 6, pops=POP4).mixed(120), {"UNK_priors": "SR"})
     run_scenario("pop4_edge", w4, POP4, synth.edge_cases("AFA") + synth.edge_cases("UNK"), {"UNK_priors": "MR"})
+    run_scenario("pop4_planc", w4, POP4, synth.plan_c_cases("HIS") + synth.plan_c_cases("UNK"), {"UNK_priors": "MR"})
+    run_scenario("pop4_planc_haps", w4, POP4, synth.plan_c_cases("API"), {"UNK_priors": "SR", "output_MUUG": False})
     run_scenario("pop4_em_mr", w4, POP4, synth.SubjectGen(cau, 14, pops=POP4).mixed(40), {"UNK_priors": "MR"},
                  hap_pop_pair=True)
 

@@ -157,6 +157,21 @@ class SubjectGen:
         return out
 
 
+def plan_c_cases(pop="CAU"):
+    """Subjects that fall through Plan A and Plan B into Plan C (impute.py:1313-1389): a locus whose
+    alleles are all unknown to the graph together with at most three typed loci."""
+    return [
+        "C0,A*98:01+A*98:02^B*07:02+B*08:01,%s,%s" % (pop, pop),
+        "C1,A*98:01+A*98:01^B*07:02/B*08:01/B*44:02+B*08:01^C*07:01+C*07:02,%s,%s" % (pop, pop),
+        "C2,B*98:07+B*98:09^DRB1*15:01+DRB1*03:01,%s,%s" % (pop, pop),
+        "C3,A*01:01+A*02:01^DQB1*98:01+DQB1*98:02/DQB1*98:03,%s,%s" % (pop, pop),
+        "C4,C*98:01+C*98:02,%s,%s" % (pop, pop),
+        "C5,A*98:01+A*98:02^B*98:01+B*98:02^C*07:01+C*07:02,%s,%s" % (pop, pop),
+        "C6,A*98:01+A*98:02^B*07:02+B*07:02^DRB1*15:01+DRB1*15:01,UNK,%s" % pop,
+        "C7,A*98:01/A*01:01+A*98:02^B*07:02+B*08:01^C*07:02+C*98:01,%s,%s" % (pop, pop),
+    ]
+
+
 def edge_cases(pop="CAU"):
     """Hand-written edge cases (SURVEY appendix A.6 + a few more)."""
     return [
