@@ -16,7 +16,18 @@
 #define GRIM_COMP_CAP 8192  // >= 2 * GRIM_SIDES * GRIM_TOPCAP
 
 // ---- graph as the kernels see it --------------------------------------------------------------
+// full-label nodes only, with the first population's frequency inline: the half-wave kernel's
+// whole look-up is one 32-byte entry (grim_small.h)
+struct FullEnt {
+  uint64_t key;
+  uint64_t node;
+  double f0;
+  double reserved;
+};
+
 struct DevGraph {
+  const FullEnt *fht;
+  uint32_t fht_mask;
   const uint64_t *node_key;
   const uint8_t *node_mask;
   const double *freq;

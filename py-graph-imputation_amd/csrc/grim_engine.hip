@@ -12,6 +12,7 @@
 
 #include "grim_plan_a.h"
 #include "grim_plan_b.h"
+#include "grim_small.h"
 
 // =================================================================================================
 // Plan-A kernel: one workgroup per subject, pulled from a work counter.  Waves build the phase
@@ -98,6 +99,14 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_a_kernel(DevArgs A) {
   }
 }
 
+#define GRIM_NCTR (8 + 4 * 64)
+
+// zero the counters and work heads of a batch (one launch instead of several memsets)
+__global__ void grim_reset_kernel(unsigned long long *counters, uint32_t *queue, uint32_t row_head0) {
+  for (int i = threadIdx.x; i < GRIM_NCTR; i += blockDim.x) counters[i] = 0;
+  if (threadIdx.x < 4) queue[threadIdx.x] = threadIdx.x == 1 ? row_head0 : 0u;
+}
+
 // =================================================================================================
 // host side
 // =================================================================================================
@@ -122,8 +131,14 @@ struct grim_batch {
   DevArgs a;
   std::vector<void *> bufs;
   uint32_t n_subj, n_slots;
-  hipEvent_t ev[4];
-  float ms_a, ms_b;
+  SmallRec *small_recs;
+  unsigned long long *hstate;  // pinned: counters + work/row heads of the last run
+  uint32_t *order_s, *order_g;  // subjects of the half-wave fast path / of the general kernel
+  uint32_t n_small, n_general, small_stride;
+  hipEvent_t ev[5];
+  hipGraphExec_t gexec;
+  int graph_state;  // 0 not tried, 1 captured, -1 direct launches
+  float ms_a, ms_b, ms_s;
   uint32_t rows_used;
   unsigned long long counters[8];
 };
@@ -246,7 +261,25 @@ extern "C" grim_graph *grim_graph_upload(grim_ctx *c, const grim_graph_desc *d) 
   D.lab_nodes = upload(c, g->bufs, d->lab_nodes, d->n_nodes, &g->bytes);
   D.ht_key = upload(c, g->bufs, hk.data(), cap, &g->bytes);
   D.ht_val = upload(c, g->bufs, hv.data(), cap, &g->bytes);
-  if (!D.node_key || !D.node_mask || !D.freq || !D.a_start || !D.a_nbr || !D.b_conn || !D.b_start || !D.b_nbr ||
+  {  // full-haplotype table
+    uint32_t nfull = d->lab_start[d->full_mask + 1] - d->lab_start[d->full_mask];
+    uint32_t fcap = 64;
+    while (fcap < 2 * (uint64_t)nfull) fcap <<= 1;
+    std::vector<FullEnt> ft(fcap);
+    memset(ft.data(), 0, sizeof(FullEnt) * fcap);
+    for (uint32_t i = 0; i < d->n_nodes; ++i) {
+      if (d->node_mask[i] != d->full_mask) continue;
+      uint64_t k = d->node_key[i];
+      uint32_t h = (uint32_t)host_mix64(k) & (fcap - 1);
+      while (ft[h].key != 0 && ft[h].key != k) h = (h + 1) & (fcap - 1);
+      ft[h].key = k;
+      ft[h].node = i;
+      ft[h].f0 = d->freq[(size_t)i * d->n_pops];
+    }
+    D.fht = upload(c, g->bufs, ft.data(), fcap, &g->bytes);
+    D.fht_mask = fcap - 1;
+  }
+  if (!D.fht || !D.node_key || !D.node_mask || !D.freq || !D.a_start || !D.a_nbr || !D.b_conn || !D.b_start || !D.b_nbr ||
       !D.lab_start || !D.lab_nodes || !D.ht_key || !D.ht_val) {
     c->err = "grim_graph_upload: device allocation or copy failed";
     for (void *p : g->bufs) hipFree(p);
@@ -276,7 +309,7 @@ extern "C" grim_batch *grim_batch_upload(grim_ctx *c, const grim_graph *g, const
   b->ctx = c;
   b->g = g;
   b->n_subj = d->n_subjects;
-  b->ms_a = b->ms_b = 0;
+  b->ms_a = b->ms_b = b->ms_s = 0;
   b->rows_used = 0;
   memset(b->counters, 0, sizeof(b->counters));
   DevArgs &A = b->a;
@@ -293,19 +326,53 @@ extern "C" grim_batch *grim_batch_upload(grim_ctx *c, const grim_graph *g, const
     A.priors = upload(c, b->bufs, pr.data(), pr.size(), &bytes);
     A.ones_prior = d->n_priors;
   }
-  std::vector<uint32_t> order(d->n_subjects);
-  for (uint32_t i = 0; i < d->n_subjects; ++i) order[i] = i;
-  A.order = upload(c, b->bufs, order.data(), d->n_subjects, &bytes);
-  A.n_work = d->n_subjects;
-  A.queue = upload<uint32_t>(c, b->bufs, nullptr, 4, &bytes);
+  // subject classes: fully typed + unambiguous + one population -> half-wave kernel (grim_small.h)
+  std::vector<uint32_t> os, og;
+  const bool small_ok = (P == 1) && p->opt_threshold > 1 && !getenv("GRIM_NO_SMALL");
+  for (uint32_t i = 0; i < d->n_subjects; ++i) {
+    const grim_subject &sj = d->subjects[i];
+    bool sm = small_ok && sj.n_loci == GRIM_MAXL && g->d.n_loci == GRIM_MAXL;
+    for (int l = 0; l < GRIM_MAXL && sm; ++l)
+      sm = sj.cnt[l][0] == 1 && sj.cnt[l][1] == 1 && sj.wid[l][0] == 1 && sj.wid[l][1] == 1;
+    (sm ? os : og).push_back(i);
+  }
+  b->n_small = (uint32_t)os.size();
+  b->n_general = (uint32_t)og.size();
+  b->small_stride = GRIM_SMALL_ROWS_FIXED + (p->n_results < 16 ? p->n_results : 16);
+  {
+    std::vector<SmallRec> recs(os.size());
+    for (size_t k = 0; k < os.size(); ++k) {
+      const grim_subject &sj = d->subjects[os[k]];
+      SmallRec &r = recs[k];
+      for (int l = 0; l < GRIM_MAXL; ++l) {
+        r.tok[2 * l] = d->tokens[sj.tok_off + 2 * l];
+        r.tok[2 * l + 1] = d->tokens[sj.tok_off + 2 * l + 1];
+        r.slot[l] = sj.slot[l];
+      }
+      r.same = sj.pad[0];
+      r.prior_idx = sj.prior_idx;
+      r.si = os[k];
+    }
+    b->small_recs = upload(c, b->bufs, recs.data(), recs.size(), &bytes);
+  }
+  b->order_s = upload(c, b->bufs, os.data(), os.size(), &bytes);
+  b->order_g = upload(c, b->bufs, og.data(), og.size(), &bytes);
+  A.order = b->order_g;
+  A.n_work = b->n_general;
+  // one state block: counters (8 + 4*64 u64) followed by queue[4] (u32): work counter, row head,
+  // plan-B list length, plan-B work counter
+  A.counters = upload<unsigned long long>(c, b->bufs, nullptr, GRIM_NCTR + 2, &bytes);
+  A.queue = (uint32_t *)(A.counters + GRIM_NCTR);
   A.row_head = A.queue + 1;
   A.next_count = A.queue + 2;
+  b->hstate = nullptr;
+  if (hipHostMalloc((void **)&b->hstate, 8 * (GRIM_NCTR + 2)) != hipSuccess) b->hstate = nullptr;
   A.next_list = upload<uint32_t>(c, b->bufs, nullptr, d->n_subjects, &bytes);
   A.res = upload<grim_subject_result>(c, b->bufs, nullptr, d->n_subjects, &bytes);
-  A.counters = upload<unsigned long long>(c, b->bufs, nullptr, 8, &bytes);
   // rows: enough for every subject to fill all four tables
   uint64_t per = 2ull * p->n_results + 2ull * (p->n_pop_results < (uint64_t)P * P ? p->n_pop_results : (uint64_t)P * P);
-  uint64_t want = per * d->n_subjects + 1024;
+  // (fast-path subjects that fall through to Plan B take their rows from the dynamic part)
+  uint64_t want = per * d->n_subjects + (uint64_t)b->small_stride * b->n_small + 1024;
   const char *env_rows = getenv("GRIM_ROW_CAP");
   if (env_rows) want = strtoull(env_rows, nullptr, 10);
   if (want > 0x7FFFFFF0ull) want = 0x7FFFFFF0ull;
@@ -315,7 +382,7 @@ extern "C" grim_batch *grim_batch_upload(grim_ctx *c, const grim_graph *g, const
   uint32_t slots = (uint32_t)c->n_cu * 2;
   const char *env_slots = getenv("GRIM_SLOTS");
   if (env_slots) slots = (uint32_t)atoi(env_slots);
-  if (slots > d->n_subjects) slots = d->n_subjects;
+  if (slots > b->n_general + (p->planb ? b->n_small : 0)) slots = b->n_general + (p->planb ? b->n_small : 0);
   if (slots == 0) slots = 1;
   b->n_slots = slots;
   A.pair_cap = GRIM_MAXPH * p->top_n * p->top_n;
@@ -350,8 +417,10 @@ extern "C" grim_batch *grim_batch_upload(grim_ctx *c, const grim_graph *g, const
   L.comp = take(8ull * GRIM_COMP_CAP);
   L.stride = align256(o);
   A.scratch = upload<uint8_t>(c, b->bufs, nullptr, (size_t)L.stride * slots, &bytes);
-  bool ok = A.subj && A.tok && A.priors && A.order && A.queue && A.next_list && A.res && A.counters && A.rows && A.scratch;
-  for (int i = 0; i < 4 && ok; ++i) ok = hipEventCreate(&b->ev[i]) == hipSuccess;
+  bool ok = A.subj && A.tok && A.priors && b->order_s && b->order_g && b->small_recs && b->hstate && A.queue && A.next_list && A.res && A.counters && A.rows && A.scratch;
+  b->gexec = nullptr;
+  b->graph_state = 0;
+  for (int i = 0; i < 5 && ok; ++i) ok = hipEventCreate(&b->ev[i]) == hipSuccess;
   if (!ok) {
     c->err = "grim_batch_upload: device allocation or copy failed (" + std::to_string((unsigned long long)(L.stride * slots >> 20)) + " MiB scratch)";
     for (void *q : b->bufs) hipFree(q);
@@ -361,30 +430,81 @@ extern "C" grim_batch *grim_batch_upload(grim_ctx *c, const grim_graph *g, const
   return b;
 }
 
+// Stage 1 of a run: reset, half-wave kernel, general plan-A kernel, state read-back.  Enqueued
+// either directly or into a stream capture (the sequence is replayed as one hipGraph launch).
+static int enqueue_stage1(grim_batch *b) {
+  grim_ctx *c = b->ctx;
+  DevArgs &A = b->a;
+  hipLaunchKernelGGL(grim_reset_kernel, dim3(1), dim3(GRIM_WG), 0, c->stream, A.counters, A.queue,
+                     b->n_small * b->small_stride);
+  HIPCHK(hipEventRecord(b->ev[0], c->stream), c, -1);
+  if (b->n_small) {
+    uint32_t per_block = GRIM_WG / 32;
+    hipLaunchKernelGGL(grim_plan_a_small_kernel, dim3((b->n_small + per_block - 1) / per_block), dim3(GRIM_WG), 0, c->stream,
+                       A, (const SmallRec *)b->small_recs, b->n_small, 0u, b->small_stride);
+  }
+  HIPCHK(hipEventRecord(b->ev[3], c->stream), c, -1);
+  if (b->n_general) {
+    uint32_t grid = b->n_slots < b->n_general ? b->n_slots : b->n_general;
+    hipLaunchKernelGGL(grim_plan_a_kernel, dim3(grid), dim3(GRIM_WG), 0, c->stream, A);
+  }
+  HIPCHK(hipEventRecord(b->ev[1], c->stream), c, -1);
+  HIPCHK(hipMemcpyAsync(b->hstate, A.counters, 8 * (GRIM_NCTR + 2), hipMemcpyDeviceToHost, c->stream), c, -1);
+  return 0;
+}
+
 extern "C" int grim_batch_run(grim_batch *b) {
   if (!b) return -1;
   grim_ctx *c = b->ctx;
   hipSetDevice(c->device);
   DevArgs &A = b->a;
-  HIPCHK(hipMemsetAsync(A.queue, 0, 16, c->stream), c, -1);
-  HIPCHK(hipMemsetAsync(A.counters, 0, 64, c->stream), c, -1);
-  HIPCHK(hipEventRecord(b->ev[0], c->stream), c, -1);
-  if (b->n_subj) {
-    hipLaunchKernelGGL(grim_plan_a_kernel, dim3(b->n_slots), dim3(GRIM_WG), 0, c->stream, A);
+  // ---- stage 1 (captured once per batch, then replayed: one API call instead of eight) ----------
+  if (b->graph_state == 0) {
+    b->graph_state = -1;
+    if (!getenv("GRIM_NO_GRAPH") && hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+      int rc = enqueue_stage1(b);
+      hipGraph_t gr = nullptr;
+      hipError_t e = hipStreamEndCapture(c->stream, &gr);
+      if (rc == 0 && e == hipSuccess && gr && hipGraphInstantiate(&b->gexec, gr, nullptr, nullptr, 0) == hipSuccess)
+        b->graph_state = 1;
+      if (gr) hipGraphDestroy(gr);
+      (void)hipGetLastError();
+    }
+  }
+  if (b->graph_state == 1) {
+    HIPCHK(hipGraphLaunch(b->gexec, c->stream), c, -1);
+  } else {
+    if (enqueue_stage1(b) != 0) return -1;
     HIPCHK(hipGetLastError(), c, -1);
   }
-  HIPCHK(hipEventRecord(b->ev[1], c->stream), c, -1);
-  if (A.prm.planb && b->n_subj) {
-    int rc = grim_launch_plan_b(A, b->n_slots, c->stream);
-    if (rc != 0) { c->err = "plan-B launch failed"; return -1; }
-  }
-  HIPCHK(hipEventRecord(b->ev[2], c->stream), c, -1);
   HIPCHK(hipStreamSynchronize(c->stream), c, -1);
-  HIPCHK(hipEventElapsedTime(&b->ms_a, b->ev[0], b->ev[1]), c, -1);
-  HIPCHK(hipEventElapsedTime(&b->ms_b, b->ev[1], b->ev[2]), c, -1);
+  if (hipEventElapsedTime(&b->ms_s, b->ev[0], b->ev[3]) != hipSuccess || hipEventElapsedTime(&b->ms_a, b->ev[0], b->ev[1]) != hipSuccess) {
+    // event nodes of a replayed graph carry no timestamps on this runtime: fall back to direct launches
+    (void)hipGetLastError();
+    if (b->graph_state == 1) {
+      b->graph_state = -1;
+      return grim_batch_run(b);
+    }
+    c->err = "grim_batch_run: hipEventElapsedTime failed";
+    return -1;
+  }
+  b->ms_b = 0;
   uint32_t head[4];
-  HIPCHK(hipMemcpy(head, A.queue, 16, hipMemcpyDeviceToHost), c, -1);
-  HIPCHK(hipMemcpy(b->counters, A.counters, 64, hipMemcpyDeviceToHost), c, -1);
+  memcpy(head, b->hstate + GRIM_NCTR, 16);
+  // ---- stage 2: Plan B / C only when the first stage left subjects for it ------------------------
+  if (A.prm.planb && head[2] > 0) {
+    HIPCHK(hipEventRecord(b->ev[4], c->stream), c, -1);
+    uint32_t grid = b->n_slots < head[2] ? b->n_slots : head[2];
+    if (grim_launch_plan_b(A, grid, c->stream) != 0) { c->err = "plan-B launch failed"; return -1; }
+    HIPCHK(hipEventRecord(b->ev[2], c->stream), c, -1);
+    HIPCHK(hipMemcpyAsync(b->hstate, A.counters, 8 * (GRIM_NCTR + 2), hipMemcpyDeviceToHost, c->stream), c, -1);
+    HIPCHK(hipStreamSynchronize(c->stream), c, -1);
+    HIPCHK(hipEventElapsedTime(&b->ms_b, b->ev[4], b->ev[2]), c, -1);
+    memcpy(head, b->hstate + GRIM_NCTR, 16);
+  }
+  memcpy(b->counters, b->hstate, 64);
+  for (int sh = 0; sh < 64; ++sh)
+    for (int k = 0; k < 3; ++k) b->counters[k] += b->hstate[8 + 4 * sh + k];
   b->rows_used = head[1];
   if (b->counters[4] != 0 || head[1] > A.row_cap) {
     c->err = "grim_batch_run: output row pool exhausted (raise GRIM_ROW_CAP or lower the batch size)";
@@ -397,6 +517,7 @@ extern "C" double grim_batch_kernel_ms(const grim_batch *b, int which) {
   if (!b) return 0.0;
   if (which == 1) return b->ms_a;
   if (which == 2) return b->ms_b;
+  if (which == 3) return b->ms_s;
   return (double)b->ms_a + (double)b->ms_b;
 }
 
@@ -423,7 +544,9 @@ extern "C" int grim_batch_results(grim_batch *b, grim_subject_result *res, grim_
 extern "C" void grim_batch_free(grim_batch *b) {
   if (!b) return;
   hipSetDevice(b->ctx->device);
-  for (int i = 0; i < 4; ++i) hipEventDestroy(b->ev[i]);
+  for (int i = 0; i < 5; ++i) hipEventDestroy(b->ev[i]);
+  if (b->gexec) hipGraphExecDestroy(b->gexec);
   for (void *p : b->bufs) hipFree(p);
+  if (b->hstate) hipHostFree(b->hstate);
   delete b;
 }

@@ -417,7 +417,7 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_b_kernel(DevArgs A) {
   const uint32_t n_work = *A.next_count;
   Slot S = make_slot(A, blockIdx.x);
   for (;;) {
-    if (tid == 0) sh.bc[3] = atomicAdd(A.queue, 1u);
+    if (tid == 0) sh.bc[3] = atomicAdd(A.queue + 3, 1u);  // own counter: no reset between kernels
     __syncthreads();
     const uint32_t w = sh.bc[3];
     if (w >= n_work) break;
@@ -564,8 +564,7 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_b_kernel(DevArgs A) {
 }
 
 static int grim_launch_plan_b(DevArgs &A, uint32_t n_slots, hipStream_t stream) {
-  // the plan-A kernel leaves the list of subjects in next_list/next_count; restart the work counter
-  if (hipMemsetAsync(A.queue, 0, 4, stream) != hipSuccess) return -1;
+  // the plan-A kernels leave the list of subjects in next_list/next_count
   hipLaunchKernelGGL(grim_plan_b_kernel, dim3(n_slots), dim3(GRIM_WG), 0, stream, A);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

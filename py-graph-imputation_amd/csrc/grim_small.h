@@ -1,0 +1,195 @@
+// grim_small.h -- Plan A for the simplest and by far most common subject class: every locus typed,
+// no '/' ambiguity, one population (BASELINE configs 2 and 3).  Same semantics as
+// grim_plan_a_kernel, specialised so that ONE HALF WAVE handles a subject entirely in registers:
+//
+//   * the 2^5 = 32 ways of picking, per locus, the allele of side 1 or side 2 are exactly the 32
+//     candidate haplotypes of all 16 phases x 2 sides (gen_phases, impute.py:274-303), so lane c of
+//     the half wave owns combination c: key -> hash probe -> node -> frequency (coalesced across
+//     the two subjects of the wave, no LDS);
+//   * phase i pairs combination i with its complement i^31 (a lane shuffle); with one population a
+//     top list has one entry, so there is one haplotype pair per phase and the reference's
+//     (phase,h,k) order is the lane order;
+//   * ladder, MaxProb, final epsilon, left-to-right sums and the stable ranking are wave
+//     reductions / shuffles over those <=16 lanes.
+//
+// Rows go to a pre-assigned fixed-stride region of the row pool (no atomics on the hot path).
+#pragma once
+#include "grim_pair.h"
+
+#define GRIM_SMALL_ROWS_FIXED 3  // umug, umug.pops, pmug.pops; then up to 16 pmug rows
+
+__device__ __forceinline__ double half_shfl_d(double v, int src_in_half) {
+  return __shfl(v, (threadIdx.x & 32) | src_in_half);
+}
+__device__ __forceinline__ uint32_t half_shfl_u(uint32_t v, int src_in_half) {
+  return __shfl(v, (threadIdx.x & 32) | src_in_half);
+}
+
+// what the library keeps in HBM per fast-path subject (built once in grim_batch_upload)
+struct SmallRec {
+  uint16_t tok[2 * GRIM_MAXL];  // position l: side-1 allele, side-2 allele
+  uint8_t slot[GRIM_MAXL];
+  uint8_t same;                 // positions whose two sides are textually identical
+  uint16_t prior_idx;
+  uint32_t si;                  // subject index in the batch
+};                              // 32 bytes
+
+__global__ __launch_bounds__(GRIM_WG) void grim_plan_a_small_kernel(DevArgs A, const SmallRec *recs, uint32_t n,
+                                                                   uint32_t row_base, uint32_t row_stride) {
+  const DevGraph &g = A.g;
+  const int hl = threadIdx.x & 31;            // lane inside the half wave = combination
+  const uint32_t w = blockIdx.x * (GRIM_WG / 32) + (threadIdx.x >> 5);
+  const bool live = w < n;
+  // ---- candidate of this lane: one 32-byte record (same address for the half wave), one probe ----
+  uint32_t node = GRIM_NONE;
+  uint64_t mykey = 0;
+  double f = 0.0;
+  uint32_t same = 0, si = 0;
+  double w_prior = 0.0;
+  if (live) {
+    const uint4 *rp = (const uint4 *)(recs + w);
+    const uint4 r0 = rp[0], r1 = rp[1];
+    const uint32_t words[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+    // tok[k] = half k&1 of word k>>1; slot[l] = byte l of bytes 20..24; same = byte 25; prior = bytes 26..27
+    same = (words[6] >> 8) & 0xFFu;
+    si = words[7];
+    w_prior = A.priors[(uint64_t)(words[6] >> 16)];  // P == 1: the matrix is one number
+#pragma unroll
+    for (int l = 0; l < GRIM_MAXL; ++l) {
+      const uint32_t tw = words[l];                       // tok[2l] | tok[2l+1] << 16
+      const uint32_t t = ((hl >> l) & 1) ? (tw >> 16) : (tw & 0xFFFFu);
+      const uint32_t slot = (l < 4 ? (words[5] >> (8 * l)) : words[6]) & 0xFFu;
+      mykey |= (uint64_t)(t + 1u) << (GRIM_ABITS * slot);
+    }
+    uint32_t h = (uint32_t)mix64(mykey) & g.fht_mask;
+    for (;;) {
+      const FullEnt e = g.fht[h];
+      if (e.key == mykey) { node = (uint32_t)e.node; f = e.f0; break; }
+      if (e.key == 0) break;
+      h = (h + 1) & g.fht_mask;
+    }
+  }
+  // ---- phases: lane i < 16 is phase i, its partner is the complementary combination ---------
+  const uint32_t node2 = half_shfl_u(node, hl ^ 31);
+  const double f2 = half_shfl_d(f, hl ^ 31);
+  const uint64_t key2 = ((uint64_t)half_shfl_u((uint32_t)(mykey >> 32), hl ^ 31) << 32) | half_shfl_u((uint32_t)mykey, hl ^ 31);
+  const uint32_t het4 = 15u & ~same;
+  bool kept = hl < 16 && ((uint32_t)hl & ~het4 & 15u) == 0 && (!((same >> 4) & 1u) || ((uint32_t)hl ^ het4) >= (uint32_t)hl);
+  // entries need p > 0 (impute.py:430); a missing node has f == 0
+  const bool pair_ok = live && kept && f > 0.0 && f2 > 0.0;
+  const bool same_hap = node == node2;
+  PairRef pr;
+  pr.p1 = f; pr.p2 = f2; pr.m2 = f2;
+  pr.e1 = same_hap ? 0u : 1u; pr.e2 = 0u;  // only equality of the two haplotypes matters below
+  // ---- ladder: first step that accepts any pair (impute.py:1665-1687) -------------------------
+  int best = A.prm.n_ladder;
+  if (pair_ok)
+    for (int idx = 0; idx < A.prm.n_ladder; ++idx)
+      if (pair_accept(A.prm.ladder[idx], pr, w_prior)) { best = idx; break; }
+  for (int d = 1; d < 16; d <<= 1) {
+    int o = __shfl_xor(best, d);
+    best = o < best ? o : best;
+  }
+  best = __shfl(best, threadIdx.x & 32);  // lanes 16..31 of the half did not take part
+  double eps = best < A.prm.n_ladder ? A.prm.ladder[best] : 0.0;
+  bool acc = pair_ok && best < A.prm.n_ladder && pair_accept(eps, pr, w_prior);
+  double prob = acc ? pair_prob(pr, w_prior) : 0.0;
+  double mx = prob;
+  for (int d = 1; d < 16; d <<= 1) {
+    double o = __shfl_xor(mx, d);
+    mx = o > mx ? o : mx;
+  }
+  mx = half_shfl_d(mx, 0);
+  if (best < A.prm.n_ladder && eps > 0.0) {
+    eps = mx / 100000.0;  // impute.py:1685, then the last round
+    acc = pair_ok && pair_accept(eps, pr, w_prior);
+    prob = acc ? pair_prob(pr, w_prior) : 0.0;
+    mx = prob;
+    for (int d = 1; d < 16; d <<= 1) {
+      double o = __shfl_xor(mx, d);
+      mx = o > mx ? o : mx;
+    }
+    mx = half_shfl_d(mx, 0);
+  }
+  const uint64_t bal = __ballot(acc);
+  const uint32_t accmask = (uint32_t)((threadIdx.x & 32) ? (bal >> 32) : bal) & 0xFFFFu;
+  const uint32_t nU = __popc(accmask);
+  // ---- sums in phase order; one genotype and one population cell hold every pair ----------------
+  double total = 0.0;
+  bool first = true;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    double pi = half_shfl_d(prob, i);
+    if ((accmask >> i) & 1u) {
+      total = first ? pi : total + pi;
+      first = false;
+    }
+  }
+  // stable ranking of the phased pairs: bigger first, earlier phase first on ties
+  uint32_t rank = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    double pi = half_shfl_d(prob, i);
+    if (((accmask >> i) & 1u) && (pi > prob || (pi == prob && i < hl))) ++rank;
+  }
+  // algorithmic byte counters: 32 probes, one frequency vector per hit (sharded to dodge contention)
+  {
+    // a kept phase looks up its two sides; combinations of dropped (duplicate) phases do not count
+    const uint64_t need = __ballot(live && kept), needp = __ballot(live && kept && node != GRIM_NONE),
+                   needq = __ballot(live && kept && node2 != GRIM_NONE);
+    if ((threadIdx.x & 63) == 0 && need) {
+      unsigned long long *c = A.counters + 8 + 4 * (blockIdx.x & 63);
+      atomicAdd(&c[0], 2ull * (unsigned long long)__popcll(need));
+      atomicAdd(&c[2], (unsigned long long)(__popcll(needp) + __popcll(needq)));
+    }
+  }
+  if (!live) return;
+  // ---- output ----------------------------------------------------------------------------------
+  const uint32_t off = row_base + w * row_stride;
+  const int first_lane = nU ? (__ffs(accmask) - 1) : 0;
+  if (nU > 0) {
+    const uint32_t n_pm = A.prm.out_haps ? (nU < A.prm.n_results ? nU : A.prm.n_results) : 0;
+    if (acc && A.prm.out_haps && rank < n_pm) {
+      grim_row r;
+      r.a = mykey;  // a found node's key is the key that found it
+      r.b = key2;
+      r.prob = prob;
+      r.popa = 0; r.popb = 0;
+      A.rows[off + GRIM_SMALL_ROWS_FIXED + rank] = r;
+    }
+    if (hl == first_lane) {
+      grim_row r;
+      r.a = mykey;
+      r.b = key2;
+      r.prob = total;
+      r.popa = 0; r.popb = 0;
+      if (A.prm.out_muug) A.rows[off + 0] = r;
+      r.a = 0; r.b = 0;
+      if (A.prm.out_muug) A.rows[off + 1] = r;
+      if (A.prm.out_haps) A.rows[off + 2] = r;
+      grim_subject_result out;
+      out.status = GRIM_ST_OK; out.plan = 'a'; out.reason = 0; out.pad = 0;
+      out.n_pairs = nU;
+      out.n_genotypes = 1;
+      out.row_off[GRIM_T_UMUG] = off + 0;       out.n_rows[GRIM_T_UMUG] = A.prm.out_muug ? 1 : 0;
+      out.row_off[GRIM_T_UMUG_POPS] = off + 1;  out.n_rows[GRIM_T_UMUG_POPS] = (A.prm.out_muug && A.prm.n_pop_results) ? 1 : 0;
+      out.row_off[GRIM_T_PMUG] = off + GRIM_SMALL_ROWS_FIXED; out.n_rows[GRIM_T_PMUG] = n_pm;
+      out.row_off[GRIM_T_PMUG_POPS] = off + 2;  out.n_rows[GRIM_T_PMUG_POPS] = (A.prm.out_haps && A.prm.n_pop_results) ? 1 : 0;
+      if (!A.prm.n_results) out.n_rows[GRIM_T_UMUG] = 0;
+      out.max_prob = mx;
+      A.res[si] = out;
+    }
+  } else if (hl == 0) {
+    grim_subject_result out;
+    memset(&out, 0, sizeof(out));
+    out.plan = 'a';
+    if (A.prm.planb) {
+      out.status = GRIM_ST_UNSUPPORTED;  // overwritten by the plan-B kernel
+      out.reason = 2;
+      A.next_list[atomicAdd(A.next_count, 1u)] = si;
+    } else {
+      out.status = GRIM_ST_MISS;
+    }
+    A.res[si] = out;
+  }
+}

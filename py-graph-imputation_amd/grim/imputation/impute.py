@@ -349,6 +349,28 @@ class Imputation(object):
 
     # ---- file driver (impute.py:1985-2155) ---------------------------------------------------------------
     def impute_file(self, config, planb=None, em_mr=False, em=False):
+        with open(config["imputation_input_file"], "r") as fh:
+            lines = fh.readlines()
+        texts = self.impute_lines(lines, config, planb=planb, em_mr=em_mr)
+        self.write_outputs(config, texts)
+
+    @staticmethod
+    def write_outputs(config, texts):
+        names = [("umug", "imputation_out_umug_freq_file", "output_MUUG"),
+                 ("umug_pops", "imputation_out_umug_pops_file", "output_MUUG"),
+                 ("pmug", "imputation_out_hap_freq_file", "output_haplotypes"),
+                 ("pmug_pops", "imputation_out_hap_pops_file", "output_haplotypes"),
+                 ("miss", "imputation_out_miss_file", None), ("problem", "imputation_out_problem_file", None)]
+        for key, path_key, flag in names:
+            if flag is not None and not config[flag]:
+                continue
+            with open(config[path_key], "w") as fh:
+                fh.write(texts[key])
+
+    def impute_lines(self, lines, config, planb=None, em_mr=False, line_offset=0):
+        """The body of impute_file on a list of input lines.  Returns the six output texts keyed
+        'umug','umug_pops','pmug','pmug_pops','miss','problem'.  `line_offset` is the global index
+        of lines[0] (multi-GPU shards keep the reference's line numbers in .miss/.problem)."""
         priority = config["priority"]
         muug_on = config["output_MUUG"]
         haps_on = config["output_haplotypes"]
@@ -361,12 +383,9 @@ class Imputation(object):
         self._prior_cache, self._priors = {}, []
         self.unsupported = []
 
-        with open(config["imputation_input_file"], "r") as fh:
-            lines = fh.readlines()
-
         outcome = []  # per line: (kind, subject_id, raw line, device index)
         records = []
-        for i, raw in enumerate(lines):
+        for raw in lines:
             line = raw.rstrip()
             sid = None
             try:
@@ -376,7 +395,7 @@ class Imputation(object):
                 race1 = race2 = None
                 if len(parts) > 2:
                     race1, race2 = parts[2], parts[3]
-                pidx = self._prior_index(race1 or "", race2 or "", priority) if (race1 or race2) else self._prior_index("", "", priority)
+                pidx = self._prior_index(race1 or "", race2 or "", priority)
                 kind, payload = self._tokenise(gl, planb)
                 if kind == _DEV:
                     outcome.append((_DEV, sid, line, len(records)))
@@ -393,66 +412,54 @@ class Imputation(object):
             res, rows = np.zeros(0, dtype=nat.RESULT_DT), np.zeros(0, dtype=nat.ROW_DT)
         per_subject = (timeit.default_timer() - start) / max(1, len(records))
 
-        bad = [(i, outcome[i][1], int(res[outcome[i][3]]["reason"])) for i in range(len(outcome))
+        bad = [(line_offset + i, outcome[i][1], int(res[outcome[i][3]]["reason"])) for i in range(len(outcome))
                if outcome[i][0] == _DEV and res[outcome[i][3]]["status"] == nat.ST_UNSUPPORTED]
         self.unsupported = bad
         if bad and self.on_unsupported == "raise":
             raise UnsupportedSubjects(bad)
         skip = {i for i, _, _ in bad}
 
-        out = {}
-        if muug_on:
-            out["umug"] = open(config["imputation_out_umug_freq_file"], "w")
-            out["umug_pops"] = open(config["imputation_out_umug_pops_file"], "w")
-        if haps_on:
-            out["pmug"] = open(config["imputation_out_hap_freq_file"], "w")
-            out["pmug_pops"] = open(config["imputation_out_hap_pops_file"], "w")
-        miss = open(config["imputation_out_miss_file"], "w")
-        problem = open(config["imputation_out_problem_file"], "w")
+        out = {k: [] for k in ("umug", "umug_pops", "pmug", "pmug_pops", "miss", "problem")}
         say = (lambda *a: None) if self.quiet else print
-        try:
-            for i, (kind, sid, line, di) in enumerate(outcome):
-                if i in skip:
-                    continue
-                if kind == _PROBLEM_RAW:
-                    say(f"{i} Subject: {sid} - Exception")
-                    problem.write(str(line) + "\n")
-                    continue
-                if kind == _PROBLEM_ID:
-                    problem.write(str(i) + "," + str(sid) + "\n")
-                    continue
-                if kind == _MISS_NO_DEVICE:
-                    n_pairs = n_geno = 0
-                    r = None
-                else:
-                    r = res[di]
-                    n_pairs = int(r["n_pairs"]) if haps_on else 0
-                    n_geno = int(r["n_genotypes"]) if muug_on else 0
-                # impute.py:2065-2068 -- with output_haplotypes off res_haps["Haps"] is the 3-char
-                # placeholder "Nan", whose len() is not 0, so .miss is never written then
-                if haps_on and n_pairs == 0 and n_geno == 0:
-                    miss.write(str(i) + "," + str(sid) + "\n")
-                plan = int(r["plan"]) if r is not None else ord("a")
-                if haps_on:
-                    say("{index} Subject: {id} {hap_length} haplotypes".format(index=i, id=sid, hap_length=n_pairs))
-                    if r is not None:
-                        self._write_rows(out["pmug"], sid, rows, r, nat.T_PMUG, plan, em_mr)
-                        self._write_rows(out["pmug_pops"], sid, rows, r, nat.T_PMUG_POPS, plan, em_mr)
-                if muug_on:
-                    say("{index} Subject: {id} {hap_length} haplotypes".format(index=i, id=sid, hap_length=n_geno))
-                    if r is not None:
-                        self._write_rows(out["umug"], sid, rows, r, nat.T_UMUG, plan, em_mr)
-                        self._write_rows(out["umug_pops"], sid, rows, r, nat.T_UMUG_POPS, plan, em_mr)
-                        if plan == ord("c") and int(r["n_rows"][nat.T_UMUG_POPS]) == 0:
-                            # Plan C always reports {"all_pops,all_pops": sum(...)}, an integer 0 when it
-                            # found nothing (impute.py:1375-1378)
-                            out["umug_pops"].write(sid + ",all_pops,all_pops,0,0\n")
-                say(per_subject)
-        finally:
-            for fh in out.values():
-                fh.close()
-            miss.close()
-            problem.close()
+        for j, (kind, sid, line, di) in enumerate(outcome):
+            i = line_offset + j
+            if i in skip:
+                continue
+            if kind == _PROBLEM_RAW:
+                say(f"{i} Subject: {sid} - Exception")
+                out["problem"].append(str(line) + "\n")
+                continue
+            if kind == _PROBLEM_ID:
+                out["problem"].append(str(i) + "," + str(sid) + "\n")
+                continue
+            if kind == _MISS_NO_DEVICE:
+                n_pairs = n_geno = 0
+                r = None
+            else:
+                r = res[di]
+                n_pairs = int(r["n_pairs"]) if haps_on else 0
+                n_geno = int(r["n_genotypes"]) if muug_on else 0
+            # impute.py:2065-2068 -- with output_haplotypes off res_haps["Haps"] is the 3-char
+            # placeholder "Nan", whose len() is not 0, so .miss is never written then
+            if haps_on and n_pairs == 0 and n_geno == 0:
+                out["miss"].append(str(i) + "," + str(sid) + "\n")
+            plan = int(r["plan"]) if r is not None else ord("a")
+            if haps_on:
+                say("{index} Subject: {id} {hap_length} haplotypes".format(index=i, id=sid, hap_length=n_pairs))
+                if r is not None:
+                    self._write_rows(out["pmug"], sid, rows, r, nat.T_PMUG, plan, em_mr)
+                    self._write_rows(out["pmug_pops"], sid, rows, r, nat.T_PMUG_POPS, plan, em_mr)
+            if muug_on:
+                say("{index} Subject: {id} {hap_length} haplotypes".format(index=i, id=sid, hap_length=n_geno))
+                if r is not None:
+                    self._write_rows(out["umug"], sid, rows, r, nat.T_UMUG, plan, em_mr)
+                    self._write_rows(out["umug_pops"], sid, rows, r, nat.T_UMUG_POPS, plan, em_mr)
+                    if plan == ord("c") and int(r["n_rows"][nat.T_UMUG_POPS]) == 0:
+                        # Plan C always reports {"all_pops,all_pops": sum(...)}, an integer 0 when it
+                        # found nothing (impute.py:1375-1378)
+                        out["umug_pops"].append(sid + ",all_pops,all_pops,0,0\n")
+            say(per_subject)
+        return {k: "".join(v) for k, v in out.items()}
 
     def _write_rows(self, fh, sid, rows, r, table, plan, em_mr):
         a0 = int(r["row_off"][table])
@@ -469,4 +476,4 @@ class Imputation(object):
                     text = self._hap_name(row["a"]) + "+" + self._hap_name(row["b"])
             else:
                 text = self._pop_name(row["a"], plan) + "," + self._pop_name(row["b"], plan)
-            fh.write(sid + "," + text + "," + str(prob) + "," + str(k) + "\n")
+            fh.append(sid + "," + text + "," + str(prob) + "," + str(k) + "\n")

@@ -114,3 +114,36 @@ def test_reference_shaped_impute_one():
     line = got["umug"].splitlines()[0].split(",")
     assert list(res_m["Haps"].keys())[0] == line[1] and str(list(res_m["Haps"].values())[0]) == line[2]
     assert len(res_h["Haps"]) == len(got["pmug"].splitlines())
+
+
+def test_small_subject_kernel_equals_general_kernel(monkeypatch):
+    """The half-wave fast path (grim_small.h) and the general kernel must agree on every subject the
+    fast path accepts -- including homozygous loci, missing race columns and Plan-B hand-over."""
+    rows = synth.read_freqs(synth.CAU_FREQS)
+    gen = synth.SubjectGen(rows, 31)
+    lines = gen.full(1500)
+    # homozygous variants: copy side 1 onto side 2 at some loci
+    rng = np.random.default_rng(9)
+    for i in range(300):
+        sid, gl, r1, r2 = lines[i].split(",")
+        loci = gl.split("^")
+        for k in range(5):
+            if rng.random() < 0.4:
+                a = loci[k].split("+")[0]
+                loci[k] = a + "+" + a
+        lines[i] = ",".join([sid, "^".join(loci), r1, r2])
+    # recombinants (fully typed, no Plan-A hit) and subjects without race columns
+    for i in range(300, 400):
+        h1, h2 = gen.recombinant(), gen.draw_hap()
+        lines[i] = "R%d,%s,CAU,CAU" % (i, gen.gl(h1, h2))
+    for i in range(400, 450):
+        lines[i] = ",".join(lines[i].split(",")[:2])
+    conf = harness.base_conf(["CAU"])
+    fast, _, imp_fast = _run("cau", conf, lines, "small_on")
+    monkeypatch.setenv("GRIM_NO_SMALL", "1")
+    slow, _, imp_slow = _run("cau", conf, lines, "small_off")
+    for k in fast:
+        assert fast[k] == slow[k], k
+    exp, _ = harness.run_oracle("cau", conf, lines[:600], tag="small_orc")
+    n = len(exp["pmug"].splitlines())
+    assert fast["pmug"].splitlines()[:n] == exp["pmug"].splitlines()
