@@ -117,6 +117,17 @@ def main():
     avg_ms = per_kernel[dom]
     achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
 
+    # HBM traffic per launch of the dominant kernel: PMC numbers cannot be collected from inside this
+    # process; they come from the committed rocprofv3 --pmc passes over this same command
+    traffic, traffic_src = None, None
+    pmc_path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+    if os.path.exists(pmc_path) and args.workload == "full" and args.subjects == 10000:
+        pmc = json.load(open(pmc_path)).get(names[dom])
+        if pmc and "hbm_bytes_raw" in pmc:
+            traffic = pmc["hbm_bytes_raw"]
+            traffic_src = "profiles/r1_pmc_traffic.json: (FETCH_SIZE + WRITE_SIZE) KB x 1024 per launch, separate --pmc passes; " \
+                          "with FETCH_SIZE doubled (gfx950 wide-read correction): %d" % pmc["hbm_bytes_fetch_doubled"]
+
     out = None
     if rank == 0:
         out = {
@@ -141,7 +152,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": names[dom], "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": algo_bytes,
                 "kernel_ms": dict(zip(names, per_kernel)),
             },
