@@ -43,7 +43,7 @@ def main():
     import harness
     import synth
     from grim import _native as nat
-    from grim.imputation.impute import Imputation, _DEV
+    from grim.imputation.impute import Imputation
     from grim.imputation.networkx_graph import Graph
     from grim.run_impute_def import load_config
 
@@ -73,15 +73,18 @@ def main():
     gen = synth.SubjectGen(rows, rank)  # seed 0 on rank 0 = config 2
     lines = gen.full(args.subjects) if args.workload == "full" else gen.mixed(args.subjects)
     imp = Imputation(graph, cfg, device=local_rank)
-    records, n_tok = [], 0
-    for line in lines:
-        parts = line.split(",")
-        pidx = imp._prior_index(parts[2], parts[3], cfg["priority"])
-        kind, payload = imp._tokenise(parts[1], cfg["planb"])
-        assert kind == _DEV
-        records.append(payload + (pidx,))
-        n_tok += sum(len(ids) for pos in payload[3] for ids, _ in pos)
-    res, rows_out, batch = imp.run_batch(records, cfg, cfg["planb"], keep=True)  # upload + first run
+    import numpy as np
+    parsed = nat.Parsed(graph.adict, ("\n".join(lines) + "\n").encode(), cfg["planb"])  # C++ tokenizer of the library
+    subj, toks = parsed.subjects(), parsed.tokens()
+    assert len(subj) == len(lines)
+    records = subj
+    n_tok = int(subj["cnt"].sum())
+    priors = np.stack([imp._prior_matrix(r1, r2, cfg["priority"]) for r1, r2 in parsed.races()])
+    params = imp._params(cfg, cfg["planb"], False)
+    ctx = nat.default_context(local_rank)
+    batch = nat.DeviceBatch(ctx, graph.device(ctx), params, subj, toks, priors)  # upload: subjects now resident in HBM
+    batch.run()
+    res, rows_out = batch.results()
     n_ok = int((res["status"] == nat.ST_OK).sum())
 
     def sync_barrier():

@@ -166,6 +166,51 @@ uint32_t grim_batch_total_rows(const grim_batch *b);
 int grim_batch_results(grim_batch *b, grim_subject_result *res, grim_row *rows);
 void grim_batch_free(grim_batch *b);
 
+/* ======================= host-side helpers (CPU, multi-threaded; no GPU needed) ====================
+ * Allele dictionary, GL tokenizer and result formatter in C++ (csrc/grim_host.cpp).  They replace,
+ * for whole files at a time, the reference's per-line Python: impute_file's line handling
+ * (impute.py:2022-2036), clean_up_gl (:105-118), gl2haps (:246-272), the writers' text and the
+ * .miss/.problem rules (:24-99, 2061-2118) including CPython's str(float). */
+typedef struct grim_dict grim_dict;     /* per locus slot: allele string <-> dense id */
+typedef struct grim_parsed grim_parsed; /* a tokenised block of input lines           */
+typedef struct grim_text grim_text;     /* the six output texts                       */
+
+grim_dict *grim_dict_create(uint32_t n_loci);
+void grim_dict_free(grim_dict *d);
+int grim_dict_set_locus(grim_dict *d, uint32_t slot, const char *locus_name);
+int32_t grim_dict_intern(grim_dict *d, uint32_t slot, const char *allele); /* id, created if new; <0 = full */
+int32_t grim_dict_find(const grim_dict *d, uint32_t slot, const char *allele);
+const char *grim_dict_name(const grim_dict *d, uint32_t slot, uint32_t id);
+uint32_t grim_dict_count(const grim_dict *d, uint32_t slot);
+
+/* per-line outcome kinds */
+enum { GRIM_K_DEVICE = 0, GRIM_K_PROBLEM_ID = 1, GRIM_K_PROBLEM_RAW = 2, GRIM_K_MISS_NO_DEVICE = 3 };
+
+/* text: '\n'-separated input lines ("id,GL[,race1,race2]" or '%'-separated).  Unknown alleles are
+ * added to the dictionary.  subjects[i].prior_idx = index of the line's (race1, race2) pair in
+ * grim_parsed_race(); the caller supplies one prior matrix per pair in that order. */
+grim_parsed *grim_tokenize(grim_dict *d, const char *text, uint64_t len, int planb, int n_threads);
+void grim_parsed_free(grim_parsed *p);
+uint32_t grim_parsed_lines(const grim_parsed *p);
+uint32_t grim_parsed_subjects(const grim_parsed *p);
+const grim_subject *grim_parsed_subject_array(const grim_parsed *p);
+const uint16_t *grim_parsed_tokens(const grim_parsed *p, uint64_t *n_tokens);
+const uint8_t *grim_parsed_kinds(const grim_parsed *p);      /* [lines]                      */
+const int32_t *grim_parsed_dev_index(const grim_parsed *p);  /* [lines] subject index or -1  */
+uint32_t grim_parsed_n_races(const grim_parsed *p);
+const char *grim_parsed_race(const grim_parsed *p, uint32_t i, int which);
+const char *grim_parsed_id(const grim_parsed *p, uint32_t line, uint32_t *len);
+
+/* res/rows as returned by grim_batch_results for the subjects of `p`.  line_offset = global index
+ * of the first line (multi-GPU shards); skip = optional [lines] mask of lines to leave out.
+ * Texts: 0 .umug, 1 .umug.pops, 2 .pmug, 3 .pmug.pops, 4 .miss, 5 .problem. */
+grim_text *grim_format(const grim_dict *d, const grim_parsed *p, const grim_params *prm, const char *const *pop_names,
+                       uint32_t n_pops, const grim_subject_result *res, const grim_row *rows, uint64_t line_offset,
+                       const uint8_t *skip, int n_threads);
+const char *grim_text_get(const grim_text *t, int which, uint64_t *len);
+void grim_text_free(grim_text *t);
+int grim_format_double(double x, char *buf, int cap); /* CPython str(float) */
+
 #ifdef __cplusplus
 }
 #endif

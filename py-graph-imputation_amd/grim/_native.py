@@ -256,3 +256,194 @@ class DeviceBatch:
             self.close()
         except Exception:
             pass
+
+
+# ======================================================================================================
+# host-side helpers of the library (C++: allele dictionary, tokenizer, formatter) -- no GPU needed
+# ======================================================================================================
+K_DEVICE, K_PROBLEM_ID, K_PROBLEM_RAW, K_MISS_NO_DEVICE = 0, 1, 2, 3
+
+EXPORTS += [
+    "grim_dict_create", "grim_dict_free", "grim_dict_set_locus", "grim_dict_intern", "grim_dict_find", "grim_dict_name",
+    "grim_dict_count", "grim_tokenize", "grim_parsed_free", "grim_parsed_lines", "grim_parsed_subjects",
+    "grim_parsed_subject_array", "grim_parsed_tokens", "grim_parsed_kinds", "grim_parsed_dev_index",
+    "grim_parsed_n_races", "grim_parsed_race", "grim_parsed_id", "grim_format", "grim_text_get", "grim_text_free",
+    "grim_format_double",
+]
+
+_host_ready = False
+
+
+def host_lib():
+    global _host_ready
+    L = lib()
+    if _host_ready:
+        return L
+    L.grim_dict_create.restype = C.c_void_p
+    L.grim_dict_create.argtypes = [C.c_uint32]
+    L.grim_dict_free.argtypes = [C.c_void_p]
+    L.grim_dict_set_locus.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p]
+    L.grim_dict_intern.restype = C.c_int32
+    L.grim_dict_intern.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p]
+    L.grim_dict_find.restype = C.c_int32
+    L.grim_dict_find.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p]
+    L.grim_dict_name.restype = C.c_char_p
+    L.grim_dict_name.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+    L.grim_dict_count.restype = C.c_uint32
+    L.grim_dict_count.argtypes = [C.c_void_p, C.c_uint32]
+    L.grim_tokenize.restype = C.c_void_p
+    L.grim_tokenize.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_int, C.c_int]
+    L.grim_parsed_free.argtypes = [C.c_void_p]
+    L.grim_parsed_lines.restype = C.c_uint32
+    L.grim_parsed_lines.argtypes = [C.c_void_p]
+    L.grim_parsed_subjects.restype = C.c_uint32
+    L.grim_parsed_subjects.argtypes = [C.c_void_p]
+    L.grim_parsed_subject_array.restype = C.c_void_p
+    L.grim_parsed_subject_array.argtypes = [C.c_void_p]
+    L.grim_parsed_tokens.restype = C.c_void_p
+    L.grim_parsed_tokens.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.grim_parsed_kinds.restype = C.c_void_p
+    L.grim_parsed_kinds.argtypes = [C.c_void_p]
+    L.grim_parsed_dev_index.restype = C.c_void_p
+    L.grim_parsed_dev_index.argtypes = [C.c_void_p]
+    L.grim_parsed_n_races.restype = C.c_uint32
+    L.grim_parsed_n_races.argtypes = [C.c_void_p]
+    L.grim_parsed_race.restype = C.c_char_p
+    L.grim_parsed_race.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
+    L.grim_parsed_id.restype = C.c_void_p
+    L.grim_parsed_id.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+    L.grim_format.restype = C.c_void_p
+    L.grim_format.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Params), C.POINTER(C.c_char_p), C.c_uint32, C.c_void_p,
+                              C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
+    L.grim_text_get.restype = C.c_void_p
+    L.grim_text_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
+    L.grim_text_free.argtypes = [C.c_void_p]
+    L.grim_format_double.restype = C.c_int
+    L.grim_format_double.argtypes = [C.c_double, C.c_char_p, C.c_int]
+    _host_ready = True
+    return L
+
+
+def host_threads():
+    n = int(os.environ.get("GRIM_HOST_THREADS", "0"))
+    if n <= 0:
+        n = min(16, os.cpu_count() or 1)
+    return n
+
+
+class AlleleDict:
+    """grim_dict: the one allele dictionary shared by the graph loader, the tokenizer and the formatter."""
+
+    def __init__(self, slot_locus):
+        L = host_lib()
+        self.n = len(slot_locus)
+        self.h = L.grim_dict_create(self.n)
+        if not self.h:
+            raise NativeError("grim_dict_create failed")
+        for s, name in enumerate(slot_locus):
+            L.grim_dict_set_locus(self.h, s, name.encode())
+        self._cache = [dict() for _ in slot_locus]
+
+    def intern(self, slot, allele):
+        i = self._cache[slot].get(allele)
+        if i is None:
+            i = host_lib().grim_dict_intern(self.h, slot, allele.encode())
+            if i < 0:
+                raise OverflowError("more than %d alleles at locus slot %d" % ((1 << ABITS) - 2, slot))
+            self._cache[slot][allele] = i
+        return i
+
+    def name(self, slot, idx):
+        s = host_lib().grim_dict_name(self.h, slot, idx)
+        return None if s is None else s.decode()
+
+    def count(self, slot):
+        return int(host_lib().grim_dict_count(self.h, slot))
+
+    def __del__(self):
+        try:
+            if self.h:
+                host_lib().grim_dict_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class Parsed:
+    """grim_parsed: a block of input lines tokenised by the library."""
+
+    def __init__(self, adict, text_bytes, planb):
+        L = host_lib()
+        self.h = L.grim_tokenize(adict.h, text_bytes, len(text_bytes), 1 if planb else 0, host_threads())
+        if not self.h:
+            raise NativeError("grim_tokenize failed")
+        self.n_lines = int(L.grim_parsed_lines(self.h))
+        self.n_subjects = int(L.grim_parsed_subjects(self.h))
+
+    def _array(self, ptr, dtype, n):
+        if n == 0:
+            return np.zeros(0, dtype=dtype)
+        buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+        return np.frombuffer(buf, dtype=dtype, count=n).copy()
+
+    def subjects(self):
+        return self._array(host_lib().grim_parsed_subject_array(self.h), SUBJECT_DT, self.n_subjects)
+
+    def tokens(self):
+        n = C.c_uint64(0)
+        ptr = host_lib().grim_parsed_tokens(self.h, C.byref(n))
+        return self._array(ptr, np.uint16, int(n.value))
+
+    def kinds(self):
+        return self._array(host_lib().grim_parsed_kinds(self.h), np.uint8, self.n_lines)
+
+    def dev_index(self):
+        return self._array(host_lib().grim_parsed_dev_index(self.h), np.int32, self.n_lines)
+
+    def races(self):
+        L = host_lib()
+        return [(L.grim_parsed_race(self.h, i, 0).decode(), L.grim_parsed_race(self.h, i, 1).decode())
+                for i in range(int(L.grim_parsed_n_races(self.h)))]
+
+    def subject_id(self, line):
+        n = C.c_uint32(0)
+        ptr = host_lib().grim_parsed_id(self.h, line, C.byref(n))
+        return C.string_at(ptr, n.value).decode() if ptr else None
+
+    def format(self, adict, params, pops, res, rows, line_offset=0, skip=None):
+        L = host_lib()
+        names = (C.c_char_p * len(pops))(*[p.encode() for p in pops])
+        res = np.ascontiguousarray(res)
+        rows = np.ascontiguousarray(rows)
+        skip_p = None
+        if skip is not None:
+            skip = np.ascontiguousarray(skip, dtype=np.uint8)
+            skip_p = _ptr(skip)
+        t = L.grim_format(adict.h, self.h, C.byref(params), names, len(pops), _ptr(res) if res.size else None,
+                          _ptr(rows) if rows.size else None, line_offset, skip_p, host_threads())
+        if not t:
+            raise NativeError("grim_format failed")
+        out = {}
+        for k, key in enumerate(("umug", "umug_pops", "pmug", "pmug_pops", "miss", "problem")):
+            n = C.c_uint64(0)
+            ptr = L.grim_text_get(t, k, C.byref(n))
+            out[key] = C.string_at(ptr, n.value).decode() if n.value else ""
+        L.grim_text_free(t)
+        return out
+
+    def close(self):
+        if self.h:
+            host_lib().grim_parsed_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def format_double(x):
+    buf = C.create_string_buffer(48)
+    n = host_lib().grim_format_double(float(x), buf, 48)
+    return buf.value[:n].decode()

@@ -370,7 +370,10 @@ class Imputation(object):
     def impute_lines(self, lines, config, planb=None, em_mr=False, line_offset=0):
         """The body of impute_file on a list of input lines.  Returns the six output texts keyed
         'umug','umug_pops','pmug','pmug_pops','miss','problem'.  `line_offset` is the global index
-        of lines[0] (multi-GPU shards keep the reference's line numbers in .miss/.problem)."""
+        of lines[0] (multi-GPU shards keep the reference's line numbers in .miss/.problem).
+
+        Tokenising and formatting run in the library (C++, all host cores); Python only builds one
+        prior matrix per distinct race pair and prints the reference's per-subject lines."""
         priority = config["priority"]
         muug_on = config["output_MUUG"]
         haps_on = config["output_haplotypes"]
@@ -380,6 +383,90 @@ class Imputation(object):
             raise NotImplementedError("bin_imputation_in_file (phase masks) is not supported by this build")
         if not config["epsilon"] > 0:
             raise NotImplementedError("epsilon <= 0: the reference returns its 'NaN' sentinel and fails every subject")
+        self.unsupported = []
+        text = "".join(l if l.endswith("\n") else l + "\n" for l in lines).encode()
+        parsed = nat.Parsed(self.netGraph.adict, text, planb)
+        try:
+            races = parsed.races()
+            if len(races) >= 65535:
+                raise OverflowError("more than 65535 distinct race pairs in one batch")
+            P = len(self.populations)
+            priors = np.ones((max(1, len(races)), P, P))
+            for k, (r1, r2) in enumerate(races):
+                priors[k] = self._prior_matrix(r1, r2, priority)
+            subj = parsed.subjects()
+            kinds = parsed.kinds()
+            dev = parsed.dev_index()
+            params = self._params(config, planb, em_mr)
+            start = timeit.default_timer()
+            if len(subj):
+                res, rows = self._run_arrays(subj, parsed.tokens(), priors, params)
+            else:
+                res, rows = np.zeros(0, dtype=nat.RESULT_DT), np.zeros(0, dtype=nat.ROW_DT)
+            per_subject = (timeit.default_timer() - start) / max(1, len(subj))
+
+            skip = None
+            bad_lines = np.nonzero((kinds == nat.K_DEVICE) & (res["status"][np.maximum(dev, 0)] == nat.ST_UNSUPPORTED))[0] \
+                if len(subj) else []
+            if len(bad_lines):
+                bad = [(line_offset + int(j), parsed.subject_id(int(j)), int(res[dev[j]]["reason"])) for j in bad_lines]
+                self.unsupported = bad
+                if self.on_unsupported == "raise":
+                    raise UnsupportedSubjects(bad)
+                skip = np.zeros(len(kinds), dtype=np.uint8)
+                skip[bad_lines] = 1
+            texts = parsed.format(self.netGraph.adict, params, self.populations, res, rows, line_offset, skip)
+            if not self.quiet:
+                self._print_log(parsed, kinds, dev, res, skip, line_offset, muug_on, haps_on, per_subject)
+            return texts
+        finally:
+            parsed.close()
+
+    def _run_arrays(self, subj, tokens, priors, params):
+        ctx = nat.default_context(self.device)
+        dgraph = self.netGraph.device(ctx)
+        batch = nat.DeviceBatch(ctx, dgraph, params, subj, tokens, priors)
+        t0 = timeit.default_timer()
+        batch.run()
+        t1 = timeit.default_timer()
+        res, rows = batch.results()
+        self.last_stats = {
+            "n": len(subj), "run_s": t1 - t0, "kernel_ms": batch.kernel_ms(0), "kernel_a_ms": batch.kernel_ms(1),
+            "kernel_b_ms": batch.kernel_ms(2), "counters": batch.counters(),
+        }
+        batch.close()
+        return res, rows
+
+    def _print_log(self, parsed, kinds, dev, res, skip, line_offset, muug_on, haps_on, per_subject):
+        """stdout of impute_file (impute.py:2074-2078, 2108-2112, 2138, 2142)."""
+        for j in range(len(kinds)):
+            if skip is not None and skip[j]:
+                continue
+            i = line_offset + j
+            k = kinds[j]
+            if k == nat.K_PROBLEM_ID:
+                continue
+            sid = parsed.subject_id(j)
+            if k == nat.K_PROBLEM_RAW:
+                print(f"{i} Subject: {sid} - Exception")
+                continue
+            r = res[dev[j]] if k == nat.K_DEVICE else None
+            if haps_on:
+                print("{index} Subject: {id} {hap_length} haplotypes".format(
+                    index=i, id=sid, hap_length=int(r["n_pairs"]) if r is not None else 0))
+            if muug_on:
+                print("{index} Subject: {id} {hap_length} haplotypes".format(
+                    index=i, id=sid, hap_length=int(r["n_genotypes"]) if r is not None else 0))
+            print(per_subject)
+
+    def impute_lines_python(self, lines, config, planb=None, em_mr=False, line_offset=0):
+        """The same in pure Python host code (tokeniser `_tokenise`, formatter `_write_rows`): kept as
+        the cross-check of the C++ host helpers in tests/ and as documentation of their rules."""
+        priority = config["priority"]
+        muug_on = config["output_MUUG"]
+        haps_on = config["output_haplotypes"]
+        if planb is None:
+            planb = config["planb"]
         self._prior_cache, self._priors = {}, []
         self.unsupported = []
 
@@ -405,12 +492,10 @@ class Imputation(object):
             except Exception:  # the reference's bare except (impute.py:2141-2144)
                 outcome.append((_PROBLEM_RAW, sid, line, -1))
 
-        start = timeit.default_timer()
         if records:
             res, rows = self.run_batch(records, config, planb, em_mr)
         else:
             res, rows = np.zeros(0, dtype=nat.RESULT_DT), np.zeros(0, dtype=nat.ROW_DT)
-        per_subject = (timeit.default_timer() - start) / max(1, len(records))
 
         bad = [(line_offset + i, outcome[i][1], int(res[outcome[i][3]]["reason"])) for i in range(len(outcome))
                if outcome[i][0] == _DEV and res[outcome[i][3]]["status"] == nat.ST_UNSUPPORTED]
@@ -420,13 +505,11 @@ class Imputation(object):
         skip = {i for i, _, _ in bad}
 
         out = {k: [] for k in ("umug", "umug_pops", "pmug", "pmug_pops", "miss", "problem")}
-        say = (lambda *a: None) if self.quiet else print
         for j, (kind, sid, line, di) in enumerate(outcome):
             i = line_offset + j
             if i in skip:
                 continue
             if kind == _PROBLEM_RAW:
-                say(f"{i} Subject: {sid} - Exception")
                 out["problem"].append(str(line) + "\n")
                 continue
             if kind == _PROBLEM_ID:
@@ -444,21 +527,16 @@ class Imputation(object):
             if haps_on and n_pairs == 0 and n_geno == 0:
                 out["miss"].append(str(i) + "," + str(sid) + "\n")
             plan = int(r["plan"]) if r is not None else ord("a")
-            if haps_on:
-                say("{index} Subject: {id} {hap_length} haplotypes".format(index=i, id=sid, hap_length=n_pairs))
-                if r is not None:
-                    self._write_rows(out["pmug"], sid, rows, r, nat.T_PMUG, plan, em_mr)
-                    self._write_rows(out["pmug_pops"], sid, rows, r, nat.T_PMUG_POPS, plan, em_mr)
-            if muug_on:
-                say("{index} Subject: {id} {hap_length} haplotypes".format(index=i, id=sid, hap_length=n_geno))
-                if r is not None:
-                    self._write_rows(out["umug"], sid, rows, r, nat.T_UMUG, plan, em_mr)
-                    self._write_rows(out["umug_pops"], sid, rows, r, nat.T_UMUG_POPS, plan, em_mr)
-                    if plan == ord("c") and int(r["n_rows"][nat.T_UMUG_POPS]) == 0:
-                        # Plan C always reports {"all_pops,all_pops": sum(...)}, an integer 0 when it
-                        # found nothing (impute.py:1375-1378)
-                        out["umug_pops"].append(sid + ",all_pops,all_pops,0,0\n")
-            say(per_subject)
+            if haps_on and r is not None:
+                self._write_rows(out["pmug"], sid, rows, r, nat.T_PMUG, plan, em_mr)
+                self._write_rows(out["pmug_pops"], sid, rows, r, nat.T_PMUG_POPS, plan, em_mr)
+            if muug_on and r is not None:
+                self._write_rows(out["umug"], sid, rows, r, nat.T_UMUG, plan, em_mr)
+                self._write_rows(out["umug_pops"], sid, rows, r, nat.T_UMUG_POPS, plan, em_mr)
+                if plan == ord("c") and int(r["n_rows"][nat.T_UMUG_POPS]) == 0:
+                    # Plan C always reports {"all_pops,all_pops": sum(...)}, an integer 0 when it
+                    # found nothing (impute.py:1375-1378)
+                    out["umug_pops"].append(sid + ",all_pops,all_pops,0,0\n")
         return {k: "".join(v) for k, v in out.items()}
 
     def _write_rows(self, fh, sid, rows, r, table, plan, em_mr):

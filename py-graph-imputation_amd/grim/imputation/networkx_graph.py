@@ -68,37 +68,24 @@ class Graph(object):
             raise NotImplementedError(
                 "loci_map order differs from the alphabetical locus order; the reference finds no "
                 "haplotypes in that configuration and this build refuses it")
-        self.allele_ids = [dict() for _ in self.full_loci]  # per slot: allele string -> id
-        self.allele_names = [list() for _ in self.full_loci]
+        # one allele dictionary (C++ side of the library) shared by loader, tokenizer and formatter
+        self.adict = nat.AlleleDict(self.slot_locus)
         self.arrays = None
         self._dev = {}
 
     # ------------------------------------------------------------------------------------------
     def allele_id(self, slot, allele, create=True):
-        d = self.allele_ids[slot]
-        i = d.get(allele)
-        if i is None and create:
-            i = len(self.allele_names[slot])
-            if i >= (1 << nat.ABITS) - 2:
-                raise OverflowError("more than %d alleles at locus %s" % ((1 << nat.ABITS) - 2, self.slot_locus[slot]))
-            d[allele] = i
-            self.allele_names[slot].append(allele)
-        return i
-
-    def key_to_name(self, key):
-        parts = []
-        for s in range(len(self.full_loci)):
-            a = (int(key) >> (nat.ABITS * s)) & 0xFFF
-            if a:
-                parts.append(self.allele_names[s][a - 1])
-        return "~".join(parts)
+        return self.adict.intern(slot, allele)
 
     def key_alleles(self, key):
         out = []
         for s in range(len(self.full_loci)):
             a = (int(key) >> (nat.ABITS * s)) & 0xFFF
-            out.append(self.allele_names[s][a - 1] if a else None)
+            out.append(self.adict.name(s, a - 1) if a else None)
         return out
+
+    def key_to_name(self, key):
+        return "~".join(x for x in self.key_alleles(key) if x)
 
     # ------------------------------------------------------------------------------------------
     def build_graph(self, nodesFile, edgesFile, allEdgesFile):
@@ -197,7 +184,7 @@ class Graph(object):
             "b_conn": b_conn, "b_start": b_start, "b_nbr": b_nbr,
             "lab_start": lab_start, "lab_nodes": lab_order,
         }
-        self.n_graph_alleles = [len(x) for x in self.allele_names]
+        self.n_graph_alleles = [self.adict.count(s) for s in range(nl)]
         self._dev = {}
         return self
 

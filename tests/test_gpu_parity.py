@@ -147,3 +147,18 @@ def test_small_subject_kernel_equals_general_kernel(monkeypatch):
     exp, _ = harness.run_oracle("cau", conf, lines[:600], tag="small_orc")
     n = len(exp["pmug"].splitlines())
     assert fast["pmug"].splitlines()[:n] == exp["pmug"].splitlines()
+
+
+@pytest.mark.parametrize("scenario", ["cau_mixed", "pop4_edge", "cau_planc", "pop4_em_mr", "cau_muug_only"])
+def test_cpp_formatter_equals_python_formatter(scenario):
+    """impute_lines (C++ tokenizer + formatter in the library) vs impute_lines_python on device results."""
+    gname, conf, lines, exp, elog, em = harness.golden(scenario)
+    got, glog, imp = _run(gname, conf, lines, "fmt_" + scenario, em)
+    cwd = os.getcwd()
+    os.chdir(harness.ensure_graph(gname))
+    try:
+        py = imp.impute_lines_python([l + "\n" for l in lines], imp.config, em_mr=em)
+    finally:
+        os.chdir(cwd)
+    for k in py:
+        assert py[k] == got[k], k

@@ -1,0 +1,102 @@
+"""The library's C++ host helpers (allele dictionary, tokenizer, float formatter) against the Python
+host code that restates the same reference rules.  No GPU needed."""
+import math
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import harness
+import synth
+
+
+def test_float_text_equals_cpython_repr():
+    from grim import _native as nat
+
+    rng = np.random.default_rng(3)
+    vals = [0.0, 1.0, 100.0, 1e16, 1e15, 123456789012345.6, 1e-4, 1e-5, 9.999e-5, 0.00012345, 5e-324, 1.7976931348623157e308,
+            8.838563003520004e-17, 3.2495135534580065e-15, 0.1, 1 / 3, 2.5e-10, 1e22, 1.5e16, 12345678.9, 6e-05, 0.5]
+    vals += list(np.exp(rng.uniform(-60, 5, 3000)))
+    vals += [struct.unpack("<d", struct.pack("<Q", int(x)))[0] for x in rng.integers(1, 0x7FEFFFFFFFFFFFFF, 3000)]
+    for v in vals:
+        if math.isfinite(v):
+            assert nat.format_double(v) == repr(float(v)), v
+            assert nat.format_double(-v) == repr(float(-v)), v
+
+
+def _decode(g, subj, toks):
+    """subject record -> structure of allele NAMES (ids of unknown alleles depend on interning order)"""
+    out = []
+    for s in subj:
+        off = int(s["tok_off"])
+        pos = []
+        for k in range(int(s["n_loci"])):
+            sides = []
+            for side in range(2):
+                n = int(s["cnt"][k][side])
+                sides.append(([g.adict.name(int(s["slot"][k]), int(t)) for t in toks[off: off + n]], int(s["wid"][k][side])))
+                off += n
+            pos.append((int(s["slot"][k]), sides))
+        out.append((int(s["n_loci"]), int(s["pad"][0]), pos))
+    return out
+
+
+@pytest.mark.parametrize("scenario", ["cau_edge", "cau_mixed", "pop4_edge", "pop4_mixed", "cau_filter", "cau_planc"])
+def test_cpp_tokenizer_equals_python_tokenizer(scenario):
+    from grim import _native as nat
+    from grim.imputation import impute as I
+    from grim.imputation.networkx_graph import Graph
+    from grim.run_impute_def import load_config
+
+    gname, conf, lines, exp, elog, em = harness.golden(scenario)
+    work = harness.ensure_graph(gname)
+    conf2, cpath = harness._write_inputs(work, conf, lines, "tok_" + scenario)
+    cwd = os.getcwd()
+    os.chdir(work)
+    try:
+        cfg, _ = load_config(cpath)
+        g = Graph(cfg).build_graph(cfg["node_file"], cfg["top_links_file"], cfg["edges_file"])
+        imp = I.Imputation(g, cfg)
+    finally:
+        os.chdir(cwd)
+    extra = ["", "X", "onlyid,", "a,b,c", "Z1,A*01:01+A*02:01^^B*07:02+B*08:01,CAU,CAU", "Z2,A*01:01+B*07:02,CAU,CAU",
+             "Z3,A*01:01+A*02:01^A*03:01+A*11:01,CAU,CAU", "Z4,Q*01:01+Q*01:02,CAU,CAU", "Z5,+^A*01:01+A*02:01,CAU,CAU",
+             "Z6, ,CAU,CAU", "Z7,A*01:01+A*02:01+A*03:01^B*07:02+B*08:01,CAU,CAU,extra", "Z8%A*01:01+A*02:01%CAU%CAU   "]
+    all_lines = lines + extra
+    for planb in (True, False):
+        parsed = nat.Parsed(g.adict, ("\n".join(all_lines) + "\n").encode(), planb)
+        kinds = parsed.kinds()
+        dev = parsed.dev_index()
+        subj = parsed.subjects()
+        toks = parsed.tokens()
+        races = parsed.races()
+        assert parsed.n_lines == len(all_lines)
+        py_kinds, py_recs, py_ids, py_races = [], [], [], []
+        for line in all_lines:
+            line = line.rstrip()
+            sid = None
+            try:
+                parts = line.split(",") if "," in line else line.split("%")
+                sid = parts[0]
+                gl = parts[1]
+                r1 = r2 = None
+                if len(parts) > 2:
+                    r1, r2 = parts[2], parts[3]
+                kind, payload = imp._tokenise(gl, planb)
+                py_kinds.append(kind)
+                if kind == I._DEV:
+                    py_recs.append(payload)
+                    py_races.append((r1 or "", r2 or ""))
+            except Exception:
+                py_kinds.append(I._PROBLEM_RAW)
+            py_ids.append(sid)
+        assert list(kinds) == py_kinds
+        assert [parsed.subject_id(i) for i in range(len(all_lines)) if py_ids[i] is not None] == [x for x in py_ids if x is not None]
+        got = _decode(g, subj, toks)
+        assert len(got) == len(py_recs)
+        for a, (n, slots, same, pos) in zip(got, py_recs):
+            exp_pos = [(slots[k], [([g.adict.name(slots[k], t) for t in pos[k][s][0]], pos[k][s][1]) for s in range(2)]) for k in range(n)]
+            assert a == (n, same, exp_pos)
+        assert [races[int(s["prior_idx"])] for s in subj] == py_races
+        parsed.close()
