@@ -74,6 +74,25 @@ struct DevArgs {
   uint32_t *next_count;
 };
 
+// ---- optional stage timers (diagnostic build only: hipcc -DGRIM_STAMPS; never in the shipped .so) ----
+#define GRIM_NCTR (8 + 4 * 64 + 16)
+#define GRIM_STAMP_BASE (8 + 4 * 64)
+#ifdef GRIM_STAMPS
+#define STAMP_BEGIN() unsigned long long _t0 = wall_clock64()
+#define STAMP(k)                                                           \
+  do {                                                                     \
+    __syncthreads();                                                       \
+    if (threadIdx.x == 0) {                                                \
+      unsigned long long _t1 = wall_clock64();                             \
+      atomicAdd(&A.counters[GRIM_STAMP_BASE + (k)], _t1 - _t0);            \
+      _t0 = _t1;                                                           \
+    }                                                                      \
+  } while (0)
+#else
+#define STAMP_BEGIN()
+#define STAMP(k)
+#endif
+
 // ---- small helpers ------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t mix64(uint64_t x) {
   x ^= x >> 33;

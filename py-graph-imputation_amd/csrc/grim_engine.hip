@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -40,11 +41,13 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_a_kernel(DevArgs A) {
     }
     if (tid < (int)(sizeof(grim_subject_result) / 4)) ((uint32_t *)&sh.out)[tid] = 0;
     __syncthreads();
+    STAMP_BEGIN();
     enumerate_phases(sh);
     const double *prior = A.priors + (uint64_t)sh.subj.prior_idx * P * P;
     const int nph = sh.nph;
     for (int s = wave_id(); s < 2 * nph; s += GRIM_NWAVE) build_side_plan_a(A, sh, S, prior, wt[wave_id()], s >> 1, s & 1, s);
     __syncthreads();
+    STAMP(8);
     bool kept = false;
     for (int i = 0; i < nph; ++i) kept |= (sh.cand_any[2 * i] && sh.cand_any[2 * i + 1]);
     uint8_t status = GRIM_ST_MISS, reason = 0, plan = 'a';
@@ -57,18 +60,22 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_a_kernel(DevArgs A) {
       const uint32_t np = pair_offsets(sh);
       int e = A.prm.n_ladder;
       if (np > 0) e = ladder_first(A, sh, S, prior, np);
+      STAMP(9);
       uint32_t nU = 0;
       double mx = 0.0;
       if (e < A.prm.n_ladder) {
         double eps = A.prm.ladder[e];
         if (eps > 0.0) {
           pair_pass(A, sh, S, prior, np, eps, false, &mx);
+          STAMP(10);
           eps = mx / 100000.0;  // impute.py:1685
         }
         nU = pair_pass(A, sh, S, prior, np, eps, true, &mx);
+        STAMP(11);
       }
       if (nU > 0) {
         emit_tables(A, sh, S, nU, sh.out);
+        STAMP(12);
         status = GRIM_ST_OK;
         if (tid == 0) sh.out.max_prob = mx;
       } else if (A.prm.planb) {
@@ -99,7 +106,6 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_a_kernel(DevArgs A) {
   }
 }
 
-#define GRIM_NCTR (8 + 4 * 64)
 
 // zero the counters and work heads of a batch (one launch instead of several memsets)
 __global__ void grim_reset_kernel(unsigned long long *counters, uint32_t *queue, uint32_t row_head0) {
@@ -336,6 +342,20 @@ extern "C" grim_batch *grim_batch_upload(grim_ctx *c, const grim_graph *g, const
       sm = sj.cnt[l][0] == 1 && sj.cnt[l][1] == 1 && sj.wid[l][0] == 1 && sj.wid[l][1] == 1;
     (sm ? os : og).push_back(i);
   }
+  {  // longest-processing-time-first: heavy subjects (many candidates) start first so that the
+     // work-queue tail is short; stable so equal-cost subjects stay in input order
+    auto cost = [&](uint32_t i) {
+      const grim_subject &sj = d->subjects[i];
+      double c = 1.0;
+      for (int l = 0; l < sj.n_loci; ++l) c *= (double)(sj.cnt[l][0] > sj.cnt[l][1] ? sj.cnt[l][0] : sj.cnt[l][1]);
+      // untyped loci multiply the neighbour fan-out
+      for (int l = sj.n_loci; l < GRIM_MAXL; ++l) c *= 8.0;
+      return c * (double)(1u << (sj.n_loci ? sj.n_loci - 1 : 0));
+    };
+    std::vector<double> cs(d->n_subjects);
+    for (uint32_t i : og) cs[i] = cost(i);
+    std::stable_sort(og.begin(), og.end(), [&](uint32_t a, uint32_t b2) { return cs[a] > cs[b2]; });
+  }
   b->n_small = (uint32_t)os.size();
   b->n_general = (uint32_t)og.size();
   b->small_stride = GRIM_SMALL_ROWS_FIXED + (p->n_results < 16 ? p->n_results : 16);
@@ -506,6 +526,11 @@ extern "C" int grim_batch_run(grim_batch *b) {
   for (int sh = 0; sh < 64; ++sh)
     for (int k = 0; k < 3; ++k) b->counters[k] += b->hstate[8 + 4 * sh + k];
   b->rows_used = head[1];
+#ifdef GRIM_STAMPS
+  fprintf(stderr, "grim stamps (us):");
+  for (int k = 0; k < 16; ++k) fprintf(stderr, " [%d]%.0f", k, b->hstate[GRIM_STAMP_BASE + k] / 100.0);
+  fprintf(stderr, "\n");
+#endif
   if (b->counters[4] != 0 || head[1] > A.row_cap) {
     c->err = "grim_batch_run: output row pool exhausted (raise GRIM_ROW_CAP or lower the batch size)";
     return -2;

@@ -166,6 +166,54 @@ __device__ inline uint32_t pair_pass(const DevArgs &A, WgShared &sh, const Slot 
                                      double eps, bool emit, double *maxp) {
   const int P = A.g.P;
   const int tid = threadIdx.x;
+  if (np <= GRIM_WG) {
+    // few pairs: one thread per pair, first-wins dedup by looking at the earlier pairs' keys in LDS
+    uint64_t *pk = (uint64_t *)sh.qprob;  // free outside pop_tables
+    bool accd = false;
+    uint64_t key = 0;
+    double prob = 0.0;
+    if ((uint32_t)tid < np) {
+      PairRef pr = pair_ref(sh, S, tid);
+      double w = prior[ENT_POP(pr.e1) * P + ENT_POP(pr.e2)];
+      if (pair_accept(eps, pr, w)) {
+        accd = true;
+        uint32_t lo = pr.e1 < pr.e2 ? pr.e1 : pr.e2, hi = pr.e1 < pr.e2 ? pr.e2 : pr.e1;
+        key = ((uint64_t)lo << 32) | hi | GRIM_VALID;
+        prob = pair_prob(pr, w);
+      }
+    }
+    pk[tid] = key;
+    __syncthreads();
+    bool win = accd;
+    for (int f2 = 0; f2 < tid && win; ++f2) win = pk[f2] != key;
+    uint64_t m = __ballot(win);
+    double mx = win ? prob : 0.0;
+    for (int d = 32; d > 0; d >>= 1) {
+      double o = __shfl_xor(mx, d);
+      if (o > mx) mx = o;
+    }
+    if (lane_id() == 0) {
+      sh.tmp[wave_id()] = (uint32_t)__popcll(m);
+      sh.dtmp[wave_id()] = mx;
+    }
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+    mx = sh.dtmp[0];
+    for (int w2 = 0; w2 < GRIM_NWAVE; ++w2) {
+      uint32_t t = sh.tmp[w2];
+      if (w2 < wave_id()) base += t;
+      tot += t;
+      if (sh.dtmp[w2] > mx) mx = sh.dtmp[w2];
+    }
+    if (emit && win) {
+      uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
+      S.Useq[pos] = tid;
+      S.Uprob[pos] = prob;
+    }
+    __syncthreads();
+    *maxp = mx;
+    return tot;
+  }
   uint32_t cap = 64;
   while (cap < 2 * np) cap <<= 1;
   if (cap > A.tab_cap) cap = A.tab_cap;
@@ -260,7 +308,7 @@ __device__ inline uint32_t pair_pass(const DevArgs &A, WgShared &sh, const Slot 
 //       2 = every pair its own group (write_best_hap_race_pairs, impute.py:79-85)
 // On return: ng groups; rank order in sva/svb (group ids, best first) -> *order_buf; gsum/ghead filled.
 __device__ inline uint32_t group_and_rank(const DevArgs &A, WgShared &sh, const Slot &S, uint32_t nU, int kind,
-                                          uint32_t **order_out) {
+                                          uint32_t **order_out, uint32_t want) {
   const int tid = threadIdx.x;
   uint32_t ng = 0;
   if (kind == 2) {
@@ -375,6 +423,101 @@ __device__ inline uint32_t group_and_rank(const DevArgs &A, WgShared &sh, const 
     S.sva[g] = g;
   }
   __syncthreads();
+  if (want > 0 && want <= 1024 && want * 4 <= ng) {
+    // Only rows [0,want) are written.  MSD radix select finds the want-th smallest key T; groups
+    // with key < T plus the first ties (group id order = first-seen order) are gathered in id
+    // order and ranked by counting in LDS.
+    uint64_t prefix = 0;
+    uint32_t remaining = want;
+    uint32_t *bins = sh.tmp + GRIM_NWAVE;  // [16]
+    for (int shift = 60; shift >= 0; shift -= 4) {
+      if (tid < 16) bins[tid] = 0;
+      __syncthreads();
+      const uint64_t himask = shift == 60 ? 0ull : (~0ull << (shift + 4));
+      uint32_t loc[16];
+#pragma unroll
+      for (int d = 0; d < 16; ++d) loc[d] = 0;
+      for (uint32_t g = tid; g < ng; g += GRIM_WG) {
+        uint64_t k = S.ska[g];
+        if ((k & himask) == (prefix & himask)) {
+          uint32_t dg = (uint32_t)(k >> shift) & 15u;
+#pragma unroll
+          for (int d = 0; d < 16; ++d) loc[d] += (dg == (uint32_t)d) ? 1u : 0u;
+        }
+      }
+#pragma unroll
+      for (int d = 0; d < 16; ++d) {
+        uint32_t v = loc[d];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane_id() == 0 && v) atomicAdd(&bins[d], v);
+      }
+      __syncthreads();
+      uint32_t cum = 0, dsel = 15;
+      for (uint32_t d = 0; d < 16; ++d) {
+        if (cum + bins[d] >= remaining) {
+          dsel = d;
+          break;
+        }
+        cum += bins[d];
+      }
+      remaining -= cum;
+      prefix |= (uint64_t)dsel << shift;
+      __syncthreads();
+    }
+    const uint64_t T = prefix;  // `remaining` ties with key == T are taken, the earliest ones
+    uint32_t taken = 0, ties = 0;
+    uint64_t *lk = (uint64_t *)sh.hist;          // [1024] keys
+    uint32_t *lg = (uint32_t *)(lk + 1024);      // [1024] group ids
+    for (uint32_t g0 = 0; g0 < ng; g0 += GRIM_WG) {
+      uint32_t g = g0 + tid;
+      uint64_t k = g < ng ? S.ska[g] : ~0ull;
+      bool less = g < ng && k < T, tie = g < ng && k == T;
+      // ties in id order
+      uint64_t mt = __ballot(tie);
+      if (lane_id() == 0) sh.tmp[wave_id()] = (uint32_t)__popcll(mt);
+      __syncthreads();
+      uint32_t tbase = ties, ttot = 0;
+      for (int w2 = 0; w2 < GRIM_NWAVE; ++w2) {
+        uint32_t t = sh.tmp[w2];
+        if (w2 < wave_id()) tbase += t;
+        ttot += t;
+      }
+      __syncthreads();
+      bool pick = less || (tie && tbase + (uint32_t)__popcll(mt & ((1ull << lane_id()) - 1ull)) < remaining);
+      ties += ttot;
+      uint64_t mp = __ballot(pick);
+      if (lane_id() == 0) sh.tmp[wave_id()] = (uint32_t)__popcll(mp);
+      __syncthreads();
+      uint32_t pbase = taken, ptot = 0;
+      for (int w2 = 0; w2 < GRIM_NWAVE; ++w2) {
+        uint32_t t = sh.tmp[w2];
+        if (w2 < wave_id()) pbase += t;
+        ptot += t;
+      }
+      if (pick) {
+        uint32_t pos = pbase + (uint32_t)__popcll(mp & ((1ull << lane_id()) - 1ull));
+        if (pos < 1024) {
+          lk[pos] = k;
+          lg[pos] = g;
+        }
+      }
+      taken += ptot;
+      __syncthreads();
+    }
+    // taken == want; rank by (key asc, id asc) -- ids were gathered in ascending order
+    for (uint32_t i = tid; i < taken; i += GRIM_WG) {
+      uint64_t k = lk[i];
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < taken; ++j) {
+        uint64_t k2 = lk[j];
+        rank += (k2 < k || (k2 == k && j < i)) ? 1u : 0u;
+      }
+      S.svb[rank] = lg[i];
+    }
+    __syncthreads();
+    *order_out = S.svb;
+    return ng;
+  }
   int w = wg_radix_sort(S.ska, S.sva, S.skb, S.svb, ng, 64, sh.hist, sh.tmp);
   *order_out = w ? S.svb : S.sva;
   return ng;
@@ -421,7 +564,29 @@ __device__ inline void pop_tables(const DevArgs &A, WgShared &sh, const Slot &S,
       if ((c / P) > (c % P)) continue;
       double s = S.qsum[c];
       uint32_t first = S.qfirst[c];
-      for (uint32_t r = 0; r < cnt; ++r) {
+      uint32_t r = 0;
+      // eight LDS reads in flight per step; the adds stay a strict left-to-right chain
+      for (; r + 8 <= cnt; r += 8) {
+        uint16_t cc[8];
+        double pp[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          cc[q] = sh.qcell[r + q];
+          pp[q] = sh.qprob[r + q];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          if (cc[q] == c) {
+            if (first == GRIM_NONE) {
+              first = u0 + r + q;
+              s = pp[q];
+            } else {
+              s = s + pp[q];
+            }
+          }
+        }
+      }
+      for (; r < cnt; ++r) {
         if (sh.qcell[r] == c) {
           if (first == GRIM_NONE) {
             first = u0 + r;
@@ -497,6 +662,146 @@ __device__ inline void pop_tables(const DevArgs &A, WgShared &sh, const Slot &S,
   __syncthreads();
 }
 
+// ---- <= 64 accepted pairs: the four tables by ONE wave with shuffles (no hash table, no barriers) ----
+// Every lane holds one pair; lanes with equal group key form a group, the lowest lane is its
+// first-seen member, every member adds the group's probabilities in lane (= sequence) order.
+__device__ __forceinline__ void wave_group(uint64_t klo, uint64_t khi, double prob, bool act, int n, int &head, double &sum) {
+  const int lane = lane_id();
+  head = lane;
+  sum = 0.0;
+  bool first = true;
+  for (int j = 0; j < n; ++j) {
+    uint64_t a = __shfl(klo, j), b = __shfl(khi, j);
+    double pj = __shfl(prob, j);
+    if (act && a == klo && b == khi) {
+      if (j < head) head = j;
+      sum = first ? pj : sum + pj;
+      first = false;
+    }
+  }
+}
+
+__device__ __forceinline__ uint32_t wave_rank(double sum, bool is_head, int n) {
+  const int lane = lane_id();
+  const uint64_t hm = __ballot(is_head);
+  uint32_t rank = 0;
+  for (int j = 0; j < n; ++j) {
+    double sj = __shfl(sum, j);
+    if (((hm >> j) & 1ull) && (sj > sum || (sj == sum && j < lane))) ++rank;
+  }
+  return rank;
+}
+
+__device__ __forceinline__ uint32_t wave_alloc_rows(const DevArgs &A, uint32_t n) {
+  uint32_t off = 0;
+  if (lane_id() == 0 && n) {
+    off = atomicAdd(A.row_head, n);
+    if (off + n > A.row_cap) {
+      atomicExch(&A.counters[4], 1ull);
+      off = GRIM_NONE;
+    }
+  }
+  return __shfl(off, 0);
+}
+
+__device__ inline void emit_small(const DevArgs &A, WgShared &sh, const Slot &S, uint32_t nU, grim_subject_result &out) {
+  const int lane = lane_id();
+  const int n = (int)nU;
+  const bool act = lane < n;
+  const int P = A.g.P;
+  uint32_t e1 = 0, e2 = 0;
+  double prob = 0.0;
+  if (act) {
+    PairRef pr = pair_ref(sh, S, S.Useq[lane]);
+    e1 = pr.e1;
+    e2 = pr.e2;
+    prob = S.Uprob[lane];
+  }
+  const uint32_t pa = ENT_POP(e1), pb = ENT_POP(e2), h1 = ENT_HAP(e1), h2 = ENT_HAP(e2);
+  const uint64_t k1 = act ? hap_key(A.g, S, h1) : 0, k2 = act ? hap_key(A.g, S, h2) : 0;
+  int head;
+  double sum;
+  // ---- population pairs (both pops files share the sums) ----------------------------------------
+  {
+    const uint64_t qk = ((uint64_t)(pa < pb ? pa : pb) * (uint64_t)P + (pa < pb ? pb : pa)) + 1;
+    wave_group(qk, 0, prob, act, n, head, sum);
+    const bool is_head = act && head == lane;
+    const uint32_t nq = (uint32_t)__popcll(__ballot(is_head));
+    const uint32_t rank = wave_rank(sum, is_head, n);
+    for (int t = 0; t < 2; ++t) {
+      const int table = t == 0 ? GRIM_T_UMUG_POPS : GRIM_T_PMUG_POPS;
+      uint32_t want = nq < A.prm.n_pop_results ? nq : A.prm.n_pop_results;
+      if (t == 1 && A.prm.em_mr) want = nq < 1 ? nq : 1;
+      if (!(t == 0 ? A.prm.out_muug : A.prm.out_haps)) want = 0;
+      const uint32_t off = wave_alloc_rows(A, want);
+      if (lane == 0) {
+        out.row_off[table] = off == GRIM_NONE ? 0 : off;
+        out.n_rows[table] = off == GRIM_NONE ? 0 : want;
+      }
+      if (off != GRIM_NONE && is_head && rank < want) {
+        uint32_t a = pa, b = pb;
+        if (t == 0 && A.prm.pop_rank[a] > A.prm.pop_rank[b]) {
+          uint32_t x = a;
+          a = b;
+          b = x;
+        }
+        grim_row r;
+        r.a = a; r.b = b; r.prob = sum; r.popa = a; r.popb = b;
+        A.rows[off + rank] = r;
+      }
+    }
+  }
+  // ---- genotypes -----------------------------------------------------------------------------------
+  {
+    uint64_t lo = 0, hi = 0;
+#pragma unroll
+    for (int l = 0; l < GRIM_MAXL; ++l) {
+      uint64_t x = (k1 >> (GRIM_ABITS * l)) & 0xFFF, y = (k2 >> (GRIM_ABITS * l)) & 0xFFF;
+      lo |= (x < y ? x : y) << (GRIM_ABITS * l);
+      hi |= (x < y ? y : x) << (GRIM_ABITS * l);
+    }
+    wave_group(lo, hi, prob, act, n, head, sum);
+    const bool is_head = act && head == lane;
+    const uint32_t ng = (uint32_t)__popcll(__ballot(is_head));
+    const uint32_t rank = wave_rank(sum, is_head, n);
+    const uint32_t want = A.prm.out_muug ? (ng < A.prm.n_results ? ng : A.prm.n_results) : 0;
+    const uint32_t off = wave_alloc_rows(A, want);
+    if (lane == 0) {
+      out.n_genotypes = ng;
+      out.row_off[GRIM_T_UMUG] = off == GRIM_NONE ? 0 : off;
+      out.n_rows[GRIM_T_UMUG] = off == GRIM_NONE ? 0 : want;
+    }
+    if (off != GRIM_NONE && is_head && rank < want) {
+      grim_row r;
+      r.a = k1; r.b = k2; r.prob = sum; r.popa = pa; r.popb = pb;
+      A.rows[off + rank] = r;
+    }
+  }
+  // ---- haplotype pairs ------------------------------------------------------------------------------
+  {
+    uint32_t want = 0, off = 0, rank = 0;
+    bool is_head = false;
+    if (A.prm.out_haps) {
+      const uint64_t hk = A.prm.em_mr ? (uint64_t)(lane + 1) : ((((uint64_t)(h1 < h2 ? h1 : h2)) << 32) | (h1 < h2 ? h2 : h1)) + 1;
+      wave_group(hk, 0, prob, act, n, head, sum);
+      is_head = act && head == lane;
+      const uint32_t ng = (uint32_t)__popcll(__ballot(is_head));
+      rank = wave_rank(sum, is_head, n);
+      want = ng < A.prm.n_results ? ng : A.prm.n_results;
+    }
+    off = wave_alloc_rows(A, want);
+    if (lane == 0) {
+      out.row_off[GRIM_T_PMUG] = off == GRIM_NONE ? 0 : off;
+      out.n_rows[GRIM_T_PMUG] = off == GRIM_NONE ? 0 : want;
+    }
+    if (off != GRIM_NONE && is_head && rank < want) {
+      grim_row r;
+      r.a = k1; r.b = k2; r.prob = sum; r.popa = pa; r.popb = pb;
+      A.rows[off + rank] = r;
+    }
+  }
+}
+
 // Everything after the final pass: the four output tables of one subject.
 __device__ inline void emit_tables(const DevArgs &A, WgShared &sh, const Slot &S, uint32_t nU, grim_subject_result &out) {
   const int tid = threadIdx.x;
@@ -505,11 +810,19 @@ __device__ inline void emit_tables(const DevArgs &A, WgShared &sh, const Slot &S
     out.n_pairs = nU;
   }
   __syncthreads();
+  if (nU <= 64) {
+    if (wave_id() == 0) emit_small(A, sh, S, nU, out);
+    __syncthreads();
+    return;
+  }
+  STAMP_BEGIN();
   pop_tables(A, sh, S, nU, out, false);
+  STAMP(13);
   // genotype table (.umug)
   {
     uint32_t *order = nullptr;
-    uint32_t ng = group_and_rank(A, sh, S, nU, 0, &order);
+    uint32_t ng = group_and_rank(A, sh, S, nU, 0, &order, A.prm.out_muug ? A.prm.n_results : 0);
+    STAMP(14);
     uint32_t want = A.prm.out_muug ? (ng < A.prm.n_results ? ng : A.prm.n_results) : 0;
     uint32_t off = alloc_rows(A, sh, want);
     if (tid == 0) {
@@ -536,7 +849,8 @@ __device__ inline void emit_tables(const DevArgs &A, WgShared &sh, const Slot &S
     uint32_t *order = nullptr;
     uint32_t ng = 0, want = 0;
     if (A.prm.out_haps) {
-      ng = group_and_rank(A, sh, S, nU, A.prm.em_mr ? 2 : 1, &order);
+      ng = group_and_rank(A, sh, S, nU, A.prm.em_mr ? 2 : 1, &order, A.prm.n_results);
+      STAMP(15);
       want = ng < A.prm.n_results ? ng : A.prm.n_results;
     }
     uint32_t off = alloc_rows(A, sh, want);

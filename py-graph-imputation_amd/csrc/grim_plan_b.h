@@ -399,9 +399,12 @@ __device__ inline bool side_plan_c(const DevArgs &A, WgShared &sh, const Slot &S
 __device__ inline bool planb_score(const DevArgs &A, WgShared &sh, const Slot &S, const double *prior, double *mx) {
   const uint32_t np = pair_offsets(sh);
   if (np == 0) return false;
+  STAMP_BEGIN();
   uint32_t nU = pair_pass(A, sh, S, prior, np, 0.0, true, mx);
+  STAMP(2);
   if (nU == 0) return false;
   emit_tables(A, sh, S, nU, sh.out);
+  STAMP(3);
   return true;
 }
 
@@ -426,6 +429,7 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_b_kernel(DevArgs A) {
     if (tid < (int)(sizeof(grim_subject_result) / 4)) ((uint32_t *)&sh.out)[tid] = 0;
     if (tid == 0) unsupported = 0;
     __syncthreads();
+    STAMP_BEGIN();
     enumerate_phases(sh);
     const int nph = sh.nph;
     const uint16_t *tok = A.tok + sh.subj.tok_off;
@@ -450,6 +454,7 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_b_kernel(DevArgs A) {
       }
     }
     __syncthreads();
+    STAMP(0);
     bool done = false;
     double mx = 0.0;
     uint8_t status = GRIM_ST_MISS, reason = 0, plan = 'b';
@@ -478,7 +483,9 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_b_kernel(DevArgs A) {
             }
           }
           __syncthreads();
+          STAMP(1);
           done = planb_score(A, sh, S, prior, &mx);
+          STAMP(6);
         }
         // ---- rescue loop (impute.py:1490-1558): its six iterations are identical, one suffices ----
         if (!done) {

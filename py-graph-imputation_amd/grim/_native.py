@@ -20,7 +20,7 @@ ST_OK, ST_MISS, ST_UNSUPPORTED = 0, 1, 2
 T_UMUG, T_UMUG_POPS, T_PMUG, T_PMUG_POPS = 0, 1, 2, 3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libgrim_hip.so")
+LIB_PATH = os.environ.get("GRIM_LIB") or os.path.join(os.path.dirname(_HERE), "libgrim_hip.so")
 
 
 class GraphDesc(C.Structure):
