@@ -124,6 +124,16 @@ __device__ __forceinline__ uint64_t f64_ord(double x) {
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
+// value of lane j (j wave-uniform): v_readlane, not the LDS-crossbar ds_bpermute that __shfl emits
+// for a run-time index
+__device__ __forceinline__ uint32_t lane_get(uint32_t v, int j) { return (uint32_t)__builtin_amdgcn_readlane((int)v, j); }
+__device__ __forceinline__ uint64_t lane_get(uint64_t v, int j) {
+  return ((uint64_t)lane_get((uint32_t)(v >> 32), j) << 32) | lane_get((uint32_t)v, j);
+}
+__device__ __forceinline__ double lane_get(double v, int j) {
+  return __longlong_as_double((long long)lane_get((uint64_t)__double_as_longlong(v), j));
+}
+
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
   int lane = lane_id();
 #pragma unroll

@@ -394,7 +394,15 @@ __device__ inline uint32_t group_and_rank(const DevArgs &A, WgShared &sh, const 
     for (uint32_t g = tid; g < ng; g += GRIM_WG) {
       uint32_t a = S.gstart[g], b = S.gstart[g + 1];
       double s = S.Uprob[sorted[a]];
-      for (uint32_t r = a + 1; r < b; ++r) s = s + S.Uprob[sorted[r]];
+      uint32_t r = a + 1;
+      for (; r + 4 <= b; r += 4) {  // four independent gathers in flight, adds stay in order
+        double v0 = S.Uprob[sorted[r]], v1 = S.Uprob[sorted[r + 1]], v2 = S.Uprob[sorted[r + 2]], v3 = S.Uprob[sorted[r + 3]];
+        s = s + v0;
+        s = s + v1;
+        s = s + v2;
+        s = s + v3;
+      }
+      for (; r < b; ++r) s = s + S.Uprob[sorted[r]];
       S.gsum[g] = s;
     }
     __syncthreads();
@@ -560,44 +568,65 @@ __device__ inline void pop_tables(const DevArgs &A, WgShared &sh, const Slot &S,
       sh.qprob[r] = S.Uprob[u0 + r];
     }
     __syncthreads();
-    for (int c = tid; c < ncell; c += GRIM_WG) {
-      if ((c / P) > (c % P)) continue;
-      double s = S.qsum[c];
-      uint32_t first = S.qfirst[c];
-      uint32_t r = 0;
-      // eight LDS reads in flight per step; the adds stay a strict left-to-right chain
-      for (; r + 8 <= cnt; r += 8) {
-        uint16_t cc[8];
-        double pp[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          cc[q] = sh.qcell[r + q];
-          pp[q] = sh.qprob[r + q];
+    // walk the chunk in order.  Each wave takes 64 entries into registers (one per lane) and replays
+    // them through v_readlane, so the strict left-to-right fp64 chain of a cell runs at register
+    // speed instead of LDS latency; lane = cell (waves whose cells do not exist skip the walk).
+    if (ncell == 1) {
+      // one population: every pair falls into the single cell -- a bare add chain (a lone wave is
+      // issue bound at ~4 cycles per instruction, so the loop body is kept to readlane + add)
+      if (wave_id() == 0) {
+        double s = S.qsum[0];
+        uint32_t r0 = 0;
+        if (u0 == 0) {
+          s = sh.qprob[0];
+          r0 = 1;
         }
+        for (uint32_t b0 = 0; b0 < cnt; b0 += 64) {
+          const uint32_t r = b0 + lane_id();
+          const double pv = r < cnt ? sh.qprob[r] : 0.0;
+          const int lo = (int)(r0 > b0 ? r0 - b0 : 0), hi = (cnt - b0) < 64 ? (int)(cnt - b0) : 64;
+          if (lo == 0 && hi == 64) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          if (cc[q] == c) {
+            for (int j = 0; j < 64; ++j) s = s + lane_get(pv, j);
+          } else {
+            for (int j = lo; j < hi; ++j) s = s + lane_get(pv, j);
+          }
+        }
+        if (lane_id() == 0) {
+          S.qsum[0] = s;
+          S.qfirst[0] = 0;
+        }
+      }
+      __syncthreads();
+      continue;
+    }
+    for (int c0 = wave_id() * 64; c0 < ncell; c0 += GRIM_WG) {
+      const int c = c0 + lane_id();
+      const bool mine = c < ncell && (c / P) <= (c % P);
+      double s = mine ? S.qsum[c] : 0.0;
+      uint32_t first = mine ? S.qfirst[c] : 0;
+      for (uint32_t r0 = 0; r0 < cnt; r0 += 64) {
+        const uint32_t r = r0 + lane_id();
+        const uint32_t cell = r < cnt ? (uint32_t)sh.qcell[r] : 0xFFFFFFFFu;
+        const double pv = r < cnt ? sh.qprob[r] : 0.0;
+        const int lim = (cnt - r0) < 64 ? (int)(cnt - r0) : 64;
+        for (int j = 0; j < lim; ++j) {
+          const uint32_t cj = lane_get(cell, j);
+          const double pj = lane_get(pv, j);
+          if (mine && cj == (uint32_t)c) {
             if (first == GRIM_NONE) {
-              first = u0 + r + q;
-              s = pp[q];
+              first = u0 + r0 + j;
+              s = pj;
             } else {
-              s = s + pp[q];
+              s = s + pj;
             }
           }
         }
       }
-      for (; r < cnt; ++r) {
-        if (sh.qcell[r] == c) {
-          if (first == GRIM_NONE) {
-            first = u0 + r;
-            s = sh.qprob[r];
-          } else {
-            s = s + sh.qprob[r];
-          }
-        }
+      if (mine) {
+        S.qsum[c] = s;
+        S.qfirst[c] = first;
       }
-      S.qsum[c] = s;
-      S.qfirst[c] = first;
     }
     __syncthreads();
   }
@@ -671,8 +700,8 @@ __device__ __forceinline__ void wave_group(uint64_t klo, uint64_t khi, double pr
   sum = 0.0;
   bool first = true;
   for (int j = 0; j < n; ++j) {
-    uint64_t a = __shfl(klo, j), b = __shfl(khi, j);
-    double pj = __shfl(prob, j);
+    uint64_t a = lane_get(klo, j), b = lane_get(khi, j);
+    double pj = lane_get(prob, j);
     if (act && a == klo && b == khi) {
       if (j < head) head = j;
       sum = first ? pj : sum + pj;
@@ -686,7 +715,7 @@ __device__ __forceinline__ uint32_t wave_rank(double sum, bool is_head, int n) {
   const uint64_t hm = __ballot(is_head);
   uint32_t rank = 0;
   for (int j = 0; j < n; ++j) {
-    double sj = __shfl(sum, j);
+    double sj = lane_get(sum, j);
     if (((hm >> j) & 1ull) && (sj > sum || (sj == sum && j < lane))) ++rank;
   }
   return rank;
