@@ -52,10 +52,11 @@ def main():
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        have_gpu = nat.lib().grim_device_count() > 0
-        if have_gpu:
-            torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl" if have_gpu else "gloo")
+        n_dev = nat.lib().grim_device_count()
+        backend = os.environ.get("GRIM_BENCH_BACKEND") or ("nccl" if n_dev > 0 else "gloo")
+        if n_dev > 0:
+            torch.cuda.set_device(local_rank % n_dev)  # ranks > devices only in rehearsals (gloo)
+        dist.init_process_group(backend=backend)
 
     # ---- graph + subjects (host work, outside the timed region) -----------------------------------
     if rank == 0:
@@ -72,7 +73,8 @@ def main():
     rows = synth.read_freqs(synth.CAU_FREQS)
     gen = synth.SubjectGen(rows, rank)  # seed 0 on rank 0 = config 2
     lines = gen.full(args.subjects) if args.workload == "full" else gen.mixed(args.subjects)
-    imp = Imputation(graph, cfg, device=local_rank)
+    n_dev_all = max(1, nat.lib().grim_device_count())
+    imp = Imputation(graph, cfg, device=local_rank % n_dev_all)
     import numpy as np
     parsed = nat.Parsed(graph.adict, ("\n".join(lines) + "\n").encode(), cfg["planb"])  # C++ tokenizer of the library
     subj, toks = parsed.subjects(), parsed.tokens()
@@ -81,7 +83,7 @@ def main():
     n_tok = int(subj["cnt"].sum())
     priors = np.stack([imp._prior_matrix(r1, r2, cfg["priority"]) for r1, r2 in parsed.races()])
     params = imp._params(cfg, cfg["planb"], False)
-    ctx = nat.default_context(local_rank)
+    ctx = nat.default_context(local_rank % n_dev_all)
     batch = nat.DeviceBatch(ctx, graph.device(ctx), params, subj, toks, priors)  # upload: subjects now resident in HBM
     batch.run()
     res, rows_out = batch.results()

@@ -61,7 +61,8 @@ struct DevArgs {
   uint32_t ones_prior;    // index of the all-ones prior matrix (impute.py:1696-1700)
   const uint32_t *order;  // subject indices this launch works on
   uint32_t n_work;
-  uint32_t *queue;        // dynamic work counter
+  uint32_t *queue;        // [0] general work counter [1] row head [2] plan-B list length [3] plan-B work counter
+                          // [4] one-wave kernel work counter [5] its hand-over count
   grim_subject_result *res;
   grim_row *rows;
   uint32_t *row_head;
@@ -70,6 +71,7 @@ struct DevArgs {
   SlotLayout lay;
   uint32_t pair_cap, tab_cap, bset_cap;
   unsigned long long *counters;  // [0] probes [1] nbr ids [2] freq vectors [3] rows [4] overflow flag
+  uint32_t *bail_list;           // subjects the one-wave kernel hands to the general kernel (count: queue[5])
   uint32_t *next_list;           // subjects handed to the next kernel (plan B)
   uint32_t *next_count;
 };

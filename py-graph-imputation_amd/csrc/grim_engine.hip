@@ -14,6 +14,7 @@
 #include "grim_plan_a.h"
 #include "grim_plan_b.h"
 #include "grim_small.h"
+#include "grim_medium.h"
 
 // =================================================================================================
 // Plan-A kernel: one workgroup per subject, pulled from a work counter.  Waves build the phase
@@ -26,14 +27,15 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_a_kernel(DevArgs A) {
   const int tid = threadIdx.x;
   const int P = A.g.P;
   Slot S = make_slot(A, blockIdx.x);
+  const uint32_t n_bail = A.bail_list ? A.queue[5] : 0;  // written by the one-wave kernel, earlier in the stream
   if (tid < GRIM_NWAVE * 4) ((unsigned long long *)sh.wctr)[tid] = 0;
   __syncthreads();
   for (;;) {
     if (tid == 0) sh.bc[3] = atomicAdd(A.queue, 1u);
     __syncthreads();
     const uint32_t w = sh.bc[3];
-    if (w >= A.n_work) break;
-    const uint32_t si = A.order[w];
+    if (w >= A.n_work + n_bail) break;
+    const uint32_t si = w < A.n_work ? A.order[w] : A.bail_list[w - A.n_work];
     if (tid < 16) ((uint32_t *)&sh.subj)[tid] = ((const uint32_t *)&A.subj[si])[tid];
     if (tid < GRIM_SIDES) {
       sh.Tn[tid] = 0;
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_a_kernel(DevArgs A) {
 // zero the counters and work heads of a batch (one launch instead of several memsets)
 __global__ void grim_reset_kernel(unsigned long long *counters, uint32_t *queue, uint32_t row_head0) {
   for (int i = threadIdx.x; i < GRIM_NCTR; i += blockDim.x) counters[i] = 0;
-  if (threadIdx.x < 4) queue[threadIdx.x] = threadIdx.x == 1 ? row_head0 : 0u;
+  if (threadIdx.x < 8) queue[threadIdx.x] = threadIdx.x == 1 ? row_head0 : 0u;
 }
 
 // =================================================================================================
@@ -139,7 +141,8 @@ struct grim_batch {
   uint32_t n_subj, n_slots;
   SmallRec *small_recs;
   unsigned long long *hstate;  // pinned: counters + work/row heads of the last run
-  uint32_t *order_s, *order_g;  // subjects of the half-wave fast path / of the general kernel
+  uint32_t *order_s, *order_g, *order_m;  // subjects of the half-wave / general / one-wave kernels
+  uint32_t n_medium;
   uint32_t n_small, n_general, small_stride;
   hipEvent_t ev[5];
   hipGraphExec_t gexec;
@@ -333,14 +336,26 @@ extern "C" grim_batch *grim_batch_upload(grim_ctx *c, const grim_graph *g, const
     A.ones_prior = d->n_priors;
   }
   // subject classes: fully typed + unambiguous + one population -> half-wave kernel (grim_small.h)
-  std::vector<uint32_t> os, og;
+  std::vector<uint32_t> os, om, og;
   const bool small_ok = (P == 1) && p->opt_threshold > 1 && !getenv("GRIM_NO_SMALL");
   for (uint32_t i = 0; i < d->n_subjects; ++i) {
     const grim_subject &sj = d->subjects[i];
     bool sm = small_ok && sj.n_loci == GRIM_MAXL && g->d.n_loci == GRIM_MAXL;
     for (int l = 0; l < GRIM_MAXL && sm; ++l)
       sm = sj.cnt[l][0] == 1 && sj.cnt[l][1] == 1 && sj.wid[l][0] == 1 && sj.wid[l][1] == 1;
-    (sm ? os : og).push_back(i);
+    if (sm) {
+      os.push_back(i);
+      continue;
+    }
+    // one-wave kernel: all sides opened by the cartesian branch and few candidates in total
+    bool md = !getenv("GRIM_NO_MEDIUM") && sj.n_loci >= 1;
+    double cand = (double)(1u << sj.n_loci), opts = 1.0;
+    for (int l = 0; l < sj.n_loci; ++l) {
+      cand *= (double)(sj.cnt[l][0] > sj.cnt[l][1] ? sj.cnt[l][0] : sj.cnt[l][1]);
+      opts *= (double)(sj.wid[l][0] > sj.wid[l][1] ? sj.wid[l][0] : sj.wid[l][1]);
+    }
+    md = md && cand <= 2048.0 && opts < (double)p->opt_threshold;
+    (md ? om : og).push_back(i);
   }
   {  // longest-processing-time-first: heavy subjects (many candidates) start first so that the
      // work-queue tail is short; stable so equal-cost subjects stay in input order
@@ -377,16 +392,19 @@ extern "C" grim_batch *grim_batch_upload(grim_ctx *c, const grim_graph *g, const
   }
   b->order_s = upload(c, b->bufs, os.data(), os.size(), &bytes);
   b->order_g = upload(c, b->bufs, og.data(), og.size(), &bytes);
+  b->order_m = upload(c, b->bufs, om.data(), om.size(), &bytes);
+  b->n_medium = (uint32_t)om.size();
+  A.bail_list = upload<uint32_t>(c, b->bufs, nullptr, om.size(), &bytes);
   A.order = b->order_g;
   A.n_work = b->n_general;
   // one state block: counters (8 + 4*64 u64) followed by queue[4] (u32): work counter, row head,
   // plan-B list length, plan-B work counter
-  A.counters = upload<unsigned long long>(c, b->bufs, nullptr, GRIM_NCTR + 2, &bytes);
+  A.counters = upload<unsigned long long>(c, b->bufs, nullptr, GRIM_NCTR + 4, &bytes);
   A.queue = (uint32_t *)(A.counters + GRIM_NCTR);
   A.row_head = A.queue + 1;
   A.next_count = A.queue + 2;
   b->hstate = nullptr;
-  if (hipHostMalloc((void **)&b->hstate, 8 * (GRIM_NCTR + 2)) != hipSuccess) b->hstate = nullptr;
+  if (hipHostMalloc((void **)&b->hstate, 8 * (GRIM_NCTR + 4)) != hipSuccess) b->hstate = nullptr;
   A.next_list = upload<uint32_t>(c, b->bufs, nullptr, d->n_subjects, &bytes);
   A.res = upload<grim_subject_result>(c, b->bufs, nullptr, d->n_subjects, &bytes);
   // rows: enough for every subject to fill all four tables
@@ -402,7 +420,7 @@ extern "C" grim_batch *grim_batch_upload(grim_ctx *c, const grim_graph *g, const
   uint32_t slots = (uint32_t)c->n_cu * 2;
   const char *env_slots = getenv("GRIM_SLOTS");
   if (env_slots) slots = (uint32_t)atoi(env_slots);
-  if (slots > b->n_general + (p->planb ? b->n_small : 0)) slots = b->n_general + (p->planb ? b->n_small : 0);
+  if (slots > d->n_subjects) slots = d->n_subjects;
   if (slots == 0) slots = 1;
   b->n_slots = slots;
   A.pair_cap = GRIM_MAXPH * p->top_n * p->top_n;
@@ -437,7 +455,7 @@ extern "C" grim_batch *grim_batch_upload(grim_ctx *c, const grim_graph *g, const
   L.comp = take(8ull * GRIM_COMP_CAP);
   L.stride = align256(o);
   A.scratch = upload<uint8_t>(c, b->bufs, nullptr, (size_t)L.stride * slots, &bytes);
-  bool ok = A.subj && A.tok && A.priors && b->order_s && b->order_g && b->small_recs && b->hstate && A.queue && A.next_list && A.res && A.counters && A.rows && A.scratch;
+  bool ok = A.subj && A.tok && A.priors && b->order_s && b->order_g && b->order_m && A.bail_list && b->small_recs && b->hstate && A.queue && A.next_list && A.res && A.counters && A.rows && A.scratch;
   b->gexec = nullptr;
   b->graph_state = 0;
   for (int i = 0; i < 5 && ok; ++i) ok = hipEventCreate(&b->ev[i]) == hipSuccess;
@@ -464,12 +482,19 @@ static int enqueue_stage1(grim_batch *b) {
                        A, (const SmallRec *)b->small_recs, b->n_small, 0u, b->small_stride);
   }
   HIPCHK(hipEventRecord(b->ev[3], c->stream), c, -1);
-  if (b->n_general) {
-    uint32_t grid = b->n_slots < b->n_general ? b->n_slots : b->n_general;
+  if (b->n_medium) {
+    uint32_t grid = (uint32_t)c->n_cu * 10;
+    if (grid > b->n_medium) grid = b->n_medium;
+    hipLaunchKernelGGL(grim_plan_a_medium_kernel, dim3(grid), dim3(64), 0, c->stream, A, (const uint32_t *)b->order_m,
+                       b->n_medium, A.bail_list);
+  }
+  if (b->n_general + b->n_medium) {
+    uint32_t want = b->n_general + b->n_medium;
+    uint32_t grid = b->n_slots < want ? b->n_slots : want;
     hipLaunchKernelGGL(grim_plan_a_kernel, dim3(grid), dim3(GRIM_WG), 0, c->stream, A);
   }
   HIPCHK(hipEventRecord(b->ev[1], c->stream), c, -1);
-  HIPCHK(hipMemcpyAsync(b->hstate, A.counters, 8 * (GRIM_NCTR + 2), hipMemcpyDeviceToHost, c->stream), c, -1);
+  HIPCHK(hipMemcpyAsync(b->hstate, A.counters, 8 * (GRIM_NCTR + 4), hipMemcpyDeviceToHost, c->stream), c, -1);
   return 0;
 }
 
@@ -509,18 +534,18 @@ extern "C" int grim_batch_run(grim_batch *b) {
     return -1;
   }
   b->ms_b = 0;
-  uint32_t head[4];
-  memcpy(head, b->hstate + GRIM_NCTR, 16);
+  uint32_t head[8];
+  memcpy(head, b->hstate + GRIM_NCTR, 32);
   // ---- stage 2: Plan B / C only when the first stage left subjects for it ------------------------
   if (A.prm.planb && head[2] > 0) {
     HIPCHK(hipEventRecord(b->ev[4], c->stream), c, -1);
     uint32_t grid = b->n_slots < head[2] ? b->n_slots : head[2];
     if (grim_launch_plan_b(A, grid, c->stream) != 0) { c->err = "plan-B launch failed"; return -1; }
     HIPCHK(hipEventRecord(b->ev[2], c->stream), c, -1);
-    HIPCHK(hipMemcpyAsync(b->hstate, A.counters, 8 * (GRIM_NCTR + 2), hipMemcpyDeviceToHost, c->stream), c, -1);
+    HIPCHK(hipMemcpyAsync(b->hstate, A.counters, 8 * (GRIM_NCTR + 4), hipMemcpyDeviceToHost, c->stream), c, -1);
     HIPCHK(hipStreamSynchronize(c->stream), c, -1);
     HIPCHK(hipEventElapsedTime(&b->ms_b, b->ev[4], b->ev[2]), c, -1);
-    memcpy(head, b->hstate + GRIM_NCTR, 16);
+    memcpy(head, b->hstate + GRIM_NCTR, 32);
   }
   memcpy(b->counters, b->hstate, 64);
   for (int sh = 0; sh < 64; ++sh)

@@ -733,21 +733,14 @@ __device__ __forceinline__ uint32_t wave_alloc_rows(const DevArgs &A, uint32_t n
   return __shfl(off, 0);
 }
 
-__device__ inline void emit_small(const DevArgs &A, WgShared &sh, const Slot &S, uint32_t nU, grim_subject_result &out) {
+// e1/e2/prob/k1/k2: this lane's pair (entities, probability, the two 60-bit haplotype keys)
+__device__ inline void emit_small_core(const DevArgs &A, uint32_t nU, uint32_t e1, uint32_t e2, double prob, uint64_t k1,
+                                       uint64_t k2, grim_subject_result &out) {
   const int lane = lane_id();
   const int n = (int)nU;
   const bool act = lane < n;
   const int P = A.g.P;
-  uint32_t e1 = 0, e2 = 0;
-  double prob = 0.0;
-  if (act) {
-    PairRef pr = pair_ref(sh, S, S.Useq[lane]);
-    e1 = pr.e1;
-    e2 = pr.e2;
-    prob = S.Uprob[lane];
-  }
   const uint32_t pa = ENT_POP(e1), pb = ENT_POP(e2), h1 = ENT_HAP(e1), h2 = ENT_HAP(e2);
-  const uint64_t k1 = act ? hap_key(A.g, S, h1) : 0, k2 = act ? hap_key(A.g, S, h2) : 0;
   int head;
   double sum;
   // ---- population pairs (both pops files share the sums) ----------------------------------------
@@ -829,6 +822,22 @@ __device__ inline void emit_small(const DevArgs &A, WgShared &sh, const Slot &S,
       A.rows[off + rank] = r;
     }
   }
+}
+
+__device__ inline void emit_small(const DevArgs &A, WgShared &sh, const Slot &S, uint32_t nU, grim_subject_result &out) {
+  const int lane = lane_id();
+  uint32_t e1 = 0, e2 = 0;
+  double prob = 0.0;
+  uint64_t k1 = 0, k2 = 0;
+  if (lane < (int)nU) {
+    PairRef pr = pair_ref(sh, S, S.Useq[lane]);
+    e1 = pr.e1;
+    e2 = pr.e2;
+    prob = S.Uprob[lane];
+    k1 = hap_key(A.g, S, ENT_HAP(e1));
+    k2 = hap_key(A.g, S, ENT_HAP(e2));
+  }
+  emit_small_core(A, nU, e1, e2, prob, k1, k2, out);
 }
 
 // Everything after the final pass: the four output tables of one subject.

@@ -162,3 +162,27 @@ def test_cpp_formatter_equals_python_formatter(scenario):
         os.chdir(cwd)
     for k in py:
         assert py[k] == got[k], k
+
+
+def test_one_wave_kernel_equals_general_kernel(monkeypatch):
+    """grim_medium.h (one wave per subject, LDS only) against the general kernel on mixed subjects of both graphs."""
+    rows = synth.read_freqs(synth.CAU_FREQS)
+    for gname, pops, seed in (("cau", ["CAU"], 41), ("pop4", harness.POPS["pop4"], 42)):
+        lines = synth.SubjectGen(rows, seed, pops=pops).mixed(1500) + synth.edge_cases(pops[0])
+        conf = harness.base_conf(pops)
+        conf["UNK_priors"] = "MR"
+        monkeypatch.delenv("GRIM_NO_MEDIUM", raising=False)
+        fast, _, _ = _run(gname, conf, lines, "med_on")
+        monkeypatch.setenv("GRIM_NO_MEDIUM", "1")
+        slow, _, _ = _run(gname, conf, lines, "med_off")
+        monkeypatch.delenv("GRIM_NO_MEDIUM", raising=False)
+        for k in fast:
+            assert fast[k] == slow[k], (gname, k)
+    # and with a short top list (cut inside a side)
+    conf = dict(harness.base_conf(["CAU"]), max_haplotypes_number_in_phase=3)
+    lines = synth.SubjectGen(rows, 43).mixed(600, amb=0.4, miss=0.3)
+    fast, _, _ = _run("cau", conf, lines, "med_on3")
+    monkeypatch.setenv("GRIM_NO_MEDIUM", "1")
+    slow, _, _ = _run("cau", conf, lines, "med_off3")
+    for k in fast:
+        assert fast[k] == slow[k], k
