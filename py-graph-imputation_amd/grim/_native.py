@@ -77,6 +77,26 @@ class NativeError(RuntimeError):
     pass
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.  Two HIP runtimes in one process do not
+    work (whoever comes second sees no GPU), and torch.distributed's RCCL backend needs torch's, so
+    when a torch wheel is installed its runtime is loaded first and this library binds to it.
+    GRIM_HIP_RUNTIME=system keeps the system runtime (then do not use torch.cuda in the process)."""
+    if os.environ.get("GRIM_HIP_RUNTIME") == "system":
+        return
+    try:
+        import importlib.util
+
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def lib():
     """Load the shared library (once).  Raises NativeError when it has not been built."""
     global _lib
@@ -86,6 +106,7 @@ def lib():
         raise NativeError(
             "libgrim_hip.so not found at %s -- build it with `python __graft_entry__.py` "
             "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    _share_hip_runtime_with_torch()
     L = C.CDLL(LIB_PATH)
     L.grim_create.restype = C.c_void_p
     L.grim_create.argtypes = [C.c_int]
