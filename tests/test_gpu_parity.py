@@ -186,3 +186,45 @@ def test_one_wave_kernel_equals_general_kernel(monkeypatch):
     slow, _, _ = _run("cau", conf, lines, "med_off3")
     for k in fast:
         assert fast[k] == slow[k], k
+
+
+def test_config4_style_20k_properties_and_oracle_sample():
+    """BASELINE config 4 at reduced size: 4-population graph, 20k subjects with missing loci, ambiguity,
+    recombinants (Plan B / C exercised), mixed race columns."""
+    rows = synth.read_freqs(synth.CAU_FREQS)
+    pops = harness.POPS["pop4"]
+    lines = synth.SubjectGen(rows, 3, pops=pops).mixed(20000)
+    conf = harness.base_conf(pops)
+    conf["UNK_priors"] = "MR"
+    got, glog, imp = _run("pop4", conf, lines, "c4")
+    assert got["problem"] == ""
+    ids = [l.split(",")[0] for l in lines]
+    seen = [l.split(",")[0] for l in got["umug"].splitlines()]
+    order = {sid: i for i, sid in enumerate(ids)}
+    assert [order[s] for s in seen] == sorted(order[s] for s in seen)            # input order kept
+    missing = set(ids) - set(seen)
+    assert missing == {l.split(",")[1] for l in got["miss"].splitlines()}        # no result <=> .miss
+    for name in ("umug", "pmug", "umug_pops", "pmug_pops"):                       # ranks count up from 0, probabilities fall
+        last_id, last_rank, last_p = None, -1, None
+        for line in got[name].splitlines():
+            f = line.rsplit(",", 2)
+            sid = line.split(",", 1)[0]
+            rank, p = int(f[2]), float(f[1])
+            if sid != last_id:
+                assert rank == 0
+            else:
+                assert rank == last_rank + 1 and p <= last_p
+            last_id, last_rank, last_p = sid, rank, p
+    exp, _ = harness.run_oracle("pop4", conf, lines[:400], tag="c4_orc")
+    for k in ("umug", "pmug", "umug_pops", "pmug_pops"):
+        n = len(exp[k].splitlines())
+        assert got[k].splitlines()[:n] == exp[k].splitlines(), k
+
+
+def test_config5_style_high_ambiguity_threshold_1e6():
+    """BASELINE config 5 style subjects (8 alternatives per locus and side, number_of_options_threshold
+    1e6 -> 32768 candidates per side through the cartesian branch) on the CAU graph."""
+    rows = synth.read_freqs(synth.CAU_FREQS)
+    lines = synth.SubjectGen(rows, 50).high_ambiguity(3, width=8)
+    conf = dict(harness.base_conf(["CAU"]), number_of_options_threshold=1000000)
+    _against_oracle("cau", conf, lines, "c5")
