@@ -25,6 +25,12 @@ struct FullEnt {
   double reserved;
 };
 
+struct HtEnt {
+  uint64_t key;
+  uint32_t val;
+  uint32_t pad;
+};
+
 struct DevGraph {
   const FullEnt *fht;
   uint32_t fht_mask;
@@ -34,8 +40,7 @@ struct DevGraph {
   const uint32_t *a_start, *a_nbr;
   const uint32_t *b_conn, *b_start, *b_nbr;
   const uint32_t *lab_start, *lab_nodes;
-  const uint64_t *ht_key;
-  const uint32_t *ht_val;
+  const HtEnt *ht;  // exact-name index: one 16-byte entry per slot, key == 0 marks an empty slot
   uint32_t n_nodes, P, full_mask, ht_mask, n_conn, n_loci;
 };
 
@@ -164,14 +169,17 @@ __device__ __forceinline__ uint32_t wg_excl_scan(uint32_t v, uint32_t *tmp, uint
 }
 
 // ---- exact-name lookup: 64-bit key -> node id (networkx_graph.py:260,290,315) ----------------------
-__device__ __forceinline__ uint32_t graph_lookup(const DevGraph &g, uint64_t key) {
-  uint32_t h = (uint32_t)mix64(key) & g.ht_mask;
+__device__ __forceinline__ uint32_t graph_lookup_from(const DevGraph &g, uint64_t key, uint32_t h) {
   for (;;) {
-    uint64_t k = g.ht_key[h];
-    if (k == key) return g.ht_val[h];
-    if (k == 0) return GRIM_NONE;
+    const HtEnt e = g.ht[h];  // one 16-byte load gives key and node id
+    if (e.key == key) return e.val;
+    if (e.key == 0) return GRIM_NONE;
     h = (h + 1) & g.ht_mask;
   }
+}
+
+__device__ __forceinline__ uint32_t graph_lookup(const DevGraph &g, uint64_t key) {
+  return graph_lookup_from(g, key, (uint32_t)mix64(key) & g.ht_mask);
 }
 
 // plan-A neighbour range of a partial node, with the reference's sentinel quirk: the range is
@@ -218,6 +226,7 @@ struct WaveTop {
   uint32_t cstart[66];
   uint32_t cnode[64];
   uint64_t caux[64];
+  uint16_t toks[GRIM_MAXL * 64];  // this side's alternatives per position (when each list has <= 64)
 };
 
 struct TopState {

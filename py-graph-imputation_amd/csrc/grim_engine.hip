@@ -268,8 +268,15 @@ extern "C" grim_graph *grim_graph_upload(grim_ctx *c, const grim_graph_desc *d) 
   D.b_nbr = upload(c, g->bufs, d->b_nbr, d->n_b_nbr, &g->bytes);
   D.lab_start = upload(c, g->bufs, d->lab_start, (1u << GRIM_MAXL) + 1, &g->bytes);
   D.lab_nodes = upload(c, g->bufs, d->lab_nodes, d->n_nodes, &g->bytes);
-  D.ht_key = upload(c, g->bufs, hk.data(), cap, &g->bytes);
-  D.ht_val = upload(c, g->bufs, hv.data(), cap, &g->bytes);
+  {
+    std::vector<HtEnt> ht(cap);
+    for (uint32_t i = 0; i < cap; ++i) {
+      ht[i].key = hk[i];
+      ht[i].val = hv[i];
+      ht[i].pad = 0;
+    }
+    D.ht = upload(c, g->bufs, ht.data(), cap, &g->bytes);
+  }
   {  // full-haplotype table
     uint32_t nfull = d->lab_start[d->full_mask + 1] - d->lab_start[d->full_mask];
     uint32_t fcap = 64;
@@ -289,7 +296,7 @@ extern "C" grim_graph *grim_graph_upload(grim_ctx *c, const grim_graph_desc *d) 
     D.fht_mask = fcap - 1;
   }
   if (!D.fht || !D.node_key || !D.node_mask || !D.freq || !D.a_start || !D.a_nbr || !D.b_conn || !D.b_start || !D.b_nbr ||
-      !D.lab_start || !D.lab_nodes || !D.ht_key || !D.ht_val) {
+      !D.lab_start || !D.lab_nodes || !D.ht) {
     c->err = "grim_graph_upload: device allocation or copy failed";
     for (void *p : g->bufs) hipFree(p);
     delete g;

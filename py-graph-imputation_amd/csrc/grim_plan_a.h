@@ -150,24 +150,76 @@ __device__ inline void build_side_plan_a(const DevArgs &A, WgShared &sh, const S
     // cartesian opening, position 0 most significant (cutils.pyx:21-29 applied locus by locus)
     any_cand = true;
     const bool full_nodes = (mask == g.full_mask);
-    for (uint32_t c0 = 0; c0 < ncand; c0 += 64) {
-      uint32_t c = c0 + lane;
-      uint32_t node = GRIM_NONE;
-      if (c < ncand) {
+    // Four chunks of 64 candidates per step: the four first probes are independent loads in flight
+    // together; hits are expanded chunk by chunk, in order.  The candidate's mixed-radix digits are
+    // advanced by +64 with carries instead of five 32-bit divisions per candidate (a lone wave is
+    // instruction-issue bound: the divisions were most of the loop).
+    uint32_t dg[GRIM_MAXL], inc64[GRIM_MAXL];
+    {
+      uint32_t rem = (uint32_t)lane, r64 = 64;
+#pragma unroll
+      for (int l = GRIM_MAXL - 1; l >= 0; --l) {
+        dg[l] = 0;
+        inc64[l] = 0;
+        if (l < n) {
+          dg[l] = rem % cn[l];
+          rem /= cn[l];
+          inc64[l] = r64 % cn[l];
+          r64 /= cn[l];
+        }
+      }
+    }
+    // the side's allele lists in LDS (64 cycles instead of an L1/L2 round trip per digit)
+    bool in_lds = true;
+#pragma unroll
+    for (int l = 0; l < GRIM_MAXL; ++l)
+      if (l < n && cn[l] > 64) in_lds = false;
+    if (in_lds) {
+#pragma unroll
+      for (int l = 0; l < GRIM_MAXL; ++l)
+        if (l < n && (uint32_t)lane < cn[l]) L.toks[l * 64 + lane] = tok[to[l] + lane];
+      WAVE_SYNC();
+    }
+    constexpr int NQ = 8;  // chunks of 64 candidates per step: NQ independent first probes in flight
+    for (uint32_t c0 = 0; c0 < ncand; c0 += 64u * NQ) {
+      uint64_t keyq[NQ];
+      HtEnt entq[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
         uint64_t key = 0;
-        uint32_t rem = c;
+#pragma unroll
+        for (int l = 0; l < GRIM_MAXL; ++l)
+          if (l < n) {
+            const uint32_t t = in_lds ? (uint32_t)L.toks[l * 64 + dg[l]] : (uint32_t)tok[to[l] + dg[l]];
+            key |= (uint64_t)(t + 1u) << (GRIM_ABITS * sl[l]);
+          }
+        keyq[q] = key;
+        uint32_t carry = 0;  // digits += 64 (indices past ncand wrap harmlessly; `c < ncand` guards their use)
 #pragma unroll
         for (int l = GRIM_MAXL - 1; l >= 0; --l) {
           if (l < n) {
-            uint32_t d = rem % cn[l];
-            rem /= cn[l];
-            key |= (uint64_t)(tok[to[l] + d] + 1u) << (GRIM_ABITS * sl[l]);
+            uint32_t v = dg[l] + inc64[l] + carry;
+            carry = v >= cn[l] ? 1u : 0u;
+            dg[l] = carry ? v - cn[l] : v;
           }
         }
-        node = graph_lookup(g, key);
       }
-      c_probe += (ncand - c0) < 64 ? (ncand - c0) : 64;
-      expand_chunk<false>(A, prior, L, st, node, full_nodes, g.a_start, g.a_nbr, 1.0, 0, item_base, c_nbr, c_freq);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) entq[q] = g.ht[(uint32_t)mix64(keyq[q]) & g.ht_mask];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const uint32_t cq = c0 + 64u * q;
+        if (cq >= ncand) break;
+        const uint32_t c = cq + lane;
+        uint32_t node = GRIM_NONE;
+        if (c < ncand) {
+          if (entq[q].key == keyq[q]) node = entq[q].val;
+          else if (entq[q].key != 0) node = graph_lookup_from(g, keyq[q], (((uint32_t)mix64(keyq[q]) & g.ht_mask) + 1) & g.ht_mask);
+        }
+        c_probe += (ncand - cq) < 64 ? (ncand - cq) : 64;
+        if (__ballot(node != GRIM_NONE) == 0) continue;  // nothing found in this chunk (the usual case)
+        expand_chunk<false>(A, prior, L, st, node, full_nodes, g.a_start, g.a_nbr, 1.0, 0, item_base, c_nbr, c_freq);
+      }
     }
   } else {
     // label scan: every node of the typed-loci label whose alleles all belong to this side's
