@@ -100,7 +100,7 @@ typedef struct {
   uint32_t tok_off;
   uint16_t prior_idx; /* index into the batch's prior matrices (impute.py:1956-1975) */
   uint8_t n_loci;
-  uint8_t flags;
+  uint8_t flags;      /* bit k: position k keeps its side in every phase (phase mask, impute.py:277-290) */
   uint8_t slot[GRIM_MAXL];
   uint8_t pad[3];
   uint16_t cnt[GRIM_MAXL][2];
@@ -200,6 +200,10 @@ const int32_t *grim_parsed_dev_index(const grim_parsed *p);  /* [lines] subject 
 uint32_t grim_parsed_n_races(const grim_parsed *p);
 const char *grim_parsed_race(const grim_parsed *p, uint32_t i, int which);
 const char *grim_parsed_id(const grim_parsed *p, uint32_t line, uint32_t *len);
+/* host-language overrides: force a line's outcome kind; set a subject's `flags` = bitmask of positions
+ * that must NOT switch sides when phases are enumerated (bin_imputation_in_file, impute.py:277-290) */
+int grim_parsed_set_kind(grim_parsed *p, uint32_t line, uint8_t kind);
+int grim_parsed_set_flags(grim_parsed *p, uint32_t line, uint8_t flags);
 
 /* res/rows as returned by grim_batch_results for the subjects of `p`.  line_offset = global index
  * of the first line (multi-GPU shards); skip = optional [lines] mask of lines to leave out.

@@ -264,12 +264,15 @@ def gl_to_genotype(gl):
     return [sorted(side1), sorted(side2)], n
 
 
-def phases_of(gen, n_loci):
-    """impute.py:274-303 with b_phases == all ones (the only value impute_file passes
-    unless a bin file is configured)."""
+def phases_of(gen, n_loci, b_phases=None):
+    """impute.py:274-303.  b_phases (bin_imputation_in_file): a position may only take side 2's
+    allele when its entry is 1."""
     out, seen = [], set()
+    allowed = None if b_phases is None else [i for i, e in enumerate(b_phases) if e == 1]
     for i in range(2 ** (n_loci - 1)):
         pick = [(i >> k) & 1 for k in range(n_loci)]
+        if allowed is not None:
+            pick = [b if k in allowed else 0 for k, b in enumerate(pick)]
         h1 = [gen[pick[k]][k] for k in range(n_loci)]
         h2 = [gen[1 - pick[k]][k] for k in range(n_loci)]
         g1 = "~".join(h1) + "^" + "~".join(h2)
@@ -773,7 +776,7 @@ class OracleImputer:
         return res
 
     # ---- per subject (impute.py:1584-1656, 1940-1983) ------------------------------------
-    def impute_one(self, gl, race1, race2, muug_out=None, haps_out=None, planb=None):
+    def impute_one(self, gl, race1, race2, muug_out=None, haps_out=None, planb=None, b_phases=None):
         cfg = self.cfg
         muug_out = cfg["output_MUUG"] if muug_out is None else muug_out
         haps_out = cfg["output_haplotypes"] if haps_out is None else haps_out
@@ -799,7 +802,7 @@ class OracleImputer:
         if parsed is None:
             return None, None
         gen, n_loci = parsed
-        pmags = phases_of(gen, n_loci)
+        pmags = phases_of(gen, n_loci, b_phases)
         if pmags == []:
             return None, None
         res_m = {"MaxProb": 0, "Haps": {}, "Pops": {}}
@@ -838,6 +841,10 @@ class OracleImputer:
         out = {k: [] for k in ("umug", "umug_pops", "pmug", "pmug_pops", "miss", "problem")}
         n_res, n_pop = cfg["number_of_results"], cfg["number_of_pop_results"]
         sid = None
+        f_bin = None
+        if os.path.isfile(cfg["bin_imputation_input_file"]):  # impute.py:2001-2005
+            with open(cfg["bin_imputation_input_file"]) as fh:
+                f_bin = json.load(fh)
         for i, line in enumerate(lines):
             try:
                 line = line.rstrip()
@@ -847,7 +854,10 @@ class OracleImputer:
                 if len(parts) > 2:
                     race1, race2 = parts[2], parts[3]
                 self.plan = "a"
-                res_m, res_h = self.impute_one(gl, race1, race2)
+                b_phases = [1] * (len(self.full_loci) - 1)
+                if f_bin is not None:
+                    b_phases = f_bin[sid]  # KeyError -> the reference's bare except
+                res_m, res_h = self.impute_one(gl, race1, race2, b_phases=b_phases)
                 if res_m is None:
                     out["problem"].append(f"{i},{sid}\n")
                     continue

@@ -347,7 +347,7 @@ extern "C" grim_batch *grim_batch_upload(grim_ctx *c, const grim_graph *g, const
   const bool small_ok = (P == 1) && p->opt_threshold > 1 && !getenv("GRIM_NO_SMALL");
   for (uint32_t i = 0; i < d->n_subjects; ++i) {
     const grim_subject &sj = d->subjects[i];
-    bool sm = small_ok && sj.n_loci == GRIM_MAXL && g->d.n_loci == GRIM_MAXL;
+    bool sm = small_ok && sj.n_loci == GRIM_MAXL && g->d.n_loci == GRIM_MAXL && sj.flags == 0;
     for (int l = 0; l < GRIM_MAXL && sm; ++l)
       sm = sj.cnt[l][0] == 1 && sj.cnt[l][1] == 1 && sj.wid[l][0] == 1 && sj.wid[l][1] == 1;
     if (sm) {

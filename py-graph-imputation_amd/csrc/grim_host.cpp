@@ -384,6 +384,18 @@ extern "C" const char *grim_parsed_race(const grim_parsed *p, uint32_t i, int wh
   if (i >= p->races.size()) return nullptr;
   return which ? p->races[i].second.c_str() : p->races[i].first.c_str();
 }
+// overrides used by the host language for things only it knows (bin_imputation_in_file phase masks,
+// impute.py:2001-2005,2030-2032): force a line's outcome kind / set a subject's fixed-position mask
+extern "C" int grim_parsed_set_kind(grim_parsed *p, uint32_t line, uint8_t kind) {
+  if (!p || line >= p->kind.size()) return -1;
+  p->kind[line] = kind;
+  return 0;
+}
+extern "C" int grim_parsed_set_flags(grim_parsed *p, uint32_t line, uint8_t flags) {
+  if (!p || line >= p->kind.size() || p->dev[line] < 0) return -1;
+  p->subj[p->dev[line]].flags = flags;
+  return 0;
+}
 // subject id text of line i (not NUL terminated)
 extern "C" const char *grim_parsed_id(const grim_parsed *p, uint32_t i, uint32_t *len) {
   if (i >= p->kind.size()) return nullptr;

@@ -14,10 +14,11 @@ __device__ inline void enumerate_phases(WgShared &sh) {
     int n = sh.subj.n_loci;
     uint32_t same = sh.subj.pad[0];
     uint32_t het = ((1u << n) - 1u) & ~same;
+    const uint32_t movable = het & ~(uint32_t)sh.subj.flags;  // phase mask: fixed positions never switch
     uint32_t seen = 0;
     int cnt = 0;
     for (uint32_t i = 0; i < (1u << (n - 1)); ++i) {
-      uint32_t p = i & het;
+      uint32_t p = i & movable;
       if (!((seen >> p) & 1u)) {
         seen |= (1u << p) | (1u << (p ^ het));
         sh.ph_pat[cnt++] = (uint8_t)p;

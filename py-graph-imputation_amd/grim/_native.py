@@ -288,7 +288,7 @@ EXPORTS += [
     "grim_dict_create", "grim_dict_free", "grim_dict_set_locus", "grim_dict_intern", "grim_dict_find", "grim_dict_name",
     "grim_dict_count", "grim_tokenize", "grim_parsed_free", "grim_parsed_lines", "grim_parsed_subjects",
     "grim_parsed_subject_array", "grim_parsed_tokens", "grim_parsed_kinds", "grim_parsed_dev_index",
-    "grim_parsed_n_races", "grim_parsed_race", "grim_parsed_id", "grim_format", "grim_text_get", "grim_text_free",
+    "grim_parsed_n_races", "grim_parsed_race", "grim_parsed_id", "grim_parsed_set_kind", "grim_parsed_set_flags", "grim_format", "grim_text_get", "grim_text_free",
     "grim_format_double",
 ]
 
@@ -333,6 +333,8 @@ def host_lib():
     L.grim_parsed_race.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
     L.grim_parsed_id.restype = C.c_void_p
     L.grim_parsed_id.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+    L.grim_parsed_set_kind.argtypes = [C.c_void_p, C.c_uint32, C.c_uint8]
+    L.grim_parsed_set_flags.argtypes = [C.c_void_p, C.c_uint32, C.c_uint8]
     L.grim_format.restype = C.c_void_p
     L.grim_format.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Params), C.POINTER(C.c_char_p), C.c_uint32, C.c_void_p,
                               C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
@@ -425,6 +427,12 @@ class Parsed:
         L = host_lib()
         return [(L.grim_parsed_race(self.h, i, 0).decode(), L.grim_parsed_race(self.h, i, 1).decode())
                 for i in range(int(L.grim_parsed_n_races(self.h)))]
+
+    def set_kind(self, line, kind):
+        host_lib().grim_parsed_set_kind(self.h, line, kind)
+
+    def set_flags(self, line, flags):
+        host_lib().grim_parsed_set_flags(self.h, line, flags)
 
     def subject_id(self, line):
         n = C.c_uint32(0)

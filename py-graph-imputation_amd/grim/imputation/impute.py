@@ -379,14 +379,32 @@ class Imputation(object):
         haps_on = config["output_haplotypes"]
         if planb is None:
             planb = config["planb"]
-        if os.path.isfile(config["bin_imputation_input_file"]):
-            raise NotImplementedError("bin_imputation_in_file (phase masks) is not supported by this build")
         if not config["epsilon"] > 0:
             raise NotImplementedError("epsilon <= 0: the reference returns its 'NaN' sentinel and fails every subject")
         self.unsupported = []
         text = "".join(l if l.endswith("\n") else l + "\n" for l in lines).encode()
         parsed = nat.Parsed(self.netGraph.adict, text, planb)
         try:
+            if os.path.isfile(config["bin_imputation_input_file"]):
+                # phase masks (impute.py:2001-2005, 2030-2032, 277-290): position m may switch sides only
+                # where the subject's list holds 1; an id missing from the file is a KeyError in the
+                # reference -> raw line to .problem
+                import json
+                with open(config["bin_imputation_input_file"]) as fh:
+                    f_bin = json.load(fh)
+                kinds0 = parsed.kinds()
+                for j in range(parsed.n_lines):
+                    if kinds0[j] == nat.K_PROBLEM_RAW:
+                        continue
+                    mask = f_bin.get(parsed.subject_id(j))
+                    if mask is None:
+                        parsed.set_kind(j, nat.K_PROBLEM_RAW)
+                    elif kinds0[j] == nat.K_DEVICE:
+                        fixed = 0
+                        for m in range(nat.MAXL):
+                            if not (m < len(mask) and mask[m] == 1):
+                                fixed |= 1 << m
+                        parsed.set_flags(j, fixed)
             races = parsed.races()
             if len(races) >= 65535:
                 raise OverflowError("more than 65535 distinct race pairs in one batch")

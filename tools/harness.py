@@ -60,6 +60,9 @@ def ensure_graph(name):
 
 def _write_inputs(work, conf, lines, tag):
     conf = dict(conf)
+    if conf.get("bin_imputation_in_file") and "_bin_src" in conf:
+        shutil.copy(conf.pop("_bin_src"), os.path.join(work, conf["bin_imputation_in_file"]))
+    conf.pop("_bin_src", None)
     conf["imputation_in_file"] = "data/subjects/%s.csv" % tag
     conf["imputation_out_path"] = "output_" + tag
     with open(os.path.join(work, conf["imputation_in_file"]), "w") as fh:
@@ -145,6 +148,8 @@ def golden(scenario):
         p = os.path.join(d, f)
         exp[k] = open(p).read() if os.path.exists(p) else ""
     log = [l for l in open(os.path.join(d, "log.txt")).read().splitlines() if "Subject:" in l]
+    if os.path.exists(os.path.join(d, "bin.json")):
+        conf["_bin_src"] = os.path.join(d, "bin.json")
     return meta["graph"], conf, lines, exp, log, meta["hap_pop_pair"]
 
 

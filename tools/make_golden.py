@@ -145,11 +145,15 @@ def build_graph(name, pops):
     return work
 
 
-def run_scenario(name, work, pops, lines, overrides=None, hap_pop_pair=False):
+def run_scenario(name, work, pops, lines, overrides=None, hap_pop_pair=False, bin_masks=None):
     from grim import grim
 
     conf = dict(BASE_CONF, populations=list(pops))
     conf.update(overrides or {})
+    if bin_masks is not None:
+        conf["bin_imputation_in_file"] = "data/subjects/bin.json"
+        with open(os.path.join(work, "data", "subjects", "bin.json"), "w") as fh:
+            json.dump(bin_masks, fh)
     with open(os.path.join(work, "data", "subjects", "input.csv"), "w") as fh:
         fh.write("\n".join(lines) + "\n")
     with open(os.path.join(work, "conf.json"), "w") as fh:
@@ -170,6 +174,8 @@ def run_scenario(name, work, pops, lines, overrides=None, hap_pop_pair=False):
     os.makedirs(out, exist_ok=True)
     shutil.copy(os.path.join(work, "conf.json"), os.path.join(out, "conf.json"))
     shutil.copy(os.path.join(work, "data", "subjects", "input.csv"), os.path.join(out, "input.csv"))
+    if bin_masks is not None:
+        shutil.copy(os.path.join(work, "data", "subjects", "bin.json"), os.path.join(out, "bin.json"))
     for f in ("don.umug", "don.umug.pops", "don.pmug", "don.pmug.pops", "don.miss", "don.problem"):
         p = os.path.join(work, "output", f)
         if os.path.exists(p):
@@ -222,6 +228,11 @@ def main():
                  {"max_haplotypes_number_in_phase": 5})
     run_scenario("cau_em_mr", w1, ["CAU"], synth.SubjectGen(cau, 13).mixed(40), hap_pop_pair=True)
     run_scenario("cau_planc", w1, ["CAU"], synth.plan_c_cases("CAU"))
+    bl = synth.SubjectGen(cau, 15).mixed(120) + synth.SubjectGen(cau, 16).full(80)
+    import numpy as _np
+    _r = _np.random.default_rng(17)
+    masks = {l.split(",")[0]: [int(x) for x in _r.integers(0, 2, 4)] for l in bl[:-3]}  # the last three ids are missing -> .problem
+    run_scenario("cau_bin", w1, ["CAU"], bl, bin_masks=masks)
 
     g4 = synth.SubjectGen(cau, 3, pops=POP4)
     # mix subjects drawn from all four tables
