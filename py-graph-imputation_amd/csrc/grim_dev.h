@@ -54,6 +54,7 @@ struct SlotLayout {
   uint64_t qsum, qfirst;               // population-pair cells [P*P]
   uint64_t bset;                       // plan-B block sets (node ids) [GRIM_NWAVE][GRIM_MAXL][bset_cap]
   uint64_t comp;                       // plan-B/C canonical haplotype table: open-addressing keys [GRIM_COMP_CAP]
+  uint64_t proj_k, proj_p;             // plan-B label-scan projections: per-wave hash set [GRIM_NWAVE][proj_cap]
   uint64_t stride;                     // bytes per slot
 };
 
@@ -74,7 +75,7 @@ struct DevArgs {
   uint32_t row_cap;
   uint8_t *scratch;
   SlotLayout lay;
-  uint32_t pair_cap, tab_cap, bset_cap;
+  uint32_t pair_cap, tab_cap, bset_cap, proj_cap;
   unsigned long long *counters;  // [0] probes [1] nbr ids [2] freq vectors [3] rows [4] overflow flag
   uint32_t *bail_list;           // subjects the one-wave kernel hands to the general kernel (count: queue[5])
   uint32_t *next_list;           // subjects handed to the next kernel (plan B)

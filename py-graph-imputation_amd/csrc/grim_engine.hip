@@ -460,6 +460,13 @@ extern "C" grim_batch *grim_batch_upload(grim_ctx *c, const grim_graph *g, const
   L.qfirst = take(4ull * P * P);
   L.bset = take(4ull * GRIM_NWAVE * GRIM_MAXL * (uint64_t)A.bset_cap);
   L.comp = take(8ull * GRIM_COMP_CAP);
+  {
+    uint32_t pc = 64;
+    while (pc < 2 * A.bset_cap) pc <<= 1;
+    A.proj_cap = pc;
+  }
+  L.proj_k = take(8ull * GRIM_NWAVE * A.proj_cap);
+  L.proj_p = take(4ull * GRIM_NWAVE * A.proj_cap);
   L.stride = align256(o);
   A.scratch = upload<uint8_t>(c, b->bufs, nullptr, (size_t)L.stride * slots, &bytes);
   bool ok = A.subj && A.tok && A.priors && b->order_s && b->order_g && b->order_m && A.bail_list && b->small_recs && b->hstate && A.queue && A.next_list && A.res && A.counters && A.rows && A.scratch;

@@ -45,6 +45,8 @@ struct Slot {
   uint32_t *qfirst;
   uint32_t *bset;
   uint64_t *comp;
+  uint64_t *proj_k;
+  uint32_t *proj_p;
 };
 
 __device__ __forceinline__ Slot make_slot(const DevArgs &A, uint32_t slot_idx) {
@@ -72,6 +74,8 @@ __device__ __forceinline__ Slot make_slot(const DevArgs &A, uint32_t slot_idx) {
   s.qfirst = (uint32_t *)(b + A.lay.qfirst);
   s.bset = (uint32_t *)(b + A.lay.bset);
   s.comp = (uint64_t *)(b + A.lay.comp);
+  s.proj_k = (uint64_t *)(b + A.lay.proj_k);
+  s.proj_p = (uint32_t *)(b + A.lay.proj_p);
   return s;
 }
 

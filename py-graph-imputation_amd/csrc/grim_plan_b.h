@@ -73,6 +73,36 @@ __device__ __forceinline__ uint32_t absent_positions(const DevArgs &A, const uin
   return m;
 }
 
+// label-scan opening (impute.py:947-981): does node `nd` of the typed-loci label use only alleles of
+// this side's alternatives?
+__device__ __forceinline__ bool node_passes(const DevGraph &g, const SideSpec &sp, const uint16_t *tok, uint32_t nd) {
+  const uint64_t key = g.node_key[nd];
+  bool ok = true;
+#pragma unroll
+  for (int l = 0; l < GRIM_MAXL; ++l) {
+    if (l < sp.n && ok) {
+      const uint32_t al = (uint32_t)((key >> (GRIM_ABITS * sp.sl[l])) & 0xFFF) - 1u;
+      bool hit = false;
+      for (uint32_t t = 0; t < sp.cn[l]; ++t) hit |= (tok[sp.to[l] + t] == al);
+      ok = hit;
+    }
+  }
+  return ok;
+}
+
+// number of candidates the label scan yields for this side (wave-uniform)
+__device__ inline uint32_t scan_count(const DevArgs &A, const SideSpec &sp, const uint16_t *tok) {
+  const DevGraph &g = A.g;
+  const uint32_t a = g.lab_start[sp.typed_mask], b = g.lab_start[sp.typed_mask + 1];
+  uint32_t n = 0;
+  for (uint32_t i0 = a; i0 < b; i0 += 64) {
+    const uint32_t i = i0 + lane_id();
+    const bool ok = i < b && node_passes(g, sp, tok, g.lab_nodes[i]);
+    n += (uint32_t)__popcll(__ballot(ok));
+  }
+  return n;
+}
+
 // Row whose first block is the full label: plain Plan-A look-up (impute.py:1118-1119).
 __device__ inline bool side_lookup_full(const DevArgs &A, WgShared &sh, const Slot &S, const double *prior, WaveTop &L,
                                         const SideSpec &sp, const uint16_t *tok, int row) {
@@ -82,6 +112,21 @@ __device__ inline bool side_lookup_full(const DevArgs &A, WgShared &sh, const Sl
   st.nrun = 0; st.nbuf = 0; st.K = (int)A.prm.top_n; st.full = false; st.thr = 0;
   uint64_t item_base = 0, c_nbr = 0, c_freq = 0;
   const bool direct = (sp.typed_mask == g.full_mask);
+  if (!sp.expansion) {
+    // candidates = the nodes the label scan lets through, in node order
+    const uint32_t a = g.lab_start[sp.typed_mask], b = g.lab_start[sp.typed_mask + 1];
+    for (uint32_t i0 = a; i0 < b; i0 += 64) {
+      const uint32_t i = i0 + lane;
+      uint32_t node = GRIM_NONE;
+      if (i < b) {
+        const uint32_t nd = g.lab_nodes[i];
+        if (node_passes(g, sp, tok, nd)) node = nd;
+      }
+      expand_chunk<true>(A, prior, L, st, node, direct, g.a_start, g.a_nbr, 1.0, 0, item_base, c_nbr, c_freq);
+    }
+    store_top<true>(S, sh, L, st, row);
+    return st.nrun > 0;
+  }
   for (uint32_t c0 = 0; c0 < sp.ncand; c0 += 64) {
     uint32_t c = c0 + lane;
     uint32_t node = GRIM_NONE;
@@ -124,7 +169,7 @@ __device__ inline bool side_absent(const DevArgs &A, WgShared &sh, const Slot &S
   const int nadd = __popc(added);
   const double scale = A.prm.factor_missing_pow[__popc(abs_mask)];
   uint64_t item_base = 0, c_nbr = 0, c_freq = 0;
-  if (src_mask != 0 && nadd <= 1) {
+  if (sp.expansion && src_mask != 0 && nadd <= 1) {
     const bool direct = (nadd == 0);
     const int add_slot = nadd ? (__ffs(added) - 1) : 0;
     for (uint32_t c0 = 0; c0 < sp.ncand; c0 += 64) {
@@ -197,6 +242,70 @@ __device__ inline bool side_blocks(const DevArgs &A, WgShared &sh, const Slot &S
             if (l < sp.n && ((tb >> sp.sl[l]) & 1u)) nsub *= sp.cn[l];
           uint32_t *out = wset + (uint64_t)b * A.bset_cap;
           uint32_t cnt = 0;
+          if (!sp.expansion) {
+            // candidates come from the label scan: their projections onto the block's typed loci,
+            // first occurrences in scan order (create_haplos_string + dict order, impute.py:1015-1039,
+            // networkx_graph.py:289-306).  Pass 1 records the first scan position of every projection
+            // in a per-wave hash set, pass 2 emits the first occurrences in order.
+            uint64_t tbmask = 0;
+#pragma unroll
+            for (int l = 0; l < GRIM_MAXL; ++l)
+              if (l < sp.n && ((tb >> sp.sl[l]) & 1u)) tbmask |= 0xFFFull << (GRIM_ABITS * sp.sl[l]);
+            uint64_t *pk = S.proj_k + (uint64_t)wave_id() * A.proj_cap;
+            uint32_t *pp = S.proj_p + (uint64_t)wave_id() * A.proj_cap;
+            const uint32_t la = g.lab_start[sp.typed_mask], lb = g.lab_start[sp.typed_mask + 1];
+            uint32_t pcap = 64;
+            while (pcap < 2 * (lb - la) && pcap < A.proj_cap) pcap <<= 1;
+            for (uint32_t q = lane; q < pcap; q += 64) {
+              pk[q] = 0;
+              pp[q] = GRIM_NONE;
+            }
+            __threadfence_block();
+            for (int pass = 0; pass < 2; ++pass) {
+              for (uint32_t i0 = la; i0 < lb; i0 += 64) {
+                const uint32_t i = i0 + lane;
+                uint32_t n_out = 0, node = GRIM_NONE, base = 0;
+                if (i < lb) {
+                  const uint32_t nd = g.lab_nodes[i];
+                  if (node_passes(g, sp, tok, nd)) {
+                    const uint64_t key = g.node_key[nd] & tbmask;
+                    const uint32_t slot = tab_insert<false>(pk, nullptr, pcap - 1, key | GRIM_VALID, 0);
+                    if (pass == 0) {
+                      atomicMin(&pp[slot], i);
+                    } else if (ALOAD(&pp[slot]) == i) {
+                      node = graph_lookup(g, key);
+                      if (node != GRIM_NONE) {
+                        if (nadd == 0) {
+                          n_out = 1;
+                        } else {
+                          uint32_t conn = g.b_conn[(uint64_t)node * GRIM_MAXL + add_slot];
+                          if (conn != GRIM_NONE) {
+                            n_out = nbr_count(g.b_start, conn);
+                            base = g.b_start[conn];
+                          }
+                        }
+                      }
+                    }
+                  }
+                }
+                if (pass == 1) {
+                  uint32_t inc = wave_incl_scan(n_out);
+                  uint32_t tot = __shfl(inc, 63);
+                  uint32_t off = cnt + inc - n_out;
+                  if (off + n_out <= A.bset_cap) {
+                    if (nadd == 0) {
+                      if (n_out) out[off] = node;
+                    } else {
+                      for (uint32_t t = 0; t < n_out; ++t) out[off + t] = g.b_nbr[base + t];
+                    }
+                  }
+                  cnt += tot;
+                }
+              }
+              __threadfence_block();
+            }
+            nsub = 0;  // skip the cartesian enumeration below
+          }
           for (uint32_t c0 = 0; c0 < nsub; c0 += 64) {
             uint32_t c = c0 + lane;
             uint32_t n_out = 0, node = GRIM_NONE, base = 0;
@@ -414,6 +523,7 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_b_kernel(DevArgs A) {
   __shared__ uint8_t memo[GRIM_SIDES];
   __shared__ uint32_t absent_side[2];
   __shared__ uint32_t unsupported;
+  __shared__ uint8_t side_scan[GRIM_SIDES], side_any[GRIM_SIDES];
   __shared__ uint16_t bestc[GRIM_MAXL][2];
   const int tid = threadIdx.x;
   const int P = A.g.P;
@@ -433,10 +543,20 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_b_kernel(DevArgs A) {
     enumerate_phases(sh);
     const int nph = sh.nph;
     const uint16_t *tok = A.tok + sh.subj.tok_off;
-    // every side must have been opened by the cartesian branch
-    if (tid < 2 * nph) {
-      SideSpec sp = side_spec(A, sh, tid >> 1, tid & 1);
-      if (!sp.expansion) atomicOr(&unsupported, 1u);
+    // open_phases keeps a phase only when both sides have candidates (impute.py:987-988); sides opened
+    // by the label scan may have none
+    if (tid < GRIM_SIDES) {
+      side_scan[tid] = 0;
+      side_any[tid] = 0;
+    }
+    __syncthreads();
+    for (int s = wave_id(); s < 2 * nph; s += GRIM_NWAVE) {
+      SideSpec sp = side_spec(A, sh, s >> 1, s & 1);
+      uint32_t ncand = sp.expansion ? 1u : scan_count(A, sp, tok);
+      if (lane_id() == 0) {
+        side_scan[s] = sp.expansion ? 0 : 1;
+        side_any[s] = ncand ? 1 : 0;
+      }
     }
     // alleles of a position that the graph has never seen on ANY phase of a side (impute.py:1224-1241)
     if (tid < 2) absent_side[tid] = 0;
@@ -446,6 +566,11 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_b_kernel(DevArgs A) {
       if (l < sh.subj.n_loci) {
         bool any = false;
         for (int i = 0; i < nph; ++i) {
+          if (!(side_any[2 * i] && side_any[2 * i + 1])) continue;  // phase dropped by open_phases
+          if (side_scan[2 * i + side]) {
+            any = true;  // candidates of a label scan are graph nodes: their alleles are known
+            continue;
+          }
           int c = (int)((sh.ph_pat[i] >> l) & 1u) ^ side;
           for (uint32_t t = 0; t < sh.subj.cnt[l][c]; ++t)
             any |= allele_known(A.g, sh.subj.slot[l], tok[sh.toff[l][c] + t]);
@@ -472,6 +597,7 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_b_kernel(DevArgs A) {
           if (tid < GRIM_SIDES) sh.Tn[tid] = 0;
           __syncthreads();
           for (int s = wave_id(); s < 2 * nph; s += GRIM_NWAVE) {
+            if (!(side_any[s] && side_any[s ^ 1])) continue;  // phase dropped by open_phases
             SideSpec sp = side_spec(A, sh, s >> 1, s & 1);
             const uint32_t ab = absent_side[s & 1];
             if (ab == 0) {
@@ -494,6 +620,7 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_b_kernel(DevArgs A) {
           __syncthreads();
           for (int s = wave_id(); s < 2 * nph; s += GRIM_NWAVE) {
             const int mine = memo[s], other = memo[s ^ 1];
+            if (!(side_any[s] && side_any[s ^ 1])) continue;
             if ((mine == 10) == (other == 10)) continue;  // both unset: skipped; both set: stale lists, no-op
             SideSpec sp = side_spec(A, sh, s >> 1, s & 1);
             if (mine == 10) {
