@@ -121,7 +121,10 @@ typedef struct {
 enum {
   GRIM_ST_OK = 0,         /* results present                                                    */
   GRIM_ST_MISS = 1,       /* nothing found on any plan  (-> .miss, impute.py:2065-2068)          */
-  GRIM_ST_UNSUPPORTED = 2 /* needs a reference path this build does not run on device yet       */
+  GRIM_ST_UNSUPPORTED = 2,/* needs a reference path this build does not run on device yet       */
+  GRIM_ST_NOPHASE = 3     /* open_phases stayed empty after both rewrites (impute.py:1619-1629): the
+                             reference writes nothing for MUUG and raises while writing the phased
+                             output -> raw line in .problem when output_haplotypes is on             */
 };
 
 /* one output row: a/b are 64-bit haplotype keys (genotype and haplotype-pair tables) or

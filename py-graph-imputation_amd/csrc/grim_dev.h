@@ -14,6 +14,7 @@
 #define GRIM_VALID 0x8000000000000000ull
 #define GRIM_SIDES (2 * GRIM_MAXPH)
 #define GRIM_COMP_CAP 8192  // >= 2 * GRIM_SIDES * GRIM_TOPCAP
+#define GRIM_RTOK_CAP 12288 // u16 tokens per slot: 3 versions of up to 4096 alleles per subject
 
 // ---- graph as the kernels see it --------------------------------------------------------------
 // full-label nodes only, with the first population's frequency inline: the half-wave kernel's
@@ -55,6 +56,7 @@ struct SlotLayout {
   uint64_t bset;                       // plan-B block sets (node ids) [GRIM_NWAVE][GRIM_MAXL][bset_cap]
   uint64_t comp;                       // plan-B/C canonical haplotype table: open-addressing keys [GRIM_COMP_CAP]
   uint64_t proj_k, proj_p;             // plan-B label-scan projections: per-wave hash set [GRIM_NWAVE][proj_cap]
+  uint64_t rtok;                       // the subject's allele lists: original + the two reduced versions [GRIM_RTOK_CAP]
   uint64_t stride;                     // bytes per slot
 };
 

@@ -47,17 +47,28 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_a_kernel(DevArgs A) {
     enumerate_phases(sh);
     const double *prior = A.priors + (uint64_t)sh.subj.prior_idx * P * P;
     const int nph = sh.nph;
-    for (int s = wave_id(); s < 2 * nph; s += GRIM_NWAVE) build_side_plan_a(A, sh, S, prior, wt[wave_id()], s >> 1, s & 1, s);
-    __syncthreads();
-    STAMP(8);
+    const bool fits = prepare_lists(A, sh, S);
     bool kept = false;
-    for (int i = 0; i < nph; ++i) kept |= (sh.cand_any[2 * i] && sh.cand_any[2 * i + 1]);
+    // open_phases; when no phase has candidates on both sides the reference rewrites the '/'-lists
+    // (known alleles only, then the 10 most frequent) and opens again (impute.py:1619-1627)
+    for (int stage = 0; fits; ++stage) {
+      for (int s = wave_id(); s < 2 * nph; s += GRIM_NWAVE) build_side_plan_a(A, sh, S, prior, wt[wave_id()], s >> 1, s & 1, s);
+      __syncthreads();
+      kept = false;
+      for (int i = 0; i < nph; ++i) kept |= (sh.cand_any[2 * i] && sh.cand_any[2 * i + 1]);
+      if (kept || stage == 2) break;
+      if (stage == 0) reduce_lists(A, sh, S, prior);
+      apply_stage(A, sh, stage + 1);
+    }
+    STAMP(8);
     uint8_t status = GRIM_ST_MISS, reason = 0, plan = 'a';
-    if (!kept) {
-      // open_phases returned nothing: the reference now rewrites the GL (reduce_phase_to_valid_allels /
-      // _commons_alleles, impute.py:1620-1627).  Not on device yet.
-      status = GRIM_ST_UNSUPPORTED;
-      reason = 1;
+    if (!fits) {
+      status = GRIM_ST_UNSUPPORTED;  // more than GRIM_RTOK_CAP/3 alleles in one GL string
+      reason = 5;
+    } else if (!kept) {
+      // no phase at all: the reference returns its placeholder result and trips over it while writing
+      // the phased file (impute.py:1607-1609, 2090-2097)
+      status = GRIM_ST_NOPHASE;
     } else {
       const uint32_t np = pair_offsets(sh);
       int e = A.prm.n_ladder;
@@ -467,6 +478,7 @@ extern "C" grim_batch *grim_batch_upload(grim_ctx *c, const grim_graph *g, const
   }
   L.proj_k = take(8ull * GRIM_NWAVE * A.proj_cap);
   L.proj_p = take(4ull * GRIM_NWAVE * A.proj_cap);
+  L.rtok = take(2ull * GRIM_RTOK_CAP);
   L.stride = align256(o);
   A.scratch = upload<uint8_t>(c, b->bufs, nullptr, (size_t)L.stride * slots, &bytes);
   bool ok = A.subj && A.tok && A.priors && b->order_s && b->order_g && b->order_m && A.bail_list && b->small_recs && b->hstate && A.queue && A.next_list && A.res && A.counters && A.rows && A.scratch;

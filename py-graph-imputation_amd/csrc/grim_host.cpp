@@ -505,6 +505,15 @@ static void format_range(const grim_dict *d, const grim_parsed *P, const grim_pa
       continue;
     }
     const grim_subject_result *r = kind == K_DEV ? &res[P->dev[j]] : nullptr;
+    if (r && r->status == GRIM_ST_NOPHASE) {
+      // no phase could be opened: the reference's placeholder result raises in the phased writer
+      // (impute.py:1607-1609, 2090-2097) -> raw line; with haplotype output off nothing is written
+      if (prm->out_haps) {
+        o.t[5].append(P->text.data() + P->line_off[j], P->line_len[j]);
+        o.t[5].push_back('\n');
+      }
+      continue;
+    }
     const uint32_t n_pairs = (r && prm->out_haps) ? r->n_pairs : 0, n_geno = (r && prm->out_muug) ? r->n_genotypes : 0;
     if (prm->out_haps && n_pairs == 0 && n_geno == 0) {  // impute.py:2065-2068 (never when haplotype output is off)
       o.t[4] += std::to_string(i);

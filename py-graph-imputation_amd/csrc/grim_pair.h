@@ -11,9 +11,22 @@
 #include "grim_dev.h"
 
 // LDS block shared by the kernels
+// one version of one '/'-list of the subject: offset into the slot's token copy, distinct alleles, width
+struct ListVer {
+  uint32_t off;
+  uint16_t cnt, wid;
+};
+
 struct WgShared {
   grim_subject subj;
   uint32_t toff[GRIM_MAXL][2];
+  // version 0 = as typed; 1 = only alleles the graph knows (reduce_phase_to_valid_allels,
+  // impute.py:864-879); 2 = the 10 most frequent of those (reduce_phase_to_commons_alleles,
+  // impute.py:881-912).  side_ver[s] = version phase side s currently uses (0 unless open_phases
+  // found no candidate in any phase, impute.py:1620-1627).
+  ListVer lv[GRIM_MAXL][2][3];
+  uint8_t side_ver[GRIM_SIDES];
+  uint32_t ntok;
   uint32_t Tn[GRIM_SIDES];
   uint8_t cand_any[GRIM_SIDES];
   uint8_t ph_pat[GRIM_MAXPH];
@@ -47,6 +60,7 @@ struct Slot {
   uint64_t *comp;
   uint64_t *proj_k;
   uint32_t *proj_p;
+  uint16_t *rtok;
 };
 
 __device__ __forceinline__ Slot make_slot(const DevArgs &A, uint32_t slot_idx) {
@@ -76,6 +90,7 @@ __device__ __forceinline__ Slot make_slot(const DevArgs &A, uint32_t slot_idx) {
   s.comp = (uint64_t *)(b + A.lay.comp);
   s.proj_k = (uint64_t *)(b + A.lay.proj_k);
   s.proj_p = (uint32_t *)(b + A.lay.proj_p);
+  s.rtok = (uint16_t *)(b + A.lay.rtok);
   return s;
 }
 

@@ -35,6 +35,95 @@ __device__ inline void enumerate_phases(WgShared &sh) {
   __syncthreads();
 }
 
+// Copy the subject's allele lists into the slot and set up the list versions (all version 0).
+// Returns false when the lists do not fit (GRIM_RTOK_CAP).  All threads call.
+__device__ inline bool prepare_lists(const DevArgs &A, WgShared &sh, const Slot &S) {
+  const grim_subject &sj = sh.subj;
+  if (threadIdx.x == 0) {
+    uint32_t acc = 0;
+    for (int l = 0; l < sj.n_loci; ++l)
+      for (int c = 0; c < 2; ++c) acc += sj.cnt[l][c];
+    sh.ntok = acc;
+  }
+  if (threadIdx.x < GRIM_SIDES) sh.side_ver[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t ntok = sh.ntok;
+  if (3 * ntok > GRIM_RTOK_CAP) return false;
+  for (uint32_t t = threadIdx.x; t < ntok; t += GRIM_WG) S.rtok[t] = A.tok[sj.tok_off + t];
+  if (threadIdx.x < 2 * GRIM_MAXL) {
+    const int l = threadIdx.x >> 1, c = threadIdx.x & 1;
+    ListVer v;
+    v.off = l < sj.n_loci ? sh.toff[l][c] : 0;
+    v.cnt = l < sj.n_loci ? sj.cnt[l][c] : 0;
+    v.wid = l < sj.n_loci ? sj.wid[l][c] : 0;
+    sh.lv[l][c][0] = sh.lv[l][c][1] = sh.lv[l][c][2] = v;
+  }
+  __syncthreads();
+  return true;
+}
+
+// The two rewrites the reference applies when open_phases finds no candidate in any phase
+// (impute.py:1620-1627): version 1 of a list keeps the alleles the graph knows (in list order),
+// version 2 the 10 with the largest sum_p freq[p]*prior[p][p] (stable, bigger first); a list none of
+// whose alleles is known stays as typed.  One thread per list; scores parked in the slot.
+__device__ inline void reduce_lists(const DevArgs &A, WgShared &sh, const Slot &S, const double *prior) {
+  const DevGraph &g = A.g;
+  const grim_subject &sj = sh.subj;
+  const int P = g.P;
+  if (threadIdx.x < 2 * GRIM_MAXL) {
+    const int l = threadIdx.x >> 1, c = threadIdx.x & 1;
+    if (l < sj.n_loci) {
+      const ListVer v0 = sh.lv[l][c][0];
+      const uint32_t off1 = sh.ntok + v0.off, off2 = 2 * sh.ntok + v0.off;
+      double *score = S.gsum + v0.off;  // free while sides are being opened
+      uint32_t n1 = 0;
+      for (uint32_t t = 0; t < v0.cnt; ++t) {
+        const uint32_t tk = S.rtok[v0.off + t];
+        const uint32_t node = graph_lookup(g, (uint64_t)(tk + 1u) << (GRIM_ABITS * sj.slot[l]));
+        if (node == GRIM_NONE) continue;
+        double sc = 0.0;
+        for (int j = 0; j < P; ++j) sc = sc + g.freq[(uint64_t)node * P + j] * prior[j * P + j];
+        S.rtok[off1 + n1] = (uint16_t)tk;
+        score[n1] = sc;
+        ++n1;
+      }
+      if (n1 > 0) {
+        ListVer v1;
+        v1.off = off1; v1.cnt = (uint16_t)n1; v1.wid = (uint16_t)n1;
+        sh.lv[l][c][1] = v1;
+        const uint32_t keep = n1 < 10 ? n1 : 10;
+        for (uint32_t t = 0; t < n1; ++t) {
+          uint32_t rank = 0;
+          for (uint32_t t2 = 0; t2 < n1; ++t2) rank += (score[t2] > score[t] || (score[t2] == score[t] && t2 < t)) ? 1u : 0u;
+          if (rank < keep) S.rtok[off2 + rank] = S.rtok[off1 + t];
+        }
+        ListVer v2;
+        v2.off = off2; v2.cnt = (uint16_t)keep; v2.wid = (uint16_t)keep;
+        sh.lv[l][c][2] = v2;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// sides whose option count reaches the threshold switch to list version `stage`
+// (impute.py:870-873, 889-892: the rewrites only touch such sides).  Returns nothing; all threads call.
+__device__ inline void apply_stage(const DevArgs &A, WgShared &sh, int stage) {
+  const grim_subject &sj = sh.subj;
+  const int s = threadIdx.x;
+  if (s < 2 * sh.nph) {
+    const uint32_t pat = sh.ph_pat[s >> 1];
+    uint64_t options = 1;
+    for (int l = 0; l < sj.n_loci; ++l) {
+      int c = (int)((pat >> l) & 1u) ^ (s & 1);
+      options *= (uint64_t)sh.lv[l][c][sh.side_ver[s]].wid;
+      if (options > 0xFFFFFFFFFFFFull) options = 0xFFFFFFFFFFFFull;
+    }
+    if (!(options < A.prm.opt_threshold)) sh.side_ver[s] = (uint8_t)stage;
+  }
+  __syncthreads();
+}
+
 // Expand the chunk of <=64 look-up hits held one per lane into (hap, pop) entries and push them
 // through the running top-K.  DIRECT: `src` is the haplotype node itself; otherwise `src` is a CSR
 // row (plan A: a partial node's top links; plan B: a connector's parents) and every neighbour is
@@ -121,10 +210,11 @@ __device__ inline void build_side_plan_a(const DevArgs &A, WgShared &sh, const S
                                          int ph, int side, int row) {
   const DevGraph &g = A.g;
   const grim_subject &sj = sh.subj;
-  const uint16_t *tok = A.tok + sj.tok_off;
+  const uint16_t *tok = S.rtok;
   const int lane = lane_id();
   const int n = sj.n_loci;
   const uint32_t pat = sh.ph_pat[ph];
+  const int ver = sh.side_ver[row];
   TopState st;
   st.nrun = 0; st.nbuf = 0; st.K = (int)A.prm.top_n; st.full = false; st.thr = 0;
   uint32_t cn[GRIM_MAXL], to[GRIM_MAXL], sl[GRIM_MAXL];
@@ -135,10 +225,11 @@ __device__ inline void build_side_plan_a(const DevArgs &A, WgShared &sh, const S
     cn[l] = 1; to[l] = 0; sl[l] = 0;
     if (l < n) {
       int c = (int)((pat >> l) & 1u) ^ side;
-      cn[l] = sj.cnt[l][c];
-      to[l] = sh.toff[l][c];
+      const ListVer lv = sh.lv[l][c][ver];
+      cn[l] = lv.cnt;
+      to[l] = lv.off;
       sl[l] = sj.slot[l];
-      uint64_t w = sj.wid[l][c];
+      uint64_t w = lv.wid;
       options = options * w;
       if (options > 0xFFFFFFFFFFFFull) options = 0xFFFFFFFFFFFFull;
       ncand *= cn[l];

@@ -42,10 +42,11 @@ __device__ __forceinline__ SideSpec side_spec(const DevArgs &A, const WgShared &
     sp.cn[l] = 1; sp.to[l] = 0; sp.sl[l] = 0;
     if (l < sp.n) {
       int c = (int)((pat >> l) & 1u) ^ side;
-      sp.cn[l] = sj.cnt[l][c];
-      sp.to[l] = sh.toff[l][c];
+      const ListVer lv = sh.lv[l][c][sh.side_ver[2 * ph + side]];
+      sp.cn[l] = lv.cnt;
+      sp.to[l] = lv.off;
       sp.sl[l] = sj.slot[l];
-      options *= (uint64_t)sj.wid[l][c];
+      options *= (uint64_t)lv.wid;
       if (options > 0xFFFFFFFFFFFFull) options = 0xFFFFFFFFFFFFull;
       sp.ncand *= sp.cn[l];
       sp.typed_mask |= 1u << sp.sl[l];
@@ -401,10 +402,9 @@ __device__ __forceinline__ bool side_row(const DevArgs &A, WgShared &sh, const S
 // replaces every '/'-list that has at least one allele known to the graph by its single most
 // frequent allele (frequency summed over populations under the all-ones prior, first wins ties);
 // best[l][c] = token index of that allele inside list (l,c), 0xFFFF if none is known.
-__device__ __forceinline__ SideSpec side_spec_c(const DevArgs &A, const WgShared &sh, const uint16_t (*best)[2], int ph,
+__device__ __forceinline__ SideSpec side_spec_c(const DevArgs &A, const WgShared &sh, const uint16_t (*best)[GRIM_MAXL], int ph,
                                                 int side) {
   SideSpec sp = side_spec(A, sh, ph, side);
-  const grim_subject &sj = sh.subj;
   const uint32_t pat = sh.ph_pat[ph];
   uint64_t options = 1;
   sp.ncand = 1;
@@ -412,11 +412,11 @@ __device__ __forceinline__ SideSpec side_spec_c(const DevArgs &A, const WgShared
   for (int l = 0; l < GRIM_MAXL; ++l) {
     if (l < sp.n) {
       int c = (int)((pat >> l) & 1u) ^ side;
-      if (best[l][c] != 0xFFFF) {
-        sp.to[l] += best[l][c];
+      if (best[2 * ph + side][l] != 0xFFFF) {
+        sp.to[l] += best[2 * ph + side][l];
         sp.cn[l] = 1;
       } else {
-        options *= (uint64_t)sj.wid[l][c];
+        options *= (uint64_t)sh.lv[l][c][sh.side_ver[2 * ph + side]].wid;
         if (options > 0xFFFFFFFFFFFFull) options = 0xFFFFFFFFFFFFull;
       }
       sp.ncand *= sp.cn[l];
@@ -524,7 +524,7 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_b_kernel(DevArgs A) {
   __shared__ uint32_t absent_side[2];
   __shared__ uint32_t unsupported;
   __shared__ uint8_t side_scan[GRIM_SIDES], side_any[GRIM_SIDES];
-  __shared__ uint16_t bestc[GRIM_MAXL][2];
+  __shared__ uint16_t bestc[GRIM_SIDES][GRIM_MAXL];
   const int tid = threadIdx.x;
   const int P = A.g.P;
   const uint32_t n_work = *A.next_count;
@@ -542,7 +542,8 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_b_kernel(DevArgs A) {
     STAMP_BEGIN();
     enumerate_phases(sh);
     const int nph = sh.nph;
-    const uint16_t *tok = A.tok + sh.subj.tok_off;
+    const uint16_t *tok = S.rtok;
+    prepare_lists(A, sh, S);  // fits: the plan-A kernel checked
     // open_phases keeps a phase only when both sides have candidates (impute.py:987-988); sides opened
     // by the label scan may have none
     if (tid < GRIM_SIDES) {
@@ -550,13 +551,21 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_b_kernel(DevArgs A) {
       side_any[tid] = 0;
     }
     __syncthreads();
-    for (int s = wave_id(); s < 2 * nph; s += GRIM_NWAVE) {
-      SideSpec sp = side_spec(A, sh, s >> 1, s & 1);
-      uint32_t ncand = sp.expansion ? 1u : scan_count(A, sp, tok);
-      if (lane_id() == 0) {
-        side_scan[s] = sp.expansion ? 0 : 1;
-        side_any[s] = ncand ? 1 : 0;
+    for (int stage = 0;; ++stage) {  // same opening (and rewrites) as the plan-A kernel went through
+      for (int s = wave_id(); s < 2 * nph; s += GRIM_NWAVE) {
+        SideSpec sp = side_spec(A, sh, s >> 1, s & 1);
+        uint32_t ncand = sp.expansion ? 1u : scan_count(A, sp, tok);
+        if (lane_id() == 0) {
+          side_scan[s] = sp.expansion ? 0 : 1;
+          side_any[s] = ncand ? 1 : 0;
+        }
       }
+      __syncthreads();
+      bool kept = false;
+      for (int i = 0; i < nph; ++i) kept |= (side_any[2 * i] && side_any[2 * i + 1]);
+      if (kept || stage == 2) break;
+      if (stage == 0) reduce_lists(A, sh, S, A.priors + (uint64_t)sh.subj.prior_idx * P * P);
+      apply_stage(A, sh, stage + 1);
     }
     // alleles of a position that the graph has never seen on ANY phase of a side (impute.py:1224-1241)
     if (tid < 2) absent_side[tid] = 0;
@@ -572,8 +581,8 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_b_kernel(DevArgs A) {
             continue;
           }
           int c = (int)((sh.ph_pat[i] >> l) & 1u) ^ side;
-          for (uint32_t t = 0; t < sh.subj.cnt[l][c]; ++t)
-            any |= allele_known(A.g, sh.subj.slot[l], tok[sh.toff[l][c] + t]);
+          const ListVer lv = sh.lv[l][c][sh.side_ver[2 * i + side]];
+          for (uint32_t t = 0; t < lv.cnt; ++t) any |= allele_known(A.g, sh.subj.slot[l], tok[lv.off + t]);
         }
         if (!any) atomicOr(&absent_side[side], 1u << l);
       }
@@ -642,13 +651,15 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_b_kernel(DevArgs A) {
         // subset of the ones that just failed, so it ends here as well.
         plan = 'c';
         const double *prior = A.priors + (uint64_t)A.ones_prior * P * P;
-        if (tid < 2 * GRIM_MAXL) {
-          const int l = tid >> 1, c = tid & 1;
+        for (int q = tid; q < 2 * nph * GRIM_MAXL; q += GRIM_WG) {
+          const int sd = q / GRIM_MAXL, l = q % GRIM_MAXL;
           uint16_t b = 0xFFFF;
           if (l < sh.subj.n_loci) {
+            const int c = (int)((sh.ph_pat[sd >> 1] >> l) & 1u) ^ (sd & 1);
+            const ListVer lv = sh.lv[l][c][sh.side_ver[sd]];
             double bs = 0.0;
-            for (uint32_t t = 0; t < sh.subj.cnt[l][c]; ++t) {
-              uint32_t node = graph_lookup(A.g, (uint64_t)(tok[sh.toff[l][c] + t] + 1u) << (GRIM_ABITS * sh.subj.slot[l]));
+            for (uint32_t t = 0; t < lv.cnt; ++t) {
+              uint32_t node = graph_lookup(A.g, (uint64_t)(tok[lv.off + t] + 1u) << (GRIM_ABITS * sh.subj.slot[l]));
               if (node == GRIM_NONE) continue;
               double sc = 0.0;
               for (int j = 0; j < P; ++j) sc = sc + A.g.freq[(uint64_t)node * P + j] * prior[j * P + j];
@@ -658,7 +669,7 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_b_kernel(DevArgs A) {
               }
             }
           }
-          bestc[l][c] = b;
+          bestc[sd][l] = b;
         }
         for (int s = tid; s < GRIM_COMP_CAP; s += GRIM_WG) S.comp[s] = 0;
         if (tid < GRIM_SIDES) sh.Tn[tid] = 0;

@@ -16,7 +16,7 @@ TOPCAP = 128
 MAXLADDER = 64
 MAXROWS = 8
 
-ST_OK, ST_MISS, ST_UNSUPPORTED = 0, 1, 2
+ST_OK, ST_MISS, ST_UNSUPPORTED, ST_NOPHASE = 0, 1, 2, 3
 T_UMUG, T_UMUG_POPS, T_PMUG, T_PMUG_POPS = 0, 1, 2, 3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

@@ -24,8 +24,9 @@ from .. import _native as nat
 _DEV, _PROBLEM_ID, _PROBLEM_RAW, _MISS_NO_DEVICE = 0, 1, 2, 3
 
 REASONS = {
-    1: "open_phases found no candidate in any phase (reduce_phase_to_* rewrite, impute.py:1620-1627)",
-    2: "Plan B / Plan C fallback (impute.py:1392-1570, 1313-1389)",
+    2: "Plan B / Plan C fallback not resolved on the device (internal)",
+    3: "Plan C for a subject whose '/'-lists stay above number_of_options_threshold after the most-common-allele reduction",
+    5: "more than 4096 alleles in one GL string",
 }
 
 
@@ -469,6 +470,13 @@ class Imputation(object):
                 print(f"{i} Subject: {sid} - Exception")
                 continue
             r = res[dev[j]] if k == nat.K_DEVICE else None
+            if r is not None and r["status"] == nat.ST_NOPHASE:
+                if haps_on:
+                    print("{index} Subject: {id} 3 haplotypes".format(index=i, id=sid))  # len("Nan")
+                    print(f"{i} Subject: {sid} - Exception")
+                else:
+                    print("{index} Subject: {id} 0 haplotypes".format(index=i, id=sid))
+                continue
             if haps_on:
                 print("{index} Subject: {id} {hap_length} haplotypes".format(
                     index=i, id=sid, hap_length=int(r["n_pairs"]) if r is not None else 0))
@@ -538,6 +546,10 @@ class Imputation(object):
                 r = None
             else:
                 r = res[di]
+                if r["status"] == nat.ST_NOPHASE:  # impute.py:1607-1609 placeholder -> raises in the phased writer
+                    if haps_on:
+                        out["problem"].append(str(line) + "\n")
+                    continue
                 n_pairs = int(r["n_pairs"]) if haps_on else 0
                 n_geno = int(r["n_genotypes"]) if muug_on else 0
             # impute.py:2065-2068 -- with output_haplotypes off res_haps["Haps"] is the 3-char

@@ -228,3 +228,16 @@ def test_config5_style_high_ambiguity_threshold_1e6():
     lines = synth.SubjectGen(rows, 50).high_ambiguity(3, width=8)
     conf = dict(harness.base_conf(["CAU"]), number_of_options_threshold=1000000)
     _against_oracle("cau", conf, lines, "c5")
+
+
+@pytest.mark.parametrize("threshold", [200, 30, 8])
+def test_label_scan_heavy_workload_vs_oracle(threshold):
+    """Low number_of_options_threshold pushes most sides through the label-scan opening: Plan A, Plan B
+    and the rewrites of an empty open_phases (impute.py:1619-1627) on that branch."""
+    rows = synth.read_freqs(synth.CAU_FREQS)
+    lines = synth.SubjectGen(rows, 61).mixed(600, amb=0.7, miss=0.1, recomb=0.5)
+    conf = dict(harness.base_conf(["CAU"]), number_of_options_threshold=threshold)
+    _against_oracle("cau", conf, lines, "scan%d" % threshold)
+    conf4 = dict(harness.base_conf(harness.POPS["pop4"]), number_of_options_threshold=threshold, UNK_priors="MR")
+    lines4 = synth.SubjectGen(rows, 62, pops=harness.POPS["pop4"]).mixed(300, amb=0.7, miss=0.1, recomb=0.5)
+    _against_oracle("pop4", conf4, lines4, "scan4_%d" % threshold)

@@ -228,6 +228,9 @@ def main():
                  {"max_haplotypes_number_in_phase": 5})
     run_scenario("cau_em_mr", w1, ["CAU"], synth.SubjectGen(cau, 13).mixed(40), hap_pop_pair=True)
     run_scenario("cau_planc", w1, ["CAU"], synth.plan_c_cases("CAU"))
+    scan_lines = synth.SubjectGen(cau, 61).mixed(250, amb=0.7, miss=0.1, recomb=0.5)
+    run_scenario("cau_scan30", w1, ["CAU"], scan_lines, {"number_of_options_threshold": 30})
+    run_scenario("cau_scan8_muug", w1, ["CAU"], scan_lines[:120], {"number_of_options_threshold": 8, "output_haplotypes": False})
     bl = synth.SubjectGen(cau, 15).mixed(120) + synth.SubjectGen(cau, 16).full(80)
     import numpy as _np
     _r = _np.random.default_rng(17)
@@ -241,6 +244,8 @@ def main():
                  {"UNK_priors": "MR"})
     run_scenario("pop4_sr", w4, POP4, synth.SubjectGen(pop_rows["HIS"], 6, pops=POP4).mixed(120), {"UNK_priors": "SR"})
     run_scenario("pop4_edge", w4, POP4, synth.edge_cases("AFA") + synth.edge_cases("UNK"), {"UNK_priors": "MR"})
+    run_scenario("pop4_scan30", w4, POP4, synth.SubjectGen(cau, 62, pops=POP4).mixed(200, amb=0.7, miss=0.1, recomb=0.5),
+                 {"number_of_options_threshold": 30, "UNK_priors": "MR"})
     run_scenario("pop4_planc", w4, POP4, synth.plan_c_cases("HIS") + synth.plan_c_cases("UNK"), {"UNK_priors": "MR"})
     run_scenario("pop4_planc_haps", w4, POP4, synth.plan_c_cases("API"), {"UNK_priors": "SR", "output_MUUG": False})
     run_scenario("pop4_em_mr", w4, POP4, synth.SubjectGen(cau, 14, pops=POP4).mixed(40), {"UNK_priors": "MR"},
