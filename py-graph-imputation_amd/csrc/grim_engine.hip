@@ -134,6 +134,10 @@ struct grim_ctx {
   hipStream_t stream;
   std::string err;
   int n_cu;
+  // per-workgroup scratch slots, kept across batches (13 GB at the default sizes: allocating them
+  // per batch cost more than the kernels)
+  void *scratch;
+  uint64_t scratch_bytes;
 };
 
 struct grim_graph {
@@ -201,6 +205,8 @@ extern "C" grim_ctx *grim_create(int device_id) {
   }
   hipDeviceProp_t prop;
   c->n_cu = 256;
+  c->scratch = nullptr;
+  c->scratch_bytes = 0;
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->n_cu = prop.multiProcessorCount;
   return c;
 }
@@ -208,6 +214,7 @@ extern "C" grim_ctx *grim_create(int device_id) {
 extern "C" void grim_destroy(grim_ctx *c) {
   if (!c) return;
   hipSetDevice(c->device);
+  if (c->scratch) hipFree(c->scratch);
   hipStreamDestroy(c->stream);
   delete c;
 }
@@ -480,7 +487,16 @@ extern "C" grim_batch *grim_batch_upload(grim_ctx *c, const grim_graph *g, const
   L.proj_p = take(4ull * GRIM_NWAVE * A.proj_cap);
   L.rtok = take(2ull * GRIM_RTOK_CAP);
   L.stride = align256(o);
-  A.scratch = upload<uint8_t>(c, b->bufs, nullptr, (size_t)L.stride * slots, &bytes);
+  {
+    uint64_t need = (uint64_t)L.stride * slots;
+    if (need > c->scratch_bytes) {
+      if (c->scratch) hipFree(c->scratch);
+      c->scratch = nullptr;
+      c->scratch_bytes = 0;
+      if (hipMalloc(&c->scratch, need) == hipSuccess) c->scratch_bytes = need;
+    }
+    A.scratch = (uint8_t *)c->scratch;
+  }
   bool ok = A.subj && A.tok && A.priors && b->order_s && b->order_g && b->order_m && A.bail_list && b->small_recs && b->hstate && A.queue && A.next_list && A.res && A.counters && A.rows && A.scratch;
   b->gexec = nullptr;
   b->graph_state = 0;

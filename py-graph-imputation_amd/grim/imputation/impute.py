@@ -281,12 +281,15 @@ class Imputation(object):
         ctx = nat.default_context(self.device)
         dgraph = self.netGraph.device(ctx)
         params = self._params(config, planb, em_mr)
+        tu = timeit.default_timer()
         batch = nat.DeviceBatch(ctx, dgraph, params, subj, tokens, priors)
         t0 = timeit.default_timer()
         batch.run()
         t1 = timeit.default_timer()
         res, rows = batch.results()
+        t2 = timeit.default_timer()
         self.last_stats = {
+            "upload_s": t0 - tu, "download_s": t2 - t1,
             "n": n, "run_s": t1 - t0, "kernel_ms": batch.kernel_ms(0), "kernel_a_ms": batch.kernel_ms(1),
             "kernel_b_ms": batch.kernel_ms(2), "counters": batch.counters(),
         }
@@ -383,8 +386,11 @@ class Imputation(object):
         if not config["epsilon"] > 0:
             raise NotImplementedError("epsilon <= 0: the reference returns its 'NaN' sentinel and fails every subject")
         self.unsupported = []
+        tm = [timeit.default_timer()]
         text = "".join(l if l.endswith("\n") else l + "\n" for l in lines).encode()
+        tm.append(timeit.default_timer())
         parsed = nat.Parsed(self.netGraph.adict, text, planb)
+        tm.append(timeit.default_timer())
         try:
             if os.path.isfile(config["bin_imputation_input_file"]):
                 # phase masks (impute.py:2001-2005, 2030-2032, 277-290): position m may switch sides only
@@ -434,7 +440,11 @@ class Imputation(object):
                     raise UnsupportedSubjects(bad)
                 skip = np.zeros(len(kinds), dtype=np.uint8)
                 skip[bad_lines] = 1
+            tm.append(timeit.default_timer())
             texts = parsed.format(self.netGraph.adict, params, self.populations, res, rows, line_offset, skip)
+            tm.append(timeit.default_timer())
+            self.last_stats["host_s"] = {"join": tm[1] - tm[0], "tokenize": tm[2] - tm[1], "device_total": tm[3] - tm[2],
+                                         "format": tm[4] - tm[3]}
             if not self.quiet:
                 self._print_log(parsed, kinds, dev, res, skip, line_offset, muug_on, haps_on, per_subject)
             return texts
@@ -444,12 +454,15 @@ class Imputation(object):
     def _run_arrays(self, subj, tokens, priors, params):
         ctx = nat.default_context(self.device)
         dgraph = self.netGraph.device(ctx)
+        tu = timeit.default_timer()
         batch = nat.DeviceBatch(ctx, dgraph, params, subj, tokens, priors)
         t0 = timeit.default_timer()
         batch.run()
         t1 = timeit.default_timer()
         res, rows = batch.results()
+        t2 = timeit.default_timer()
         self.last_stats = {
+            "upload_s": t0 - tu, "download_s": t2 - t1,
             "n": len(subj), "run_s": t1 - t0, "kernel_ms": batch.kernel_ms(0), "kernel_a_ms": batch.kernel_ms(1),
             "kernel_b_ms": batch.kernel_ms(2), "counters": batch.counters(),
         }
