@@ -67,6 +67,10 @@ def _write_inputs(work, conf, lines, tag):
     conf["imputation_out_path"] = "output_" + tag
     with open(os.path.join(work, conf["imputation_in_file"]), "w") as fh:
         fh.write("\n".join(lines) + "\n")
+    for f in OUT_FILES.values():  # a run that switches an output off must not see an older run's file
+        stale = os.path.join(work, "output_" + tag, f)
+        if os.path.exists(stale):
+            os.remove(stale)
     cpath = os.path.join(work, "conf_%s.json" % tag)
     with open(cpath, "w") as fh:
         json.dump(conf, fh)
