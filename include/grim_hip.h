@@ -142,7 +142,8 @@ typedef struct {
   uint8_t status;
   uint8_t plan;           /* 'a', 'b' or 'c' as in impute.py:216,1638,1702 */
   uint8_t reason;         /* for GRIM_ST_UNSUPPORTED */
-  uint8_t pad;
+  uint8_t plan_phased;    /* plan the .pmug/.pmug.pops rows came from when it differs from `plan` (the phased pass
+                             after a MUUG Plan C starts over, impute.py:1645-1654); 0 = same as `plan` */
   uint32_t n_pairs;       /* len(res_haps["Haps"])  (impute.py:2074-2078) */
   uint32_t n_genotypes;   /* len(res_muugs["Haps"]) (impute.py:2108-2112) */
   uint32_t row_off[GRIM_T_COUNT];

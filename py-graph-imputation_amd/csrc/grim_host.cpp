@@ -522,13 +522,14 @@ static void format_range(const grim_dict *d, const grim_parsed *P, const grim_pa
       o.t[4].push_back('\n');
     }
     if (!r) continue;
-    const int plan = r->plan;
     for (int pass = 0; pass < 4; ++pass) {
       // the reference writes phased rows, phased pops, MUUG rows, MUUG pops (impute.py:2070-2118)
       static const int order[4] = {GRIM_T_PMUG, GRIM_T_PMUG_POPS, GRIM_T_UMUG, GRIM_T_UMUG_POPS};
       const int table = order[pass];
       const bool on = (table == GRIM_T_UMUG || table == GRIM_T_UMUG_POPS) ? prm->out_muug : prm->out_haps;
       if (!on) continue;
+      const bool phased = table == GRIM_T_PMUG || table == GRIM_T_PMUG_POPS;
+      const int plan = phased && r->plan_phased ? r->plan_phased : r->plan;
       std::string &out = o.t[table];
       for (uint32_t k = 0; k < r->n_rows[table]; ++k) {
         const grim_row &row = rows[r->row_off[table] + k];

@@ -27,6 +27,11 @@ struct WgShared {
   ListVer lv[GRIM_MAXL][2][3];
   uint8_t side_ver[GRIM_SIDES];
   uint32_t ntok;
+  // Plan C's most-common-allele reduction (impute.py:881-912 with commons_number=1, planc=True):
+  // bestc[s][l] = index inside side s's current list at position l of the allele that stays
+  // (0xFFFF: none of the list is known to the graph, the list stays); active while `reduced` is set
+  uint16_t bestc[GRIM_SIDES][GRIM_MAXL];
+  uint8_t reduced;
   uint32_t Tn[GRIM_SIDES];
   uint8_t cand_any[GRIM_SIDES];
   uint8_t ph_pat[GRIM_MAXPH];
@@ -568,7 +573,7 @@ __device__ inline uint32_t alloc_rows(const DevArgs &A, WgShared &sh, uint32_t n
 // population-pair table: one lane per unordered cell walks U in order (sums are left-to-right,
 // impute.py:535-543 and 24-39); both display orientations come from the same sums.
 __device__ inline void pop_tables(const DevArgs &A, WgShared &sh, const Slot &S, uint32_t nU, grim_subject_result &out,
-                                  bool plan_c) {
+                                  uint32_t mask) {
   const int tid = threadIdx.x;
   const int P = A.g.P;
   const int ncell = P * P;
@@ -675,6 +680,7 @@ __device__ inline void pop_tables(const DevArgs &A, WgShared &sh, const Slot &S,
     // (impute.py:2088) and leaves the MUUG pops file as usual
   }
   for (int t = 0; t < 2; ++t) {
+    if (!((mask >> t) & 1u)) continue;  // this half of the tables belongs to another pass
     int table = t == 0 ? GRIM_T_UMUG_POPS : GRIM_T_PMUG_POPS;
     bool on = t == 0 ? A.prm.out_muug : A.prm.out_haps;
     uint32_t want = nrow;
@@ -754,7 +760,7 @@ __device__ __forceinline__ uint32_t wave_alloc_rows(const DevArgs &A, uint32_t n
 
 // e1/e2/prob/k1/k2: this lane's pair (entities, probability, the two 60-bit haplotype keys)
 __device__ inline void emit_small_core(const DevArgs &A, uint32_t nU, uint32_t e1, uint32_t e2, double prob, uint64_t k1,
-                                       uint64_t k2, grim_subject_result &out) {
+                                       uint64_t k2, grim_subject_result &out, uint32_t mask = 3) {
   const int lane = lane_id();
   const int n = (int)nU;
   const bool act = lane < n;
@@ -770,6 +776,7 @@ __device__ inline void emit_small_core(const DevArgs &A, uint32_t nU, uint32_t e
     const uint32_t nq = (uint32_t)__popcll(__ballot(is_head));
     const uint32_t rank = wave_rank(sum, is_head, n);
     for (int t = 0; t < 2; ++t) {
+      if (!((mask >> t) & 1u)) continue;
       const int table = t == 0 ? GRIM_T_UMUG_POPS : GRIM_T_PMUG_POPS;
       uint32_t want = nq < A.prm.n_pop_results ? nq : A.prm.n_pop_results;
       if (t == 1 && A.prm.em_mr) want = nq < 1 ? nq : 1;
@@ -793,7 +800,7 @@ __device__ inline void emit_small_core(const DevArgs &A, uint32_t nU, uint32_t e
     }
   }
   // ---- genotypes -----------------------------------------------------------------------------------
-  {
+  if (mask & 1u) {
     uint64_t lo = 0, hi = 0;
 #pragma unroll
     for (int l = 0; l < GRIM_MAXL; ++l) {
@@ -819,7 +826,7 @@ __device__ inline void emit_small_core(const DevArgs &A, uint32_t nU, uint32_t e
     }
   }
   // ---- haplotype pairs ------------------------------------------------------------------------------
-  {
+  if (mask & 2u) {
     uint32_t want = 0, off = 0, rank = 0;
     bool is_head = false;
     if (A.prm.out_haps) {
@@ -843,7 +850,8 @@ __device__ inline void emit_small_core(const DevArgs &A, uint32_t nU, uint32_t e
   }
 }
 
-__device__ inline void emit_small(const DevArgs &A, WgShared &sh, const Slot &S, uint32_t nU, grim_subject_result &out) {
+__device__ inline void emit_small(const DevArgs &A, WgShared &sh, const Slot &S, uint32_t nU, grim_subject_result &out,
+                                  uint32_t mask) {
   const int lane = lane_id();
   uint32_t e1 = 0, e2 = 0;
   double prob = 0.0;
@@ -856,27 +864,30 @@ __device__ inline void emit_small(const DevArgs &A, WgShared &sh, const Slot &S,
     k1 = hap_key(A.g, S, ENT_HAP(e1));
     k2 = hap_key(A.g, S, ENT_HAP(e2));
   }
-  emit_small_core(A, nU, e1, e2, prob, k1, k2, out);
+  emit_small_core(A, nU, e1, e2, prob, k1, k2, out, mask);
 }
 
 // Everything after the final pass: the four output tables of one subject.
-__device__ inline void emit_tables(const DevArgs &A, WgShared &sh, const Slot &S, uint32_t nU, grim_subject_result &out) {
+// mask: bit 0 = the MUUG half (.umug, .umug.pops), bit 1 = the phased half (.pmug, .pmug.pops).  The two
+// halves come from different passes when the MUUG pass ended in Plan C (impute.py:1637-1654).
+__device__ inline void emit_tables(const DevArgs &A, WgShared &sh, const Slot &S, uint32_t nU, grim_subject_result &out,
+                                   uint32_t mask = 3) {
   const int tid = threadIdx.x;
   if (tid == 0) {
     sh.bc[2] = 0;
-    out.n_pairs = nU;
+    if (mask & 2u) out.n_pairs = nU;
   }
   __syncthreads();
   if (nU <= 64) {
-    if (wave_id() == 0) emit_small(A, sh, S, nU, out);
+    if (wave_id() == 0) emit_small(A, sh, S, nU, out, mask);
     __syncthreads();
     return;
   }
   STAMP_BEGIN();
-  pop_tables(A, sh, S, nU, out, false);
+  pop_tables(A, sh, S, nU, out, mask);
   STAMP(13);
   // genotype table (.umug)
-  {
+  if (mask & 1u) {
     uint32_t *order = nullptr;
     uint32_t ng = group_and_rank(A, sh, S, nU, 0, &order, A.prm.out_muug ? A.prm.n_results : 0);
     STAMP(14);
@@ -902,7 +913,7 @@ __device__ inline void emit_tables(const DevArgs &A, WgShared &sh, const Slot &S
     __syncthreads();
   }
   // haplotype-pair table (.pmug)
-  {
+  if (mask & 2u) {
     uint32_t *order = nullptr;
     uint32_t ng = 0, want = 0;
     if (A.prm.out_haps) {

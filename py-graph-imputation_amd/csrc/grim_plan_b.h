@@ -52,6 +52,25 @@ __device__ __forceinline__ SideSpec side_spec(const DevArgs &A, const WgShared &
       sp.typed_mask |= 1u << sp.sl[l];
     }
   }
+  if (sh.reduced) {  // Plan C's reduction: one allele per list wherever the graph knows any
+    options = 1;
+    sp.ncand = 1;
+#pragma unroll
+    for (int l = 0; l < GRIM_MAXL; ++l) {
+      if (l < sp.n) {
+        const uint16_t b = sh.bestc[2 * ph + side][l];
+        if (b != 0xFFFF) {
+          sp.to[l] += b;
+          sp.cn[l] = 1;
+        } else {
+          int c = (int)((pat >> l) & 1u) ^ side;
+          options *= (uint64_t)sh.lv[l][c][sh.side_ver[2 * ph + side]].wid;
+          if (options > 0xFFFFFFFFFFFFull) options = 0xFFFFFFFFFFFFull;
+        }
+        sp.ncand *= sp.cn[l];
+      }
+    }
+  }
   sp.expansion = options < A.prm.opt_threshold;
   return sp;
 }
@@ -402,30 +421,6 @@ __device__ __forceinline__ bool side_row(const DevArgs &A, WgShared &sh, const S
 // replaces every '/'-list that has at least one allele known to the graph by its single most
 // frequent allele (frequency summed over populations under the all-ones prior, first wins ties);
 // best[l][c] = token index of that allele inside list (l,c), 0xFFFF if none is known.
-__device__ __forceinline__ SideSpec side_spec_c(const DevArgs &A, const WgShared &sh, const uint16_t (*best)[GRIM_MAXL], int ph,
-                                                int side) {
-  SideSpec sp = side_spec(A, sh, ph, side);
-  const uint32_t pat = sh.ph_pat[ph];
-  uint64_t options = 1;
-  sp.ncand = 1;
-#pragma unroll
-  for (int l = 0; l < GRIM_MAXL; ++l) {
-    if (l < sp.n) {
-      int c = (int)((pat >> l) & 1u) ^ side;
-      if (best[2 * ph + side][l] != 0xFFFF) {
-        sp.to[l] += best[2 * ph + side][l];
-        sp.cn[l] = 1;
-      } else {
-        options *= (uint64_t)sh.lv[l][c][sh.side_ver[2 * ph + side]].wid;
-        if (options > 0xFFFFFFFFFFFFull) options = 0xFFFFFFFFFFFFull;
-      }
-      sp.ncand *= sp.cn[l];
-    }
-  }
-  sp.expansion = options < A.prm.opt_threshold;
-  return sp;
-}
-
 __device__ __forceinline__ double pop_sum(const DevGraph &g, uint32_t node) {  // allel_to_SR, impute.py:1260-1262
   double s = 0.0;
   for (uint32_t j = 0; j < g.P; ++j) s = s + g.freq[(uint64_t)node * g.P + j];
@@ -504,27 +499,198 @@ __device__ inline bool side_plan_c(const DevArgs &A, WgShared &sh, const Slot &S
   return st.nrun > 0;
 }
 
-// Score the lists currently in the slot at epsilon 0 and, if anything was accepted, write the tables.
-__device__ inline bool planb_score(const DevArgs &A, WgShared &sh, const Slot &S, const double *prior, double *mx) {
+// ---- the fallback passes; each leaves its accepted pairs in the slot (U) and returns their count --------
+struct PbState {
+  uint8_t memo[GRIM_SIDES];
+  uint8_t side_scan[GRIM_SIDES], side_any[GRIM_SIDES];
+  uint32_t absent_side[2];
+  uint32_t flag;
+};
+
+// candidates per side for the current list versions: which sides the label scan opens, which phases
+// survive open_phases (impute.py:987-988), which positions hold only unseen alleles (impute.py:1224-1241)
+__device__ inline void pb_open(const DevArgs &A, WgShared &sh, PbState &st, const uint16_t *tok) {
+  const int tid = threadIdx.x;
+  const int nph = sh.nph;
+  if (tid < GRIM_SIDES) {
+    st.side_scan[tid] = 0;
+    st.side_any[tid] = 0;
+  }
+  if (tid < 2) st.absent_side[tid] = 0;
+  __syncthreads();
+  for (int s = wave_id(); s < 2 * nph; s += GRIM_NWAVE) {
+    SideSpec sp = side_spec(A, sh, s >> 1, s & 1);
+    uint32_t ncand = sp.expansion ? 1u : scan_count(A, sp, tok);
+    if (lane_id() == 0) {
+      st.side_scan[s] = sp.expansion ? 0 : 1;
+      st.side_any[s] = ncand ? 1 : 0;
+    }
+  }
+  __syncthreads();
+}
+
+__device__ inline void pb_absent(const DevArgs &A, WgShared &sh, PbState &st, const uint16_t *tok) {
+  const int tid = threadIdx.x;
+  const int nph = sh.nph;
+  if (tid < 2) st.absent_side[tid] = 0;
+  __syncthreads();
+  if (tid < 2 * GRIM_MAXL) {
+    const int side = tid / GRIM_MAXL, l = tid % GRIM_MAXL;
+    if (l < sh.subj.n_loci) {
+      bool any = false;
+      for (int i = 0; i < nph; ++i) {
+        if (!(st.side_any[2 * i] && st.side_any[2 * i + 1])) continue;  // phase dropped by open_phases
+        if (st.side_scan[2 * i + side]) {
+          any = true;  // candidates of a label scan are graph nodes: their alleles are known
+          continue;
+        }
+        SideSpec sp = side_spec(A, sh, i, side);
+        for (uint32_t t = 0; t < sp.cn[l]; ++t) any |= allele_known(A.g, sp.sl[l], tok[sp.to[l] + t]);
+      }
+      if (!any) atomicOr(&st.absent_side[side], 1u << l);
+    }
+  }
+  __syncthreads();
+}
+
+__device__ inline uint32_t pb_pairs(const DevArgs &A, WgShared &sh, const Slot &S, const double *prior, double *mx) {
   const uint32_t np = pair_offsets(sh);
-  if (np == 0) return false;
-  STAMP_BEGIN();
-  uint32_t nU = pair_pass(A, sh, S, prior, np, 0.0, true, mx);
-  STAMP(2);
-  if (nU == 0) return false;
-  emit_tables(A, sh, S, nU, sh.out);
-  STAMP(3);
-  return true;
+  if (np == 0) return 0;
+  return pair_pass(A, sh, S, prior, np, 0.0, true, mx);
+}
+
+// Plan B proper: two prior levels x (matrix rows + rescue) (impute.py:1696-1722, 1392-1570)
+__device__ inline uint32_t pb_levels(const DevArgs &A, WgShared &sh, const Slot &S, WaveTop *wt, PbState &st, const uint16_t *tok,
+                                     double *mx) {
+  const int tid = threadIdx.x;
+  const int P = A.g.P;
+  const int nph = sh.nph;
+  for (int level = 0; level < 2; ++level) {
+    const double *prior = A.priors + (uint64_t)(level == 0 ? sh.subj.prior_idx : A.ones_prior) * P * P;
+    if (tid < GRIM_SIDES) st.memo[tid] = 10;
+    __syncthreads();
+    for (int m = 0; m < (int)A.prm.planb_rows; ++m) {
+      for (int s = tid; s < GRIM_COMP_CAP; s += GRIM_WG) S.comp[s] = 0;
+      if (tid < GRIM_SIDES) sh.Tn[tid] = 0;
+      __syncthreads();
+      for (int s = wave_id(); s < 2 * nph; s += GRIM_NWAVE) {
+        if (!(st.side_any[s] && st.side_any[s ^ 1])) continue;  // phase dropped by open_phases
+        SideSpec sp = side_spec(A, sh, s >> 1, s & 1);
+        const uint32_t ab = st.absent_side[s & 1];
+        if (ab == 0) {
+          int idx = m < (int)st.memo[s] ? m : (int)st.memo[s];
+          bool nonempty = side_row(A, sh, S, prior, wt[wave_id()], sp, tok, idx, s);
+          if (nonempty && lane_id() == 0) st.memo[s] = (uint8_t)idx;
+        } else {
+          side_absent(A, sh, S, prior, wt[wave_id()], sp, tok, ab, s);
+        }
+      }
+      __syncthreads();
+      uint32_t nU = pb_pairs(A, sh, S, prior, mx);
+      if (nU) return nU;
+    }
+    // rescue loop (impute.py:1490-1558): its six iterations are identical, one suffices
+    for (int s = tid; s < GRIM_COMP_CAP; s += GRIM_WG) S.comp[s] = 0;
+    if (tid < GRIM_SIDES) sh.Tn[tid] = 0;
+    __syncthreads();
+    for (int s = wave_id(); s < 2 * nph; s += GRIM_NWAVE) {
+      const int mine = st.memo[s], other = st.memo[s ^ 1];
+      if (!(st.side_any[s] && st.side_any[s ^ 1])) continue;
+      if ((mine == 10) == (other == 10)) continue;  // both unset: skipped; both set: stale lists, no-op
+      SideSpec sp = side_spec(A, sh, s >> 1, s & 1);
+      if (mine == 10) {
+        uint32_t ab = absent_positions(A, tok, sp);
+        side_absent(A, sh, S, prior, wt[wave_id()], sp, tok, ab, s);
+      } else {
+        side_row(A, sh, S, prior, wt[wave_id()], sp, tok, mine, s);
+      }
+    }
+    __syncthreads();
+    uint32_t nU = pb_pairs(A, sh, S, prior, mx);
+    if (nU) return nU;
+  }
+  return 0;
+}
+
+// Plan A on the current (possibly reduced) specs, inside this kernel: the phased pass after a MUUG pass
+// that ended in Plan C starts over with the reduced phases (impute.py:1637-1648)
+__device__ inline uint32_t pb_plan_a(const DevArgs &A, WgShared &sh, const Slot &S, WaveTop *wt, PbState &st, const uint16_t *tok,
+                                     double *mx) {
+  const int tid = threadIdx.x;
+  const int P = A.g.P;
+  const int nph = sh.nph;
+  const double *prior = A.priors + (uint64_t)sh.subj.prior_idx * P * P;
+  for (int s = tid; s < GRIM_COMP_CAP; s += GRIM_WG) S.comp[s] = 0;
+  if (tid < GRIM_SIDES) sh.Tn[tid] = 0;
+  __syncthreads();
+  for (int s = wave_id(); s < 2 * nph; s += GRIM_NWAVE) {
+    if (!(st.side_any[s] && st.side_any[s ^ 1])) continue;
+    SideSpec sp = side_spec(A, sh, s >> 1, s & 1);
+    side_lookup_full(A, sh, S, prior, wt[wave_id()], sp, tok, s);
+  }
+  __syncthreads();
+  const uint32_t np = pair_offsets(sh);
+  if (np == 0) return 0;
+  const int e = ladder_first(A, sh, S, prior, np);
+  if (e >= A.prm.n_ladder) return 0;
+  double eps = A.prm.ladder[e];
+  if (eps > 0.0) {
+    pair_pass(A, sh, S, prior, np, eps, false, mx);
+    eps = *mx / 100000.0;
+  }
+  return pair_pass(A, sh, S, prior, np, eps, true, mx);
+}
+
+// Plan C's reduction under `prior` (the all-ones matrix left by level 1): sets sh.bestc / sh.reduced
+__device__ inline void pb_reduce_for_plan_c(const DevArgs &A, WgShared &sh, const uint16_t *tok, const double *prior) {
+  const int tid = threadIdx.x;
+  const int P = A.g.P;
+  const int nph = sh.nph;
+  for (int q = tid; q < 2 * nph * GRIM_MAXL; q += GRIM_WG) {
+    const int sd = q / GRIM_MAXL, l = q % GRIM_MAXL;
+    uint16_t b = 0xFFFF;
+    if (l < sh.subj.n_loci) {
+      const int c = (int)((sh.ph_pat[sd >> 1] >> l) & 1u) ^ (sd & 1);
+      const ListVer lv = sh.lv[l][c][sh.side_ver[sd]];
+      double bs = 0.0;
+      for (uint32_t t = 0; t < lv.cnt; ++t) {
+        uint32_t node = graph_lookup(A.g, (uint64_t)(tok[lv.off + t] + 1u) << (GRIM_ABITS * sh.subj.slot[l]));
+        if (node == GRIM_NONE) continue;
+        double sc = 0.0;
+        for (int j = 0; j < P; ++j) sc = sc + A.g.freq[(uint64_t)node * P + j] * prior[j * P + j];
+        if (b == 0xFFFF || sc > bs) {
+          b = (uint16_t)t;
+          bs = sc;
+        }
+      }
+    }
+    sh.bestc[sd][l] = b;
+  }
+  __syncthreads();
+  if (tid == 0) sh.reduced = 1;
+  __syncthreads();
+}
+
+__device__ inline uint32_t pb_plan_c(const DevArgs &A, WgShared &sh, const Slot &S, WaveTop *wt, const uint16_t *tok, double *mx) {
+  const int tid = threadIdx.x;
+  const int P = A.g.P;
+  const int nph = sh.nph;
+  const double *prior = A.priors + (uint64_t)A.ones_prior * P * P;
+  for (int s = tid; s < GRIM_COMP_CAP; s += GRIM_WG) S.comp[s] = 0;
+  if (tid < GRIM_SIDES) sh.Tn[tid] = 0;
+  __syncthreads();
+  for (int s = wave_id(); s < 2 * nph; s += GRIM_NWAVE) {
+    SideSpec sp = side_spec(A, sh, s >> 1, s & 1);
+    side_plan_c(A, sh, S, prior, wt[wave_id()], sp, tok, s);
+  }
+  __syncthreads();
+  return pb_pairs(A, sh, S, prior, mx);
 }
 
 __global__ __launch_bounds__(GRIM_WG) void grim_plan_b_kernel(DevArgs A) {
   __shared__ WgShared sh;
   __shared__ WaveTop wt[GRIM_NWAVE];
-  __shared__ uint8_t memo[GRIM_SIDES];
-  __shared__ uint32_t absent_side[2];
-  __shared__ uint32_t unsupported;
-  __shared__ uint8_t side_scan[GRIM_SIDES], side_any[GRIM_SIDES];
-  __shared__ uint16_t bestc[GRIM_SIDES][GRIM_MAXL];
+  __shared__ PbState st;
   const int tid = threadIdx.x;
   const int P = A.g.P;
   const uint32_t n_work = *A.next_count;
@@ -537,163 +703,67 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_b_kernel(DevArgs A) {
     const uint32_t si = A.next_list[w];
     if (tid < 16) ((uint32_t *)&sh.subj)[tid] = ((const uint32_t *)&A.subj[si])[tid];
     if (tid < (int)(sizeof(grim_subject_result) / 4)) ((uint32_t *)&sh.out)[tid] = 0;
-    if (tid == 0) unsupported = 0;
+    if (tid == 0) sh.reduced = 0;
     __syncthreads();
-    STAMP_BEGIN();
     enumerate_phases(sh);
     const int nph = sh.nph;
     const uint16_t *tok = S.rtok;
     prepare_lists(A, sh, S);  // fits: the plan-A kernel checked
-    // open_phases keeps a phase only when both sides have candidates (impute.py:987-988); sides opened
-    // by the label scan may have none
-    if (tid < GRIM_SIDES) {
-      side_scan[tid] = 0;
-      side_any[tid] = 0;
-    }
-    __syncthreads();
-    for (int stage = 0;; ++stage) {  // same opening (and rewrites) as the plan-A kernel went through
-      for (int s = wave_id(); s < 2 * nph; s += GRIM_NWAVE) {
-        SideSpec sp = side_spec(A, sh, s >> 1, s & 1);
-        uint32_t ncand = sp.expansion ? 1u : scan_count(A, sp, tok);
-        if (lane_id() == 0) {
-          side_scan[s] = sp.expansion ? 0 : 1;
-          side_any[s] = ncand ? 1 : 0;
-        }
-      }
-      __syncthreads();
+    // same opening (and rewrites of an empty open_phases, impute.py:1619-1627) as the plan-A kernel went through
+    for (int stage = 0;; ++stage) {
+      pb_open(A, sh, st, tok);
       bool kept = false;
-      for (int i = 0; i < nph; ++i) kept |= (side_any[2 * i] && side_any[2 * i + 1]);
+      for (int i = 0; i < nph; ++i) kept |= (st.side_any[2 * i] && st.side_any[2 * i + 1]);
       if (kept || stage == 2) break;
       if (stage == 0) reduce_lists(A, sh, S, A.priors + (uint64_t)sh.subj.prior_idx * P * P);
       apply_stage(A, sh, stage + 1);
     }
-    // alleles of a position that the graph has never seen on ANY phase of a side (impute.py:1224-1241)
-    if (tid < 2) absent_side[tid] = 0;
-    __syncthreads();
-    if (tid < 2 * GRIM_MAXL) {
-      const int side = tid / GRIM_MAXL, l = tid % GRIM_MAXL;
-      if (l < sh.subj.n_loci) {
-        bool any = false;
-        for (int i = 0; i < nph; ++i) {
-          if (!(side_any[2 * i] && side_any[2 * i + 1])) continue;  // phase dropped by open_phases
-          if (side_scan[2 * i + side]) {
-            any = true;  // candidates of a label scan are graph nodes: their alleles are known
-            continue;
-          }
-          int c = (int)((sh.ph_pat[i] >> l) & 1u) ^ side;
-          const ListVer lv = sh.lv[l][c][sh.side_ver[2 * i + side]];
-          for (uint32_t t = 0; t < lv.cnt; ++t) any |= allele_known(A.g, sh.subj.slot[l], tok[lv.off + t]);
-        }
-        if (!any) atomicOr(&absent_side[side], 1u << l);
-      }
-    }
-    __syncthreads();
-    STAMP(0);
-    bool done = false;
+    pb_absent(A, sh, st, tok);
     double mx = 0.0;
-    uint8_t status = GRIM_ST_MISS, reason = 0, plan = 'b';
-    if (unsupported) {
-      status = GRIM_ST_UNSUPPORTED;
-      reason = 3;
+    uint8_t status = GRIM_ST_MISS, reason = 0, plan = 'b', plan_haps = 0;
+    // ---- the pass on the phases as opened: Plan B (Plan A already failed in the first kernels) --------
+    uint32_t nU = pb_levels(A, sh, S, wt, st, tok, &mx);
+    if (nU) {
+      emit_tables(A, sh, S, nU, sh.out, 3);
+      status = GRIM_ST_OK;
     } else {
-      for (int level = 0; level < 2 && !done; ++level) {
-        const double *prior = A.priors + (uint64_t)(level == 0 ? sh.subj.prior_idx : A.ones_prior) * P * P;
-        if (tid < GRIM_SIDES) memo[tid] = 10;
-        __syncthreads();
-        // ---- first loop: matrix rows until something is accepted (impute.py:1414-1488) ----------
-        for (int m = 0; m < (int)A.prm.planb_rows && !done; ++m) {
-          for (int s = tid; s < GRIM_COMP_CAP; s += GRIM_WG) S.comp[s] = 0;
-          if (tid < GRIM_SIDES) sh.Tn[tid] = 0;
-          __syncthreads();
-          for (int s = wave_id(); s < 2 * nph; s += GRIM_NWAVE) {
-            if (!(side_any[s] && side_any[s ^ 1])) continue;  // phase dropped by open_phases
-            SideSpec sp = side_spec(A, sh, s >> 1, s & 1);
-            const uint32_t ab = absent_side[s & 1];
-            if (ab == 0) {
-              int idx = m < (int)memo[s] ? m : (int)memo[s];
-              bool nonempty = side_row(A, sh, S, prior, wt[wave_id()], sp, tok, idx, s);
-              if (nonempty && lane_id() == 0) memo[s] = (uint8_t)idx;
-            } else {
-              side_absent(A, sh, S, prior, wt[wave_id()], sp, tok, ab, s);
-            }
-          }
-          __syncthreads();
-          STAMP(1);
-          done = planb_score(A, sh, S, prior, &mx);
-          STAMP(6);
-        }
-        // ---- rescue loop (impute.py:1490-1558): its six iterations are identical, one suffices ----
-        if (!done) {
-          for (int s = tid; s < GRIM_COMP_CAP; s += GRIM_WG) S.comp[s] = 0;
-          if (tid < GRIM_SIDES) sh.Tn[tid] = 0;
-          __syncthreads();
-          for (int s = wave_id(); s < 2 * nph; s += GRIM_NWAVE) {
-            const int mine = memo[s], other = memo[s ^ 1];
-            if (!(side_any[s] && side_any[s ^ 1])) continue;
-            if ((mine == 10) == (other == 10)) continue;  // both unset: skipped; both set: stale lists, no-op
-            SideSpec sp = side_spec(A, sh, s >> 1, s & 1);
-            if (mine == 10) {
-              uint32_t ab = absent_positions(A, tok, sp);
-              // with nothing absent the reference indexes an empty list (IndexError) once a look-up
-              // succeeds; that needs all loci typed and found, which Plan A would have caught
-              side_absent(A, sh, S, prior, wt[wave_id()], sp, tok, ab, s);
-            } else {
-              side_row(A, sh, S, prior, wt[wave_id()], sp, tok, mine, s);
-            }
-          }
-          __syncthreads();
-          done = planb_score(A, sh, S, prior, &mx);
-        }
-      }
-      if (!done) {
-        // ---- Plan C under the all-ones prior left behind by level 1 (impute.py:1637-1643, 1649-1654).
-        // The phased pass re-runs Plan A and B on the reduced phases first; their candidates are a
-        // subset of the ones that just failed, so it ends here as well.
-        plan = 'c';
-        const double *prior = A.priors + (uint64_t)A.ones_prior * P * P;
-        for (int q = tid; q < 2 * nph * GRIM_MAXL; q += GRIM_WG) {
-          const int sd = q / GRIM_MAXL, l = q % GRIM_MAXL;
-          uint16_t b = 0xFFFF;
-          if (l < sh.subj.n_loci) {
-            const int c = (int)((sh.ph_pat[sd >> 1] >> l) & 1u) ^ (sd & 1);
-            const ListVer lv = sh.lv[l][c][sh.side_ver[sd]];
-            double bs = 0.0;
-            for (uint32_t t = 0; t < lv.cnt; ++t) {
-              uint32_t node = graph_lookup(A.g, (uint64_t)(tok[lv.off + t] + 1u) << (GRIM_ABITS * sh.subj.slot[l]));
-              if (node == GRIM_NONE) continue;
-              double sc = 0.0;
-              for (int j = 0; j < P; ++j) sc = sc + A.g.freq[(uint64_t)node * P + j] * prior[j * P + j];
-              if (b == 0xFFFF || sc > bs) {
-                b = (uint16_t)t;
-                bs = sc;
-              }
-            }
-          }
-          bestc[sd][l] = b;
-        }
-        for (int s = tid; s < GRIM_COMP_CAP; s += GRIM_WG) S.comp[s] = 0;
-        if (tid < GRIM_SIDES) sh.Tn[tid] = 0;
-        if (tid == 0) unsupported = 0;
-        __syncthreads();
-        if (tid < 2 * nph) {
-          SideSpec sp = side_spec_c(A, sh, bestc, tid >> 1, tid & 1);
-          if (!sp.expansion) atomicOr(&unsupported, 1u);
-        }
-        __syncthreads();
-        if (unsupported) {
-          status = GRIM_ST_UNSUPPORTED;
-          reason = 3;
-        } else {
-          for (int s = wave_id(); s < 2 * nph; s += GRIM_NWAVE) {
-            SideSpec sp = side_spec_c(A, sh, bestc, s >> 1, s & 1);
-            side_plan_c(A, sh, S, prior, wt[wave_id()], sp, tok, s);
-          }
-          __syncthreads();
-          done = planb_score(A, sh, S, prior, &mx);
-          status = done ? GRIM_ST_OK : GRIM_ST_MISS;
-        }
+      // ---- Plan C (impute.py:1637-1643 / 1649-1654): lists reduced to their most common allele under the
+      // all-ones prior level 1 left behind; every phase opens again
+      pb_reduce_for_plan_c(A, sh, tok, A.priors + (uint64_t)A.ones_prior * P * P);
+      pb_open(A, sh, st, tok);
+      bool wide = false;
+      for (int s = 0; s < 2 * nph; ++s) wide |= st.side_scan[s] != 0;
+      if (wide) {
+        status = GRIM_ST_UNSUPPORTED;  // a list of unseen alleles still above the options threshold
+        reason = 3;
       } else {
-        status = GRIM_ST_OK;
+        plan = 'c';
+        const bool two_pass = A.prm.out_muug && A.prm.out_haps;
+        nU = pb_plan_c(A, sh, S, wt, tok, &mx);
+        if (nU) {
+          emit_tables(A, sh, S, nU, sh.out, two_pass ? 1u : 3u);
+          status = GRIM_ST_OK;
+        }
+        if (two_pass) {
+          // the phased pass starts over on the REDUCED phases (impute.py:1645-1654): Plan A with the
+          // subject's prior, Plan B's two levels, Plan C again
+          double mx2 = 0.0;
+          pb_absent(A, sh, st, tok);
+          plan_haps = 'a';
+          uint32_t nH = pb_plan_a(A, sh, S, wt, st, tok, &mx2);
+          if (!nH) {
+            plan_haps = 'b';
+            nH = pb_levels(A, sh, S, wt, st, tok, &mx2);
+          }
+          if (!nH) {
+            plan_haps = 'c';
+            nH = pb_plan_c(A, sh, S, wt, tok, &mx2);
+          }
+          if (nH) {
+            emit_tables(A, sh, S, nH, sh.out, 2u);
+            status = GRIM_ST_OK;
+          }
+        }
       }
     }
     __syncthreads();
@@ -701,6 +771,7 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_b_kernel(DevArgs A) {
       sh.out.status = status;
       sh.out.reason = reason;
       sh.out.plan = plan;
+      sh.out.plan_phased = plan_haps;
       sh.out.max_prob = mx;
       A.res[si] = sh.out;
     }

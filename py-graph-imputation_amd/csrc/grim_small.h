@@ -168,7 +168,7 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_a_small_kernel(DevArgs A, c
       if (A.prm.out_muug) A.rows[off + 1] = r;
       if (A.prm.out_haps) A.rows[off + 2] = r;
       grim_subject_result out;
-      out.status = GRIM_ST_OK; out.plan = 'a'; out.reason = 0; out.pad = 0;
+      out.status = GRIM_ST_OK; out.plan = 'a'; out.reason = 0; out.plan_phased = 0;
       out.n_pairs = nU;
       out.n_genotypes = 1;
       out.row_off[GRIM_T_UMUG] = off + 0;       out.n_rows[GRIM_T_UMUG] = A.prm.out_muug ? 1 : 0;

@@ -61,7 +61,7 @@ SUBJECT_DT = np.dtype([
 assert SUBJECT_DT.itemsize == 64
 
 RESULT_DT = np.dtype([
-    ("status", "u1"), ("plan", "u1"), ("reason", "u1"), ("pad", "u1"),
+    ("status", "u1"), ("plan", "u1"), ("reason", "u1"), ("plan_phased", "u1"),
     ("n_pairs", "<u4"), ("n_genotypes", "<u4"),
     ("row_off", "<u4", (4,)), ("n_rows", "<u4", (4,)), ("pad2", "<u4"), ("max_prob", "<f8"),
 ], align=False)

@@ -344,6 +344,7 @@ class Imputation(object):
             for row in rows[r["row_off"][nat.T_UMUG_POPS]: r["row_off"][nat.T_UMUG_POPS] + r["n_rows"][nat.T_UMUG_POPS]]:
                 res_m["Pops"][self._pop_name(row["a"], plan) + "," + self._pop_name(row["b"], plan)] = float(row["prob"])
         if haps_output:
+            plan = int(r["plan_phased"]) or plan
             res_h["MaxProb"] = float(r["max_prob"])
             for row in rows[r["row_off"][nat.T_PMUG]: r["row_off"][nat.T_PMUG] + r["n_rows"][nat.T_PMUG]]:
                 res_h["Haps"].append([self._hap_name(row["a"]), self._hap_name(row["b"])])
@@ -571,8 +572,9 @@ class Imputation(object):
                 out["miss"].append(str(i) + "," + str(sid) + "\n")
             plan = int(r["plan"]) if r is not None else ord("a")
             if haps_on and r is not None:
-                self._write_rows(out["pmug"], sid, rows, r, nat.T_PMUG, plan, em_mr)
-                self._write_rows(out["pmug_pops"], sid, rows, r, nat.T_PMUG_POPS, plan, em_mr)
+                plan_h = int(r["plan_phased"]) or plan
+                self._write_rows(out["pmug"], sid, rows, r, nat.T_PMUG, plan_h, em_mr)
+                self._write_rows(out["pmug_pops"], sid, rows, r, nat.T_PMUG_POPS, plan_h, em_mr)
             if muug_on and r is not None:
                 self._write_rows(out["umug"], sid, rows, r, nat.T_UMUG, plan, em_mr)
                 self._write_rows(out["umug_pops"], sid, rows, r, nat.T_UMUG_POPS, plan, em_mr)

@@ -146,6 +146,9 @@ def build_graph(name, pops):
 
 
 def run_scenario(name, work, pops, lines, overrides=None, hap_pop_pair=False, bin_masks=None):
+    only = os.environ.get("GOLDEN_ONLY")  # comma-separated scenario names: regenerate just those
+    if only and name not in only.split(","):
+        return
     from grim import grim
 
     conf = dict(BASE_CONF, populations=list(pops))
@@ -248,6 +251,13 @@ def main():
                  {"number_of_options_threshold": 30, "UNK_priors": "MR"})
     run_scenario("pop4_planc", w4, POP4, synth.plan_c_cases("HIS") + synth.plan_c_cases("UNK"), {"UNK_priors": "MR"})
     run_scenario("pop4_planc_haps", w4, POP4, synth.plan_c_cases("API"), {"UNK_priors": "SR", "output_MUUG": False})
+    # found by tools/fuzz.py: the MUUG pass ends in Plan C, the phased pass then starts over on the reduced
+    # phases and succeeds earlier (impute.py:1637-1654)
+    rerun = [l.rstrip("\n") for l in open(os.path.join(HERE, "cases", "planc_rerun.csv"))]
+    rerun_conf = {"UNK_priors": "MR", "number_of_options_threshold": 5,
+                  "priority": {"alpha": 0.128, "eta": 0.09, "beta": 0.168, "gamma": 0.165, "delta": 0.667}, "epsilon": 1e-7}
+    run_scenario("pop4_planc_rerun", w4, POP4, rerun, rerun_conf)
+    run_scenario("pop4_planc_rerun_em", w4, POP4, rerun[40:100], rerun_conf, hap_pop_pair=True)
     run_scenario("pop4_em_mr", w4, POP4, synth.SubjectGen(cau, 14, pops=POP4).mixed(40), {"UNK_priors": "MR"},
                  hap_pop_pair=True)
 
