@@ -41,8 +41,10 @@ struct DevGraph {
   const uint32_t *a_start, *a_nbr;
   const uint32_t *b_conn, *b_start, *b_nbr;
   const uint32_t *lab_start, *lab_nodes;
+  const uint64_t *lab_key;  // node_key[lab_nodes[i]]: the label scans stream this instead of gathering
   const HtEnt *ht;  // exact-name index: one 16-byte entry per slot, key == 0 marks an empty slot
   uint32_t n_nodes, P, full_mask, ht_mask, n_conn, n_loci;
+  uint32_t scan_ok;  // names unique and every top-link row shorter than 2^22: the intersection opening may be used
 };
 
 // ---- per-workgroup scratch slot in HBM (offsets in bytes, filled by the host) -------------------
@@ -235,6 +237,7 @@ struct WaveTop {
 struct TopState {
   int nrun, nbuf, K;
   bool full;
+  bool ge;  // entries arrive out of stream order: one that ties the K-th key may still beat it on `tie`
   uint64_t thr;
 };
 
@@ -288,7 +291,7 @@ __device__ __forceinline__ void top_flush(WaveTop &L, TopState &st) {
 __device__ __forceinline__ void top_push(WaveTop &L, TopState &st, bool active, double p, double key, uint64_t tie,
                                          uint32_t hap, uint64_t aux = 0) {
   uint64_t ord = f64_ord(key);
-  bool adm = active && (!st.full || ord > st.thr);
+  bool adm = active && (!st.full || ord > st.thr || (st.ge && ord == st.thr));
   uint64_t m = __ballot(adm);
   if (m == 0) return;
   if (adm) {

@@ -255,14 +255,19 @@ extern "C" grim_graph *grim_graph_upload(grim_ctx *c, const grim_graph_desc *d) 
   while (cap < 2 * (uint64_t)d->n_nodes) cap <<= 1;
   std::vector<uint64_t> hk(cap, 0);
   std::vector<uint32_t> hv(cap, 0);
+  bool unique_names = true;
   for (uint32_t i = 0; i < d->n_nodes; ++i) {
     uint64_t k = d->node_key[i];
     if (k == 0) { c->err = "grim_graph_upload: node with empty key"; delete g; return nullptr; }
     uint32_t h = (uint32_t)host_mix64(k) & (cap - 1);
     while (hk[h] != 0 && hk[h] != k) h = (h + 1) & (cap - 1);
+    if (hk[h] == k) unique_names = false;
     hk[h] = k;  // a repeated name keeps the later row, like dict assignment (networkx_graph.py:53)
     hv[h] = i;
   }
+  uint32_t max_deg = 0;
+  for (uint32_t i = 0; i < d->n_nodes; ++i)
+    if (d->a_start[i + 1] > d->a_start[i]) max_deg = std::max(max_deg, d->a_start[i + 1] - d->a_start[i]);
   uint32_t maxlab = 0;
   for (uint32_t m = 0; m < (1u << GRIM_MAXL); ++m) {
     uint32_t n = d->lab_start[m + 1] - d->lab_start[m];
@@ -286,6 +291,12 @@ extern "C" grim_graph *grim_graph_upload(grim_ctx *c, const grim_graph_desc *d) 
   D.b_nbr = upload(c, g->bufs, d->b_nbr, d->n_b_nbr, &g->bytes);
   D.lab_start = upload(c, g->bufs, d->lab_start, (1u << GRIM_MAXL) + 1, &g->bytes);
   D.lab_nodes = upload(c, g->bufs, d->lab_nodes, d->n_nodes, &g->bytes);
+  {
+    std::vector<uint64_t> lk(d->n_nodes);
+    for (uint32_t i = 0; i < d->n_nodes; ++i) lk[i] = d->node_key[d->lab_nodes[i]];
+    D.lab_key = upload(c, g->bufs, lk.data(), d->n_nodes, &g->bytes);
+  }
+  D.scan_ok = (unique_names && max_deg < (1u << 22) && d->n_pops <= 64) ? 1u : 0u;
   {
     std::vector<HtEnt> ht(cap);
     for (uint32_t i = 0; i < cap; ++i) {
@@ -314,7 +325,7 @@ extern "C" grim_graph *grim_graph_upload(grim_ctx *c, const grim_graph_desc *d) 
     D.fht_mask = fcap - 1;
   }
   if (!D.fht || !D.node_key || !D.node_mask || !D.freq || !D.a_start || !D.a_nbr || !D.b_conn || !D.b_start || !D.b_nbr ||
-      !D.lab_start || !D.lab_nodes || !D.ht) {
+      !D.lab_start || !D.lab_nodes || !D.lab_key || !D.ht) {
     c->err = "grim_graph_upload: device allocation or copy failed";
     for (void *p : g->bufs) hipFree(p);
     delete g;

@@ -32,6 +32,9 @@ struct WgShared {
   // (0xFFFF: none of the list is known to the graph, the list stays); active while `reduced` is set
   uint16_t bestc[GRIM_SIDES][GRIM_MAXL];
   uint8_t reduced;
+  // abits[l][c]: bit a set = allele id a is in the subject's list of position l, column c (version 0).
+  // The intersection opening tests a graph node against a side with one bit per position.
+  uint32_t abits[GRIM_MAXL][2][128];
   uint32_t Tn[GRIM_SIDES];
   uint8_t cand_any[GRIM_SIDES];
   uint8_t ph_pat[GRIM_MAXPH];

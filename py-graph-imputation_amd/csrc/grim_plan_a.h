@@ -50,6 +50,9 @@ __device__ inline bool prepare_lists(const DevArgs &A, WgShared &sh, const Slot 
   const uint32_t ntok = sh.ntok;
   if (3 * ntok > GRIM_RTOK_CAP) return false;
   for (uint32_t t = threadIdx.x; t < ntok; t += GRIM_WG) S.rtok[t] = A.tok[sj.tok_off + t];
+  const bool ambiguous = ntok > 2u * sj.n_loci;  // otherwise no side ever has enough candidates to intersect
+  if (ambiguous)
+    for (int i = threadIdx.x; i < GRIM_MAXL * 2 * 128; i += GRIM_WG) (&sh.abits[0][0][0])[i] = 0;
   if (threadIdx.x < 2 * GRIM_MAXL) {
     const int l = threadIdx.x >> 1, c = threadIdx.x & 1;
     ListVer v;
@@ -57,6 +60,15 @@ __device__ inline bool prepare_lists(const DevArgs &A, WgShared &sh, const Slot 
     v.cnt = l < sj.n_loci ? sj.cnt[l][c] : 0;
     v.wid = l < sj.n_loci ? sj.wid[l][c] : 0;
     sh.lv[l][c][0] = sh.lv[l][c][1] = sh.lv[l][c][2] = v;
+  }
+  __syncthreads();
+  if (ambiguous && threadIdx.x < 2 * GRIM_MAXL) {
+    const int l = threadIdx.x >> 1, c = threadIdx.x & 1;
+    const ListVer v = sh.lv[l][c][0];
+    for (uint32_t t = 0; t < v.cnt; ++t) {
+      const uint32_t tk = A.tok[sj.tok_off + v.off + t];
+      sh.abits[l][c][(tk >> 5) & 127u] |= 1u << (tk & 31u);
+    }
   }
   __syncthreads();
   return true;
@@ -128,7 +140,10 @@ __device__ inline void apply_stage(const DevArgs &A, WgShared &sh, int stage) {
 // through the running top-K.  DIRECT: `src` is the haplotype node itself; otherwise `src` is a CSR
 // row (plan A: a partial node's top links; plan B: a connector's parents) and every neighbour is
 // a haplotype.  AUX: entries carry the 60-bit key node_key | L.caux[owner] and p is scaled.
-template <bool AUX>
+// RANKED: hits arrive in arbitrary order; aux_or carries the hit's position in the reference's candidate
+// stream (< 2^28) and `tie` is rebuilt from (that position, neighbour index < 2^22, population < 64), so the
+// top-K keeps exactly the entries -- in exactly the order -- the in-order stream would have produced.
+template <bool AUX, bool RANKED = false>
 __device__ __forceinline__ void expand_chunk(const DevArgs &A, const double *prior, WaveTop &L, TopState &st, uint32_t src,
                                              bool direct, const uint32_t *csr_start, const uint32_t *csr_nbr, double scale,
                                              uint64_t aux_or, uint64_t &item_base, uint64_t &c_nbr, uint64_t &c_freq) {
@@ -142,14 +157,14 @@ __device__ __forceinline__ void expand_chunk(const DevArgs &A, const double *pri
   if (total == 0) return;
   L.cstart[lane] = inc - cnt;
   L.cnode[lane] = src;
-  if (AUX) L.caux[lane] = aux_or;
+  if (AUX || RANKED) L.caux[lane] = aux_or;
   if (lane == 0) L.cstart[64] = total;
   WAVE_SYNC();
   for (uint32_t t0 = 0; t0 < total; t0 += 64) {
     uint32_t t = t0 + lane;
     bool valid = t < total;
     uint32_t hap = 0;
-    uint64_t aux = 0;
+    uint64_t aux = 0, rtie = 0;
     if (valid) {
       int lo = 0, hi = 63;  // owner lane: last l with cstart[l] <= t
       while (lo < hi) {
@@ -159,6 +174,7 @@ __device__ __forceinline__ void expand_chunk(const DevArgs &A, const double *pri
       uint32_t nd = L.cnode[lo];
       hap = direct ? nd : csr_nbr[csr_start[nd] + (t - L.cstart[lo])];
       if (AUX) aux = g.node_key[hap] | L.caux[lo];
+      if (RANKED) rtie = ((L.caux[lo] << 22) | (uint64_t)(t - L.cstart[lo])) << 14;
     }
     for (int j = 0; j < P; ++j) {
       double p = valid ? g.freq[(uint64_t)hap * P + j] : 0.0;
@@ -166,6 +182,7 @@ __device__ __forceinline__ void expand_chunk(const DevArgs &A, const double *pri
       bool act = valid && p > 0.0;
       double key = p * prior[j * P + j];
       uint64_t tie = (((item_base + t) * (uint64_t)P + (uint64_t)j) << 8) | (uint64_t)j;
+      if (RANKED) tie = rtie | ((uint64_t)j << 8) | (uint64_t)j;
       top_push(L, st, act, p, key, tie, hap, aux);
     }
   }
@@ -216,7 +233,7 @@ __device__ inline void build_side_plan_a(const DevArgs &A, WgShared &sh, const S
   const uint32_t pat = sh.ph_pat[ph];
   const int ver = sh.side_ver[row];
   TopState st;
-  st.nrun = 0; st.nbuf = 0; st.K = (int)A.prm.top_n; st.full = false; st.thr = 0;
+  st.nrun = 0; st.nbuf = 0; st.K = (int)A.prm.top_n; st.full = false; st.ge = false; st.thr = 0;
   uint32_t cn[GRIM_MAXL], to[GRIM_MAXL], sl[GRIM_MAXL];
   uint64_t options = 1;
   uint32_t ncand = 1, mask = 0;
@@ -272,8 +289,43 @@ __device__ inline void build_side_plan_a(const DevArgs &A, WgShared &sh, const S
         if (l < n && (uint32_t)lane < cn[l]) L.toks[l * 64 + lane] = tok[to[l] + lane];
       WAVE_SYNC();
     }
+    // Intersection opening: when the cartesian product dwarfs the label, walk the label's nodes instead
+    // (coalesced key stream, one LDS bit per position) and give each hit its position in the cartesian
+    // order; the ranked top-K then yields the list the in-order probe stream would.
+    const uint32_t la = g.lab_start[mask], lb = g.lab_start[mask + 1];
+    const bool intersect = g.scan_ok && in_lds && ncand >= 2048u && ncand < (1u << 28) && (uint64_t)ncand > 8ull * (lb - la);
+    if (intersect) {
+      st.ge = true;
+      for (uint32_t i0 = la; i0 < lb; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        bool ok = i < lb;
+        uint64_t key = ok ? g.lab_key[i] : 0;
+#pragma unroll
+        for (int l = 0; l < GRIM_MAXL; ++l)
+          if (l < n) {
+            const uint32_t al = ((uint32_t)(key >> (GRIM_ABITS * sl[l])) & 0xFFFu) - 1u;
+            const int c = (int)((pat >> l) & 1u) ^ side;
+            ok = ok && ((sh.abits[l][c][(al >> 5) & 127u] >> (al & 31u)) & 1u);
+          }
+        if (__ballot(ok) == 0) continue;
+        uint64_t rank = 0;  // mixed-radix position, position 0 most significant (as the expansion counts)
+#pragma unroll
+        for (int l = 0; l < GRIM_MAXL; ++l)
+          if (l < n && ok) {
+            const uint32_t al = ((uint32_t)(key >> (GRIM_ABITS * sl[l])) & 0xFFFu) - 1u;
+            uint32_t d = 0;
+            while (d < cn[l] && (uint32_t)L.toks[l * 64 + d] != al) ++d;
+            ok = d < cn[l];  // the bit came from version 0 of the list; a reduced version may lack the allele
+            rank = rank * cn[l] + d;
+          }
+        const uint32_t node = ok ? g.lab_nodes[i] : GRIM_NONE;
+        if (__ballot(ok) == 0) continue;
+        expand_chunk<false, true>(A, prior, L, st, node, full_nodes, g.a_start, g.a_nbr, 1.0, rank, item_base, c_nbr, c_freq);
+      }
+      c_probe += ((uint64_t)(lb - la) * 3) / 4;  // a scanned node costs 12 bytes (key + id), a probe 16
+    }
     constexpr int NQ = 8;  // chunks of 64 candidates per step: NQ independent first probes in flight
-    for (uint32_t c0 = 0; c0 < ncand; c0 += 64u * NQ) {
+    for (uint32_t c0 = 0; !intersect && c0 < ncand; c0 += 64u * NQ) {
       uint64_t keyq[NQ];
       HtEnt entq[NQ];
 #pragma unroll

@@ -129,7 +129,7 @@ __device__ inline bool side_lookup_full(const DevArgs &A, WgShared &sh, const Sl
   const DevGraph &g = A.g;
   const int lane = lane_id();
   TopState st;
-  st.nrun = 0; st.nbuf = 0; st.K = (int)A.prm.top_n; st.full = false; st.thr = 0;
+  st.nrun = 0; st.nbuf = 0; st.K = (int)A.prm.top_n; st.full = false; st.ge = false; st.thr = 0;
   uint64_t item_base = 0, c_nbr = 0, c_freq = 0;
   const bool direct = (sp.typed_mask == g.full_mask);
   if (!sp.expansion) {
@@ -177,7 +177,7 @@ __device__ inline bool side_absent(const DevArgs &A, WgShared &sh, const Slot &S
   const DevGraph &g = A.g;
   const int lane = lane_id();
   TopState st;
-  st.nrun = 0; st.nbuf = 0; st.K = (int)A.prm.top_n; st.full = false; st.thr = 0;
+  st.nrun = 0; st.nbuf = 0; st.K = (int)A.prm.top_n; st.full = false; st.ge = false; st.thr = 0;
   uint32_t src_mask = 0, abs_mask = 0;
 #pragma unroll
   for (int l = 0; l < GRIM_MAXL; ++l)
@@ -229,7 +229,7 @@ __device__ inline bool side_blocks(const DevArgs &A, WgShared &sh, const Slot &S
   const int P = g.P;
   const int nb = A.prm.planb_nblk[mrow];
   TopState st;
-  st.nrun = 0; st.nbuf = 0; st.K = (int)A.prm.top_n; st.full = false; st.thr = 0;
+  st.nrun = 0; st.nbuf = 0; st.K = (int)A.prm.top_n; st.full = false; st.ge = false; st.thr = 0;
   uint32_t *wset = S.bset + (uint64_t)wave_id() * GRIM_MAXL * A.bset_cap;
   const uint32_t *setp[GRIM_MAXL];
   uint32_t setn[GRIM_MAXL];
@@ -436,7 +436,7 @@ __device__ inline bool side_plan_c(const DevArgs &A, WgShared &sh, const Slot &S
   const int lane = lane_id();
   const int P = g.P;
   TopState st;
-  st.nrun = 0; st.nbuf = 0; st.K = (int)A.prm.top_n; st.full = false; st.thr = 0;
+  st.nrun = 0; st.nbuf = 0; st.K = (int)A.prm.top_n; st.full = false; st.ge = false; st.thr = 0;
   const uint32_t miss = g.full_mask & ~sp.typed_mask;
   const uint32_t r0 = miss ? g.lab_start[miss] : 0, rn = miss ? (g.lab_start[miss + 1] - g.lab_start[miss]) : 1;
   const uint64_t total = (uint64_t)sp.ncand * rn;

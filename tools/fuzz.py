@@ -45,8 +45,9 @@ def mutate(line, rng, by_locus):
         for x in loci:
             a, b = x.split("+"); loc = a.split("*")[0]
             pool = by_locus[loc]
-            ext = [str(e) for e in rng.choice(pool, size=min(6, len(pool)), replace=False)]
-            loci2.append("/".join([a] + ext) + "+" + "/".join([b] + ext[:3]))
+            k1 = int(rng.integers(3, 13)); k2 = int(rng.integers(1, 13))
+            ext = [str(e) for e in rng.choice(pool, size=min(max(k1, k2), len(pool)), replace=False)]
+            loci2.append("/".join([a] + ext[:k1]) + "+" + "/".join([b] + ext[:k2]))
         loci = loci2
     parts[1] = "^".join(loci)
     return ",".join(parts)
@@ -83,13 +84,23 @@ def main():
         n = int(rng.integers(40, 160))
         lines = gen.mixed(n, amb=float(rng.random() * 0.7), miss=float(rng.random() * 0.4), recomb=float(rng.random() * 0.6))
         lines = [mutate(l, rng, gen.by_locus) if rng.random() < 0.35 else l for l in lines]
+        binf = None
+        if rng.random() < 0.2:  # per-subject phase masks (bin_imputation_in_file, impute.py:2001-2020)
+            binf = os.path.join(harness.WORK, "fuzz_bin.json")
+            ids = [l.split(",")[0] for l in lines]
+            json.dump({sid: [int(x) for x in rng.integers(0, 2, 4)] for sid in ids[: max(1, len(ids) - 2)]}, open(binf, "w"))
+            conf["bin_imputation_in_file"] = "data/subjects/fuzz_bin.json"
+        if binf:
+            conf["_bin_src"] = binf
         got, glog, imp = harness.run_product(gname, conf, lines, tag="fz", em_mr=em, on_unsupported="skip")
+        if binf:
+            conf["_bin_src"] = binf
         exp, elog = harness.run_oracle(gname, conf, lines, tag="fz_orc", em_mr=em)
         skipped = [sid for _, sid, _ in imp.unsupported]
         exp2 = harness.drop_subjects(exp, skipped)
         bad = [k for k in exp2 if exp2[k] != got[k]]
-        print("round %3d %-4s thr=%-6d top=%-3d planb=%d out=%d em=%d n=%-3d unsupported=%d %s  [%.0fs]" % (
-            rd, gname, conf["number_of_options_threshold"], conf["max_haplotypes_number_in_phase"], conf["planb"], out, em, n,
+        print("round %3d %-4s thr=%-6d top=%-3d planb=%d out=%d em=%d bin=%d n=%-3d unsupported=%d %s  [%.0fs]" % (
+            rd, gname, conf["number_of_options_threshold"], conf["max_haplotypes_number_in_phase"], conf["planb"], out, em, bool(binf), n,
             len(skipped), "OK" if not bad else "DIFF " + str(bad), time.time() - t0), flush=True)
         if bad:
             os.makedirs(os.path.join(harness.ROOT, "gpurun_out"), exist_ok=True)
