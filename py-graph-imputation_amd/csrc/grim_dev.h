@@ -80,6 +80,7 @@ struct DevArgs {
   uint8_t *scratch;
   SlotLayout lay;
   uint32_t pair_cap, tab_cap, bset_cap, proj_cap;
+  uint32_t *small_ctr;           // half-wave kernel: per wave {probes, frequency vectors}, plain stores; summed on request
   unsigned long long *counters;  // [0] probes [1] nbr ids [2] freq vectors [3] rows [4] overflow flag
   uint32_t *bail_list;           // subjects the one-wave kernel hands to the general kernel (count: queue[5])
   uint32_t *next_list;           // subjects handed to the next kernel (plan B)

@@ -155,6 +155,8 @@ struct grim_batch {
   std::vector<void *> bufs;
   uint32_t n_subj, n_slots;
   SmallRec *small_recs;
+  uint32_t n_small_waves;
+  bool small_ctr_pending;  // the half-wave kernel's per-wave counts have not been added to `counters` yet
   unsigned long long *hstate;  // pinned: counters + work/row heads of the last run
   uint32_t *order_s, *order_g, *order_m;  // subjects of the half-wave / general / one-wave kernels
   uint32_t n_medium;
@@ -425,6 +427,9 @@ extern "C" grim_batch *grim_batch_upload(grim_ctx *c, const grim_graph *g, const
       r.si = os[k];
     }
     b->small_recs = upload(c, b->bufs, recs.data(), recs.size(), &bytes);
+    const uint32_t per_block = GRIM_WG / 32;
+    b->n_small_waves = ((b->n_small + per_block - 1) / per_block) * (GRIM_WG / 64);
+    A.small_ctr = upload<uint32_t>(c, b->bufs, nullptr, 2 * (size_t)b->n_small_waves + 2, &bytes);
   }
   b->order_s = upload(c, b->bufs, os.data(), os.size(), &bytes);
   b->order_g = upload(c, b->bufs, og.data(), og.size(), &bytes);
@@ -601,6 +606,7 @@ extern "C" int grim_batch_run(grim_batch *b) {
     memcpy(head, b->hstate + GRIM_NCTR, 32);
   }
   memcpy(b->counters, b->hstate, 64);
+  b->small_ctr_pending = b->n_small > 0;
   for (int sh = 0; sh < 64; ++sh)
     for (int k = 0; k < 3; ++k) b->counters[k] += b->hstate[8 + 4 * sh + k];
   b->rows_used = head[1];
@@ -624,8 +630,20 @@ extern "C" double grim_batch_kernel_ms(const grim_batch *b, int which) {
   return (double)b->ms_a + (double)b->ms_b;
 }
 
-extern "C" int grim_batch_counters(const grim_batch *b, uint64_t out[4]) {
-  if (!b) return -1;
+extern "C" int grim_batch_counters(const grim_batch *cb, uint64_t out[4]) {
+  if (!cb) return -1;
+  grim_batch *b = const_cast<grim_batch *>(cb);  // lazily folds the half-wave kernel's per-wave counts in
+  if (b->small_ctr_pending) {
+    grim_ctx *c = b->ctx;
+    hipSetDevice(c->device);
+    std::vector<uint32_t> h(2 * (size_t)b->n_small_waves);
+    HIPCHK(hipMemcpy(h.data(), b->a.small_ctr, 4 * h.size(), hipMemcpyDeviceToHost), c, -1);
+    for (size_t i = 0; i < h.size(); i += 2) {
+      b->counters[0] += h[i];
+      b->counters[2] += h[i + 1];
+    }
+    b->small_ctr_pending = false;
+  }
   out[0] = b->counters[0];
   out[1] = b->counters[1];
   out[2] = b->counters[2];

@@ -25,6 +25,24 @@ __device__ __forceinline__ uint32_t half_shfl_u(uint32_t v, int src_in_half) {
   return __shfl(v, (threadIdx.x & 32) | src_in_half);
 }
 
+// max over the 16 lanes of a DPP row (lanes 0-15 / 16-31 / 32-47 / 48-63), left in every lane of the row:
+// four row rotations, no LDS crossbar
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)((unsigned long long)b >> 32), CTRL, 0xF, 0xF, false);
+  return __longlong_as_double((long long)(((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo));
+}
+__device__ __forceinline__ double row16_max(double v) {
+  double o;
+  o = dpp_d<0x121>(v); v = o > v ? o : v;  // row_ror:1
+  o = dpp_d<0x122>(v); v = o > v ? o : v;  // row_ror:2
+  o = dpp_d<0x124>(v); v = o > v ? o : v;  // row_ror:4
+  o = dpp_d<0x128>(v); v = o > v ? o : v;  // row_ror:8
+  return v;
+}
+
 // what the library keeps in HBM per fast-path subject (built once in grim_batch_upload)
 struct SmallRec {
   uint16_t tok[2 * GRIM_MAXL];  // position l: side-1 allele, side-2 allele
@@ -81,66 +99,63 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_a_small_kernel(DevArgs A, c
   PairRef pr;
   pr.p1 = f; pr.p2 = f2; pr.m2 = f2;
   pr.e1 = same_hap ? 0u : 1u; pr.e2 = 0u;  // only equality of the two haplotypes matters below
-  // ---- ladder: first step that accepts any pair (impute.py:1665-1687) -------------------------
-  int best = A.prm.n_ladder;
-  if (pair_ok)
-    for (int idx = 0; idx < A.prm.n_ladder; ++idx)
-      if (pair_accept(A.prm.ladder[idx], pr, w_prior)) { best = idx; break; }
-  for (int d = 1; d < 16; d <<= 1) {
-    int o = __shfl_xor(best, d);
-    best = o < best ? o : best;
+  // ---- ladder: first step that accepts any pair (impute.py:1665-1687).  Acceptance is monotone in
+  // epsilon, so the subject's first step is the first at which ANY of its lanes accepts: the loop ends
+  // as soon as both halves have one (scalar ballots, no per-lane search to the lane's own first step).
+  const bool hi_half = (threadIdx.x & 32) != 0;
+  double eps = 0.0;
+  bool found = false;
+  {
+    const uint64_t okb = __ballot(pair_ok);
+    bool need_lo = (okb & 0xFFFFull) != 0, need_hi = ((okb >> 32) & 0xFFFFull) != 0;
+    bool got_lo = false, got_hi = false;
+    double eps_lo = 0.0, eps_hi = 0.0;
+    for (int idx = 0; idx < A.prm.n_ladder && (need_lo || need_hi); ++idx) {
+      const double e = A.prm.ladder[idx];
+      const uint64_t b = __ballot(pair_ok && pair_accept(e, pr, w_prior));
+      if (need_lo && (b & 0xFFFFull)) { need_lo = false; got_lo = true; eps_lo = e; }
+      if (need_hi && ((b >> 32) & 0xFFFFull)) { need_hi = false; got_hi = true; eps_hi = e; }
+    }
+    eps = hi_half ? eps_hi : eps_lo;
+    found = hi_half ? got_hi : got_lo;
   }
-  best = __shfl(best, threadIdx.x & 32);  // lanes 16..31 of the half did not take part
-  double eps = best < A.prm.n_ladder ? A.prm.ladder[best] : 0.0;
-  bool acc = pair_ok && best < A.prm.n_ladder && pair_accept(eps, pr, w_prior);
+  bool acc = pair_ok && found && pair_accept(eps, pr, w_prior);
   double prob = acc ? pair_prob(pr, w_prior) : 0.0;
-  double mx = prob;
-  for (int d = 1; d < 16; d <<= 1) {
-    double o = __shfl_xor(mx, d);
-    mx = o > mx ? o : mx;
-  }
-  mx = half_shfl_d(mx, 0);
-  if (best < A.prm.n_ladder && eps > 0.0) {
+  double mx = row16_max(prob);  // the 16 phase lanes of a half are one DPP row
+  if (found && eps > 0.0) {
     eps = mx / 100000.0;  // impute.py:1685, then the last round
     acc = pair_ok && pair_accept(eps, pr, w_prior);
     prob = acc ? pair_prob(pr, w_prior) : 0.0;
-    mx = prob;
-    for (int d = 1; d < 16; d <<= 1) {
-      double o = __shfl_xor(mx, d);
-      mx = o > mx ? o : mx;
-    }
-    mx = half_shfl_d(mx, 0);
+    mx = row16_max(prob);
   }
   const uint64_t bal = __ballot(acc);
-  const uint32_t accmask = (uint32_t)((threadIdx.x & 32) ? (bal >> 32) : bal) & 0xFFFFu;
+  const uint32_t accmask = (uint32_t)(hi_half ? (bal >> 32) : bal) & 0xFFFFu;
   const uint32_t nU = __popc(accmask);
-  // ---- sums in phase order; one genotype and one population cell hold every pair ----------------
+  // ---- sums in phase order; one genotype and one population cell hold every pair.  Stable ranking of
+  // the phased pairs: bigger first, earlier phase first on ties.  Only phases some half accepted are
+  // visited (1-4 of the 16, typically); their values come over v_readlane.
   double total = 0.0;
   bool first = true;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    double pi = half_shfl_d(prob, i);
+  uint32_t rank = 0;
+  for (uint32_t um = ((uint32_t)bal | (uint32_t)(bal >> 32)) & 0xFFFFu; um; um &= um - 1) {
+    const int i = __builtin_ctz(um);
+    const double p_lo = lane_get(prob, i), p_hi = lane_get(prob, 32 + i);
+    const double pi = hi_half ? p_hi : p_lo;
     if ((accmask >> i) & 1u) {
       total = first ? pi : total + pi;
       first = false;
+      if (pi > prob || (pi == prob && i < hl)) ++rank;
     }
   }
-  // stable ranking of the phased pairs: bigger first, earlier phase first on ties
-  uint32_t rank = 0;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    double pi = half_shfl_d(prob, i);
-    if (((accmask >> i) & 1u) && (pi > prob || (pi == prob && i < hl))) ++rank;
-  }
-  // algorithmic byte counters: 32 probes, one frequency vector per hit (sharded to dodge contention)
+  // algorithmic byte counters: 32 probes, one frequency vector per hit.  One plain store per wave into
+  // its own cell (atomics on shared cells serialised at the L2 and cost a third of the kernel).
   {
     // a kept phase looks up its two sides; combinations of dropped (duplicate) phases do not count
     const uint64_t need = __ballot(live && kept), needp = __ballot(live && kept && node != GRIM_NONE),
                    needq = __ballot(live && kept && node2 != GRIM_NONE);
-    if ((threadIdx.x & 63) == 0 && need) {
-      unsigned long long *c = A.counters + 8 + 4 * (blockIdx.x & 63);
-      atomicAdd(&c[0], 2ull * (unsigned long long)__popcll(need));
-      atomicAdd(&c[2], (unsigned long long)(__popcll(needp) + __popcll(needq)));
+    if ((threadIdx.x & 63) == 0) {
+      const uint32_t gw = blockIdx.x * (GRIM_WG / 64) + (threadIdx.x >> 6);
+      *(uint2 *)(A.small_ctr + 2 * gw) = make_uint2(2u * (uint32_t)__popcll(need), (uint32_t)(__popcll(needp) + __popcll(needq)));
     }
   }
   if (!live) return;
