@@ -73,6 +73,23 @@ grim_graph *grim_graph_upload(grim_ctx *ctx, const grim_graph_desc *desc);
 void grim_graph_free(grim_graph *g);
 uint64_t grim_graph_device_bytes(const grim_graph *g);
 
+/* ---- graph, host side (C++, no GPU) ------------------------------------------------------
+ * grim_hostgraph_load_csv: nodes.csv / top_links.csv / edges.csv -> the arrays above, i.e. all of
+ *   Graph.build_graph (networkx_graph.py:42-213; argument order nodes, top links, all edges as at
+ *   :42); alleles are interned into `dict` in file order.  NULL + message in err on failure.
+ * grim_graphgen_csv: hpf.csv -> the four graph CSVs, i.e. generate_graph
+ *   (graph_generation/generate_neo4j_multi_hpf.py:209-486); cutoff[p] = freq_trim_threshold /
+ *   population count as computed at :251-262; locus_names/locus_index = the conf's loci_map. */
+typedef struct grim_hostgraph grim_hostgraph;
+typedef struct grim_dict grim_dict;     /* per locus slot: allele string <-> dense id (see the host helpers below) */
+grim_hostgraph *grim_hostgraph_load_csv(grim_dict *dict, const char *full_loci, const char *nodes_csv, const char *top_links_csv,
+                                        const char *edges_csv, char *err, uint64_t err_cap);
+int grim_hostgraph_desc(const grim_hostgraph *h, grim_graph_desc *out);
+void grim_hostgraph_free(grim_hostgraph *h);
+int grim_graphgen_csv(const char *hpf_csv, const char *const *pops, const double *cutoff, uint32_t n_pops,
+                      const char *const *locus_names, const uint32_t *locus_index, uint32_t n_locus_names, const char *nodes_csv,
+                      const char *edges_csv, const char *top_links_csv, const char *info_csv, char *err, uint64_t err_cap);
+
 /* ---- run parameters: the conf keys of run_impute_def.py:63-129 that reach the hot path ------ */
 typedef struct {
   double ladder[GRIM_MAXLADDER]; /* eps values tried in order (impute.py:1665-1673), host-computed */
@@ -175,7 +192,6 @@ void grim_batch_free(grim_batch *b);
  * for whole files at a time, the reference's per-line Python: impute_file's line handling
  * (impute.py:2022-2036), clean_up_gl (:105-118), gl2haps (:246-272), the writers' text and the
  * .miss/.problem rules (:24-99, 2061-2118) including CPython's str(float). */
-typedef struct grim_dict grim_dict;     /* per locus slot: allele string <-> dense id */
 typedef struct grim_parsed grim_parsed; /* a tokenised block of input lines           */
 typedef struct grim_text grim_text;     /* the six output texts                       */
 

@@ -22,18 +22,7 @@
 
 #include "../../include/grim_hip.h"
 
-using sv = std::string_view;
-
-// ------------------------------------------------------------------------------------------------
-// allele dictionary: per locus slot, allele string <-> dense id
-// ------------------------------------------------------------------------------------------------
-struct grim_dict {
-  uint32_t n_loci;
-  std::vector<std::string> locus_name;
-  std::unordered_map<std::string, uint32_t> locus_slot;
-  std::vector<std::unordered_map<std::string, uint32_t>> ids;
-  std::vector<std::vector<std::string>> names;
-};
+#include "grim_host_internal.h"
 
 extern "C" grim_dict *grim_dict_create(uint32_t n_loci) {
   if (n_loci == 0 || n_loci > GRIM_MAXL) return nullptr;
@@ -54,7 +43,7 @@ extern "C" int grim_dict_set_locus(grim_dict *d, uint32_t slot, const char *name
   return 0;
 }
 
-static int32_t dict_intern(grim_dict *d, uint32_t slot, sv a) {
+int32_t dict_intern(grim_dict *d, uint32_t slot, sv a) {
   auto &m = d->ids[slot];
   std::string key(a);
   auto it = m.find(key);
@@ -407,7 +396,7 @@ extern "C" const char *grim_parsed_id(const grim_parsed *p, uint32_t i, uint32_t
 // formatter
 // ------------------------------------------------------------------------------------------------
 // str(float) of CPython (repr style 'r': shortest digits; exponent form when exp10 < -4 or >= 16)
-static void py_float(double x, std::string &out) {
+void py_float(double x, std::string &out) {
   if (x == 0.0) {
     out += (std::signbit(x) ? "-0.0" : "0.0");
     return;

@@ -47,7 +47,7 @@ def _num(x):
 
 
 def generate_graph(config_file="../conf/minimal-configuration-script.json", em_pop=None, em=False,
-                   use_default_path=False, quiet=False):
+                   use_default_path=False, quiet=False, python_twin=False):
     base = ""
     if use_default_path:
         base = os.path.dirname(os.path.realpath(__file__)) + "/"
@@ -85,6 +85,14 @@ def generate_graph(config_file="../conf/minimal-configuration-script.json", em_p
         print(bar)
 
     locus_index = dict(conf.get("loci_map"))
+    if not python_twin:
+        # the library's C++ generator (grim_graphgen_csv): same four files, byte for byte
+        from grim import _native as nat
+
+        nat.graphgen_csv(freq_file, pops, [cutoff[p] for p in pops], locus_index, csvdir + conf.get("node_csv_file"),
+                         csvdir + conf.get("edges_csv_file"), csvdir + conf.get("top_links_csv_file"),
+                         csvdir + conf.get("info_node_csv_file"))
+        return
     full = "".join(sorted({str(v) for v in locus_index.values()}))
     nloc = len(full)
     labels = _label_list(full)

@@ -289,7 +289,7 @@ EXPORTS += [
     "grim_dict_count", "grim_tokenize", "grim_parsed_free", "grim_parsed_lines", "grim_parsed_subjects",
     "grim_parsed_subject_array", "grim_parsed_tokens", "grim_parsed_kinds", "grim_parsed_dev_index",
     "grim_parsed_n_races", "grim_parsed_race", "grim_parsed_id", "grim_parsed_set_kind", "grim_parsed_set_flags", "grim_format", "grim_text_get", "grim_text_free",
-    "grim_format_double",
+    "grim_format_double", "grim_hostgraph_load_csv", "grim_hostgraph_desc", "grim_hostgraph_free", "grim_graphgen_csv",
 ]
 
 _host_ready = False
@@ -343,6 +343,15 @@ def host_lib():
     L.grim_text_free.argtypes = [C.c_void_p]
     L.grim_format_double.restype = C.c_int
     L.grim_format_double.argtypes = [C.c_double, C.c_char_p, C.c_int]
+    L.grim_hostgraph_load_csv.restype = C.c_void_p
+    L.grim_hostgraph_load_csv.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint64]
+    L.grim_hostgraph_desc.restype = C.c_int
+    L.grim_hostgraph_desc.argtypes = [C.c_void_p, C.POINTER(GraphDesc)]
+    L.grim_hostgraph_free.argtypes = [C.c_void_p]
+    L.grim_graphgen_csv.restype = C.c_int
+    L.grim_graphgen_csv.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.c_uint32, C.POINTER(C.c_char_p),
+                                    C.POINTER(C.c_uint32), C.c_uint32, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p,
+                                    C.c_char_p, C.c_uint64]
     _host_ready = True
     return L
 
@@ -476,3 +485,55 @@ def format_double(x):
     buf = C.create_string_buffer(48)
     n = host_lib().grim_format_double(float(x), buf, 48)
     return buf.value[:n].decode()
+
+
+def load_graph_csv(adict, full_loci, nodes_csv, top_links_csv, edges_csv):
+    """grim_hostgraph_load_csv: the three graph CSVs -> dict of numpy arrays (same keys as the Python loader
+    builds; the arrays are copies, the C object is freed before returning)."""
+    L = host_lib()
+    err = C.create_string_buffer(512)
+    h = L.grim_hostgraph_load_csv(adict.h, full_loci.encode(), os.fsencode(nodes_csv), os.fsencode(top_links_csv),
+                                  os.fsencode(edges_csv), err, len(err))
+    if not h:
+        msg = err.value.decode()
+        if msg.startswith("graph: the highest-numbered vertex"):
+            raise IndexError(msg)
+        raise ValueError(msg)
+    try:
+        d = GraphDesc()
+        L.grim_hostgraph_desc(h, C.byref(d))
+
+        def arr(ptr, dtype, n):
+            if n == 0:
+                return np.zeros(0, dtype=dtype)
+            buf = (C.c_char * (int(n) * np.dtype(dtype).itemsize)).from_address(ptr)
+            return np.frombuffer(buf, dtype=dtype, count=int(n)).copy()
+
+        V, P = int(d.n_nodes), int(d.n_pops)
+        return {
+            "n_nodes": V, "n_pops": P, "n_loci": int(d.n_loci), "full_mask": int(d.full_mask),
+            "node_key": arr(d.node_key, np.uint64, V), "node_mask": arr(d.node_mask, np.uint8, V),
+            "freq": arr(d.freq, np.float64, V * P).reshape(V, P),
+            "a_start": arr(d.a_start, np.uint32, V + 1), "a_nbr": arr(d.a_nbr, np.uint32, d.n_a_nbr),
+            "b_conn": arr(d.b_conn, np.uint32, V * MAXL), "b_start": arr(d.b_start, np.uint32, int(d.n_conn) + 1),
+            "b_nbr": arr(d.b_nbr, np.uint32, d.n_b_nbr),
+            "lab_start": arr(d.lab_start, np.uint32, (1 << MAXL) + 1), "lab_nodes": arr(d.lab_nodes, np.uint32, V),
+        }
+    finally:
+        L.grim_hostgraph_free(h)
+
+
+def graphgen_csv(hpf_csv, pops, cutoffs, loci_map, nodes_csv, edges_csv, top_links_csv, info_csv):
+    """grim_graphgen_csv: hpf.csv -> nodes.csv, edges.csv, top_links.csv, info_node.csv."""
+    L = host_lib()
+    err = C.create_string_buffer(512)
+    pop_arr = (C.c_char_p * len(pops))(*[p.encode() for p in pops])
+    cut_arr = (C.c_double * len(pops))(*[float(c) for c in cutoffs])
+    names = list(loci_map.keys())
+    name_arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+    idx_arr = (C.c_uint32 * len(names))(*[int(loci_map[n]) for n in names])
+    rc = L.grim_graphgen_csv(os.fsencode(hpf_csv), pop_arr, cut_arr, len(pops), name_arr, idx_arr, len(names),
+                             os.fsencode(nodes_csv), os.fsencode(edges_csv), os.fsencode(top_links_csv), os.fsencode(info_csv),
+                             err, len(err))
+    if rc != 0:
+        raise ValueError(err.value.decode())

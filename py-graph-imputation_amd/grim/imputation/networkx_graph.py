@@ -90,7 +90,15 @@ class Graph(object):
     # ------------------------------------------------------------------------------------------
     def build_graph(self, nodesFile, edgesFile, allEdgesFile):
         """nodesFile = nodes.csv, edgesFile = top_links.csv, allEdgesFile = edges.csv
-        (argument names as in networkx_graph.py:42)."""
+        (argument names as in networkx_graph.py:42).  Parsed and indexed by the library's C++ loader
+        (grim_hostgraph_load_csv); `_build_graph_python` is the same thing in numpy, kept as the
+        cross-check in tests/."""
+        self.arrays = nat.load_graph_csv(self.adict, self.full_loci, nodesFile, edgesFile, allEdgesFile)
+        self.n_graph_alleles = [self.adict.count(s) for s in range(len(self.full_loci))]
+        self._dev = {}
+        return self
+
+    def _build_graph_python(self, nodesFile, edgesFile, allEdgesFile):
         nl = len(self.full_loci)
         ids, keys, masks, freqs = [], [], [], []
         id_to_row = {}

@@ -31,3 +31,98 @@ def test_generated_csv_identical_to_reference(name):
     assert got == info["md5"]
     assert open(os.path.join(work, "output", "pop_counts_file.txt")).read() == open(
         os.path.join(harness.GOLD, "graphs", name, "pop_counts_file.txt")).read()
+
+
+def _gen_both(work, conf, tmp_path):
+    """generate_graph through the library's C++ generator and through the Python twin -> two dirs of CSVs"""
+    from graph_generation.generate_neo4j_multi_hpf import generate_graph
+
+    out = {}
+    cwd = os.getcwd()
+    os.chdir(work)
+    try:
+        for tag, twin in (("cpp", False), ("py", True)):
+            c = dict(conf, graph_files_path=str(tmp_path / tag) + "/")
+            cpath = str(tmp_path / (tag + ".json"))
+            json.dump(c, open(cpath, "w"))
+            generate_graph(cpath, quiet=True, python_twin=twin)
+            out[tag] = str(tmp_path / tag)
+    finally:
+        os.chdir(cwd)
+    return out
+
+
+def _load_both(conf_path, csvdir):
+    import numpy as np
+    from grim.imputation.networkx_graph import Graph
+    from grim.run_impute_def import load_config
+
+    cfg, _ = load_config(conf_path)
+    files = [os.path.join(csvdir, f) for f in ("nodes.csv", "top_links.csv", "edges.csv")]
+    a = Graph(cfg).build_graph(*files).arrays
+    b = Graph(cfg)._build_graph_python(*files).arrays
+    assert set(a) == set(b)
+    for k in b:
+        if isinstance(b[k], np.ndarray):
+            assert a[k].dtype == b[k].dtype and np.array_equal(a[k], b[k]), k
+        else:
+            assert a[k] == b[k], k
+
+
+@pytest.mark.parametrize("name", ["cau", "pop4"])
+def test_cpp_generator_and_loader_equal_python_twins(name, tmp_path):
+    work = harness.ensure_graph(name)
+    conf = json.load(open(os.path.join(work, "graph_conf.json")))
+    dirs = _gen_both(work, conf, tmp_path)
+    info = json.load(open(os.path.join(harness.GOLD, "graphs", name, "graph_info.json")))["md5"]
+    for f in ("nodes.csv", "edges.csv", "top_links.csv", "info_node.csv"):
+        assert open(os.path.join(dirs["cpp"], f), "rb").read() == open(os.path.join(dirs["py"], f), "rb").read(), f
+    for f in ("nodes.csv", "edges.csv", "info_node.csv"):  # and both equal the reference's own files
+        assert _md5(os.path.join(dirs["cpp"], f)) == info[f]
+    assert _md5(os.path.join(dirs["cpp"], "top_links.csv"), True) == info["top_links.csv(sorted rows)"]
+    _load_both(os.path.join(work, "graph_conf.json"), dirs["cpp"])
+
+
+def test_cpp_generator_odd_rows(tmp_path):
+    """rows below the cutoff, zero frequencies, a repeated (haplotype, population) row, 'g' suffixes, a population
+    a haplotype never appears in (the integer 0 of the reference's running sums) -- C++ and Python twin agree"""
+    work = tmp_path / "w"
+    (work / "output").mkdir(parents=True)
+    rows = [
+        "hap,pop,freq",
+        "A*01:01g~B*08:01g~C*07:01g~DQB1*02:01~DRB1*03:01,CAU,0.05",
+        "A*01:01g~B*08:01g~C*07:01g~DQB1*02:01~DRB1*03:01,AFA,0.0125",
+        "A*02:01~B*07:02~C*07:02~DQB1*06:02~DRB1*15:01,CAU,0.03",
+        "A*02:01~B*07:02~C*07:02~DQB1*06:02~DRB1*15:01,CAU,0.031",      # repeated: the later value wins
+        "A*03:01~B*07:02~C*07:02~DQB1*06:02~DRB1*15:01,AFA,1e-09",       # below the cutoff
+        "A*03:01~B*35:01~C*04:01~DQB1*03:01~DRB1*01:01,AFA,0.0",         # zero
+        "A*02:01~B*44:02~C*05:01~DQB1*03:01~DRB1*04:01,AFA,7.25e-05",
+        "A*02:01~B*44:02~C*05:01~DQB1*03:01~DRB1*04:01,HIS,0.00019999999999999998",
+        "A*24:02~B*07:02~C*07:02~DQB1*06:02~DRB1*15:01,HIS,3.3333333333333335e-05",
+    ]
+    (work / "output" / "hpf.csv").write_text("\n".join(rows) + "\n")
+    (work / "output" / "pop_counts_file.txt").write_text("CAU,100,0.5\nAFA,50,0.25\nHIS,50,0.25\n")
+    conf = harness.base_conf(["CAU", "AFA", "HIS"])
+    dirs = _gen_both(str(work), conf, tmp_path)
+    for f in ("nodes.csv", "edges.csv", "top_links.csv", "info_node.csv"):
+        assert open(os.path.join(dirs["cpp"], f), "rb").read() == open(os.path.join(dirs["py"], f), "rb").read(), f
+    nodes = open(os.path.join(dirs["cpp"], "nodes.csv")).read()
+    assert ";0;" in nodes or ",0;" in nodes  # an untouched integer 0 is printed as "0", not "0.0"
+    cpath = str(tmp_path / "cpp.json")
+    cwd = os.getcwd()
+    os.chdir(str(work))
+    try:
+        _load_both(cpath, dirs["cpp"])
+    finally:
+        os.chdir(cwd)
+
+
+def test_cpp_generator_reports_errors(tmp_path):
+    from grim import _native as nat
+
+    with pytest.raises(ValueError):
+        nat.graphgen_csv(str(tmp_path / "missing.csv"), ["CAU"], [1e-5], {"A": 1, "B": 2}, *[str(tmp_path / f) for f in "abcd"])
+    bad = tmp_path / "hpf.csv"
+    bad.write_text("hap,pop,freq\nA*01:01~B*08:01,XXX,0.1\n")
+    with pytest.raises(ValueError):  # the reference dies with KeyError on a population it was not configured for
+        nat.graphgen_csv(str(bad), ["CAU"], [1e-5], {"A": 1, "B": 2}, *[str(tmp_path / f) for f in "abcd"])
