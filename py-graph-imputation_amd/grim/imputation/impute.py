@@ -353,6 +353,73 @@ class Imputation(object):
         return subject_id, res_m, res_h
 
     # ---- file driver (impute.py:1985-2155) ---------------------------------------------------------------
+    # ---- EM hook of the sibling EM package (impute.py:305-351): pure string work on the host ------------
+    @staticmethod
+    def gl2haps(GL_String):
+        """impute.py:246-272: {"Genotype": [sorted side-1 entries, sorted side-2 entries], "N_Loc": n}, or []."""
+        if GL_String in ("", " "):
+            return []
+        first, second, n_loci = [], [], 0
+        for locus in GL_String.split("^"):
+            if locus[0] == "+":  # an empty entry raises IndexError here, as in the reference
+                locus = locus[1:]
+            halves = locus.split("+")
+            if len(halves) == 1:
+                if halves[0] == "":
+                    continue
+                return []
+            first.append(halves[0])
+            second.append(halves[1])
+            n_loci += 1
+        return {"Genotype": [sorted(first), sorted(second)], "N_Loc": n_loci}
+
+    @staticmethod
+    def gen_phases(gen, n_loci, b_phases=None):
+        """impute.py:274-303: the <= 2^(n-1) phases [H1, H2], mirror images and repeats dropped."""
+        free = None if b_phases is None else {k for k, bit in enumerate(b_phases) if bit == 1}
+        phases, seen = [], set()
+        for code in range(1 << (n_loci - 1)):
+            side = [(code >> k) & 1 if (free is None or k in free) else 0 for k in range(n_loci)]
+            h1 = [gen[side[k]][k] for k in range(n_loci)]
+            h2 = [gen[1 - side[k]][k] for k in range(n_loci)]
+            a, b = "~".join(h1), "~".join(h2)
+            if (a + "^" + b) not in seen or (b + "^" + a) not in seen:
+                seen.update((a + "^" + b, b + "^" + a))
+                phases.append([h1, h2])
+        return phases
+
+    @staticmethod
+    def open_phases_for_em(haps, N_Loc, cutoff):
+        """impute.py:322-351: per phase [[haplotypes of side 1], [haplotypes of side 2]] with every '/'
+        ambiguity expanded (position 0 most significant); a phase with a side of >= cutoff options is dropped."""
+        import itertools
+
+        out = []
+        for phase in haps:
+            sides = []
+            for entries in phase[:2]:
+                alts = [tuple(e.split("/")) for e in entries]
+                options = 1
+                for i in range(N_Loc):
+                    options *= len(alts[i])
+                if options < cutoff:
+                    sides.append([[list(c) for c in itertools.product(*alts[:N_Loc])]])
+                else:
+                    sides.append([])
+            if sides[0] and sides[1]:
+                out.append(sides)
+        return out
+
+    def open_gl_string(self, gl_string, cutoff):
+        """impute.py:305-320."""
+        chrom = self.gl2haps(gl_string)
+        if chrom == []:
+            return None
+        phases = self.gen_phases(chrom["Genotype"], chrom["N_Loc"], None)
+        if phases == []:
+            return None
+        return self.open_phases_for_em(phases, chrom["N_Loc"], cutoff)
+
     def impute_file(self, config, planb=None, em_mr=False, em=False):
         with open(config["imputation_input_file"], "r") as fh:
             lines = fh.readlines()

@@ -162,3 +162,17 @@ def test_product_fails_loudly_without_gpu(graphs):
     imp = Imputation(g, cfg)
     with pytest.raises(_native.NativeError):
         imp.impute_one("S", "A*01:01+A*02:01", [1, 1, 1, 1], "CAU", "CAU", cfg["priority"], 1e-3, 1000, True, True, True, False)
+
+
+def test_open_gl_string_hook_equals_reference_vectors():
+    """Imputation.open_gl_string (the EM package's hook, impute.py:305-351) against vectors taken from the
+    reference (tests/golden/open_gl_string.json; made by calling the reference's method on these inputs)."""
+    from grim.imputation.impute import Imputation
+
+    imp = Imputation.__new__(Imputation)
+    for case in json.load(open(os.path.join(harness.GOLD, "open_gl_string.json"))):
+        try:
+            got = ["ok", imp.open_gl_string(case["gl"], case["cutoff"])]
+        except Exception as e:  # the reference raises IndexError on an empty locus entry
+            got = ["exc", type(e).__name__]
+        assert got == case["result"], case["gl"]

@@ -193,9 +193,39 @@ def run_scenario(name, work, pops, lines, overrides=None, hap_pop_pair=False, bi
         name, len(lines), sum(1 for _ in open(os.path.join(out, "don.umug"))) if os.path.exists(os.path.join(out, "don.umug")) else -1))
 
 
+OPEN_GL_CASES = [
+    "A*01:01/A*02:01+A*03:01^B*07:02+B*08:01/B*44:02/B*15:01^C*07:01+C*07:02",
+    "A*01:01+A*01:01^B*08:01+B*08:01", "A*01:01+A*02:01^^B*08:01+B*07:02", "A*01:01+A*02:01^+^B*08:01+B*07:02",
+    "A*01:01+A*02:01", "", " ", "A*01:01", "+A*01:01+A*02:01^B*08:01+B*07:02",
+    "A*02:01/A*02:02/A*02:03+A*01:01/A*01:02^B*07:02/B*07:03+B*08:01^C*07:01/C*07:02/C*07:04+C*04:01"
+    "^DQB1*02:01+DQB1*03:01/DQB1*03:02^DRB1*03:01+DRB1*04:01",
+]
+
+
+def open_gl_vectors():
+    """tests/golden/open_gl_string.json: the reference's Imputation.open_gl_string (the EM hook) on a few GL strings."""
+    from grim.imputation.impute import Imputation
+
+    ref = Imputation.__new__(Imputation)  # the method only uses string helpers
+    out = []
+    for gl in OPEN_GL_CASES:
+        for cutoff in (1, 4, 20, 1000):
+            try:
+                res = ["ok", ref.open_gl_string(gl, cutoff)]
+            except Exception as e:
+                res = ["exc", type(e).__name__]
+            out.append({"gl": gl, "cutoff": cutoff, "result": res})
+    with open(os.path.join(GOLD, "open_gl_string.json"), "w") as fh:
+        json.dump(out, fh, indent=0)
+
+
 def main():
     os.environ.setdefault("PYTHONHASHSEED", "0")
     prepare_reference()
+    if not os.environ.get("GOLDEN_ONLY") or "open_gl_string" in os.environ["GOLDEN_ONLY"].split(","):
+        open_gl_vectors()
+    if os.environ.get("GOLDEN_ONLY") == "open_gl_string":
+        return
     # ---- data files -----------------------------------------------------------------
     fdir = os.path.join(GOLD, "data", "freqs")
     os.makedirs(fdir, exist_ok=True)
