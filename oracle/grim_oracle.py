@@ -827,18 +827,19 @@ class OracleImputer:
                 self.prior = saved
             if haps_out:
                 res_h = self._ladder(eps, phases, False, planb)
-                if planb and len(res_h["Haps"]) == 0:
+                if planb and len(res_h["Haps"]) == 0 and not getattr(self, "em", False):  # impute.py:1649
                     self._reduce_common(pmags, n_loci, 1, True)
                     phases = self._open(pmags, n_loci)
                     res_h = self._plan_c(phases, False)
         return res_m, res_h
 
     # ---- file driver (impute.py:1985-2155) and writers (impute.py:24-99) ---------------------
-    def impute_lines(self, lines, em_mr=False):
+    def impute_lines(self, lines, em_mr=False, em=False):
         """Returns dict of the six output texts keyed 'umug','umug_pops','pmug','pmug_pops',
         'miss','problem'.  self.log collects the per-subject stdout lines."""
         cfg = self.cfg
         out = {k: [] for k in ("umug", "umug_pops", "pmug", "pmug_pops", "miss", "problem")}
+        self.em = em  # impute_file(em=True), impute.py:1985
         n_res, n_pop = cfg["number_of_results"], cfg["number_of_pop_results"]
         sid = None
         f_bin = None

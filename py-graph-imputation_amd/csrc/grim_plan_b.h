@@ -726,6 +726,8 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_b_kernel(DevArgs A) {
     if (nU) {
       emit_tables(A, sh, S, nU, sh.out, 3);
       status = GRIM_ST_OK;
+    } else if (!A.prm.out_muug && A.prm.em) {
+      // impute_file(em=True): the phased pass stops after Plan B (impute.py:1649); nothing was found
     } else {
       // ---- Plan C (impute.py:1637-1643 / 1649-1654): lists reduced to their most common allele under the
       // all-ones prior level 1 left behind; every phase opens again
@@ -755,7 +757,7 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_b_kernel(DevArgs A) {
             plan_haps = 'b';
             nH = pb_levels(A, sh, S, wt, st, tok, &mx2);
           }
-          if (!nH) {
+          if (!nH && !A.prm.em) {
             plan_haps = 'c';
             nH = pb_plan_c(A, sh, S, wt, tok, &mx2);
           }

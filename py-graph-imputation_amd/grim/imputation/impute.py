@@ -211,7 +211,7 @@ class Imputation(object):
         return _DEV, (n, slots, same, pos)
 
     # ---- parameters ---------------------------------------------------------------------------------
-    def _params(self, config, planb, em_mr):
+    def _params(self, config, planb, em_mr, em=False):
         p = nat.Params()
         eps = config["epsilon"]
         ladder = []
@@ -234,6 +234,7 @@ class Imputation(object):
         p.out_muug = 1 if config["output_MUUG"] else 0
         p.out_haps = 1 if config["output_haplotypes"] else 0
         p.planb = 1 if planb else 0
+        p.em = 1 if em else 0
         p.em_mr = 1 if em_mr else 0
         order = sorted(range(len(self.populations)), key=lambda i: self.populations[i])
         for rank, i in enumerate(order):
@@ -256,7 +257,7 @@ class Imputation(object):
         return p
 
     # ---- batch on the device --------------------------------------------------------------------------
-    def run_batch(self, records, config, planb, em_mr=False, keep=False):
+    def run_batch(self, records, config, planb, em_mr=False, keep=False, em=False):
         """records: list of (n_loci, slots, same_mask, positions, prior_idx).  Returns (res, rows)."""
         n = len(records)
         subj = np.zeros(n, dtype=nat.SUBJECT_DT)
@@ -280,7 +281,7 @@ class Imputation(object):
         priors = np.stack(self._priors) if self._priors else np.ones((1, len(self.populations), len(self.populations)))
         ctx = nat.default_context(self.device)
         dgraph = self.netGraph.device(ctx)
-        params = self._params(config, planb, em_mr)
+        params = self._params(config, planb, em_mr, em)
         tu = timeit.default_timer()
         batch = nat.DeviceBatch(ctx, dgraph, params, subj, tokens, priors)
         t0 = timeit.default_timer()
@@ -331,7 +332,7 @@ class Imputation(object):
         if kind == _MISS_NO_DEVICE:
             return subject_id, res_m, res_h
         pidx = self._prior_index(race1 or "", race2 or "", priority)
-        res, rows = self.run_batch([payload + (pidx,)], cfg, planb)
+        res, rows = self.run_batch([payload + (pidx,)], cfg, planb, em=em)
         r = res[0]
         if r["status"] == nat.ST_UNSUPPORTED:
             raise UnsupportedSubjects([(0, subject_id, int(r["reason"]))])
@@ -423,7 +424,7 @@ class Imputation(object):
     def impute_file(self, config, planb=None, em_mr=False, em=False):
         with open(config["imputation_input_file"], "r") as fh:
             lines = fh.readlines()
-        texts = self.impute_lines(lines, config, planb=planb, em_mr=em_mr)
+        texts = self.impute_lines(lines, config, planb=planb, em_mr=em_mr, em=em)
         self.write_outputs(config, texts)
 
     @staticmethod
@@ -439,7 +440,7 @@ class Imputation(object):
             with open(config[path_key], "w") as fh:
                 fh.write(texts[key])
 
-    def impute_lines(self, lines, config, planb=None, em_mr=False, line_offset=0):
+    def impute_lines(self, lines, config, planb=None, em_mr=False, line_offset=0, em=False):
         """The body of impute_file on a list of input lines.  Returns the six output texts keyed
         'umug','umug_pops','pmug','pmug_pops','miss','problem'.  `line_offset` is the global index
         of lines[0] (multi-GPU shards keep the reference's line numbers in .miss/.problem).
@@ -490,7 +491,7 @@ class Imputation(object):
             subj = parsed.subjects()
             kinds = parsed.kinds()
             dev = parsed.dev_index()
-            params = self._params(config, planb, em_mr)
+            params = self._params(config, planb, em_mr, em)
             start = timeit.default_timer()
             if len(subj):
                 res, rows = self._run_arrays(subj, parsed.tokens(), priors, params)
@@ -566,7 +567,7 @@ class Imputation(object):
                     index=i, id=sid, hap_length=int(r["n_genotypes"]) if r is not None else 0))
             print(per_subject)
 
-    def impute_lines_python(self, lines, config, planb=None, em_mr=False, line_offset=0):
+    def impute_lines_python(self, lines, config, planb=None, em_mr=False, line_offset=0, em=False):
         """The same in pure Python host code (tokeniser `_tokenise`, formatter `_write_rows`): kept as
         the cross-check of the C++ host helpers in tests/ and as documentation of their rules."""
         priority = config["priority"]
@@ -600,7 +601,7 @@ class Imputation(object):
                 outcome.append((_PROBLEM_RAW, sid, line, -1))
 
         if records:
-            res, rows = self.run_batch(records, config, planb, em_mr)
+            res, rows = self.run_batch(records, config, planb, em_mr, em=em)
         else:
             res, rows = np.zeros(0, dtype=nat.RESULT_DT), np.zeros(0, dtype=nat.ROW_DT)
 

@@ -63,6 +63,7 @@ def _write_inputs(work, conf, lines, tag):
     if conf.get("bin_imputation_in_file") and "_bin_src" in conf:
         shutil.copy(conf.pop("_bin_src"), os.path.join(work, conf["bin_imputation_in_file"]))
     conf.pop("_bin_src", None)
+    conf.pop("_em", None)
     conf["imputation_in_file"] = "data/subjects/%s.csv" % tag
     conf["imputation_out_path"] = "output_" + tag
     with open(os.path.join(work, conf["imputation_in_file"]), "w") as fh:
@@ -95,6 +96,7 @@ def run_product(graph_name, conf, lines, tag="prod", em_mr=False, on_unsupported
     from grim.run_impute_def import load_config
 
     work = ensure_graph(graph_name)
+    em = bool(conf.get("_em"))  # impute_file(em=True)
     conf, cpath = _write_inputs(work, conf, lines, tag)
     cwd = os.getcwd()
     os.chdir(work)
@@ -110,7 +112,7 @@ def run_product(graph_name, conf, lines, tag="prod", em_mr=False, on_unsupported
         os.makedirs(out_dir, exist_ok=True)
         buf = io.StringIO()
         with contextlib.redirect_stdout(buf):
-            imp.impute_file(cfg, em_mr=em_mr)
+            imp.impute_file(cfg, em_mr=em_mr, em=em)
     finally:
         os.chdir(cwd)
     log = [l for l in buf.getvalue().splitlines() if "Subject:" in l]
@@ -125,6 +127,7 @@ def run_oracle(graph_name, conf, lines, tag="orc", em_mr=False):
     import grim_oracle as go
 
     work = ensure_graph(graph_name)
+    em = bool(conf.get("_em"))
     conf, cpath = _write_inputs(work, conf, lines, tag)
     cwd = os.getcwd()
     os.chdir(work)
@@ -135,7 +138,7 @@ def run_oracle(graph_name, conf, lines, tag="orc", em_mr=False):
             g = go.OGraph(cfg["full_loci"]).load(cfg["node_file"], cfg["top_links_file"], cfg["edges_file"])
             _ograph_cache[graph_name] = g
         imp = go.OracleImputer(g, cfg)
-        texts = imp.impute_lines(lines, em_mr=em_mr)
+        texts = imp.impute_lines(lines, em_mr=em_mr, em=em)
     finally:
         os.chdir(cwd)
     return texts, list(imp.log)
@@ -152,6 +155,8 @@ def golden(scenario):
         p = os.path.join(d, f)
         exp[k] = open(p).read() if os.path.exists(p) else ""
     log = [l for l in open(os.path.join(d, "log.txt")).read().splitlines() if "Subject:" in l]
+    if meta.get("em"):
+        conf["_em"] = True
     if os.path.exists(os.path.join(d, "bin.json")):
         conf["_bin_src"] = os.path.join(d, "bin.json")
     return meta["graph"], conf, lines, exp, log, meta["hap_pop_pair"]

@@ -145,7 +145,7 @@ def build_graph(name, pops):
     return work
 
 
-def run_scenario(name, work, pops, lines, overrides=None, hap_pop_pair=False, bin_masks=None):
+def run_scenario(name, work, pops, lines, overrides=None, hap_pop_pair=False, bin_masks=None, em=False):
     only = os.environ.get("GOLDEN_ONLY")  # comma-separated scenario names: regenerate just those
     if only and name not in only.split(","):
         return
@@ -169,8 +169,16 @@ def run_scenario(name, work, pops, lines, overrides=None, hap_pop_pair=False, bi
     os.chdir(work)
     buf = io.StringIO()
     try:
-        with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()):
-            grim.impute("conf.json", hap_pop_pair=hap_pop_pair)
+        from grim.imputation.impute import Imputation as _RefImputation
+
+        orig = _RefImputation.impute_file
+        if em:  # impute_file(em=True) is only reachable by calling the method; route grim.impute's call to it
+            _RefImputation.impute_file = lambda self, config, planb=None, em_mr=False, em=False: orig(self, config, planb, em_mr, True)
+        try:
+            with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()):
+                grim.impute("conf.json", hap_pop_pair=hap_pop_pair)
+        finally:
+            _RefImputation.impute_file = orig
     finally:
         os.chdir(cwd)
     out = os.path.join(GOLD, name)
@@ -187,6 +195,8 @@ def run_scenario(name, work, pops, lines, overrides=None, hap_pop_pair=False, bi
     with open(os.path.join(out, "log.txt"), "w") as fh:
         fh.write("\n".join(log) + "\n")
     meta = {"graph": os.path.basename(work), "hap_pop_pair": hap_pop_pair, "n_subjects": len(lines)}
+    if em:
+        meta["em"] = True
     with open(os.path.join(out, "meta.json"), "w") as fh:
         json.dump(meta, fh)
     print("scenario %-18s %5d subjects  umug=%d rows" % (
@@ -288,6 +298,8 @@ def main():
                   "priority": {"alpha": 0.128, "eta": 0.09, "beta": 0.168, "gamma": 0.165, "delta": 0.667}, "epsilon": 1e-7}
     run_scenario("pop4_planc_rerun", w4, POP4, rerun, rerun_conf)
     run_scenario("pop4_planc_rerun_em", w4, POP4, rerun[40:100], rerun_conf, hap_pop_pair=True)
+    run_scenario("pop4_planc_em", w4, POP4, synth.plan_c_cases("API") + rerun[:60], dict(rerun_conf, UNK_priors="SR"), em=True)
+    run_scenario("pop4_planc_em_haps", w4, POP4, synth.plan_c_cases("HIS"), {"UNK_priors": "MR", "output_MUUG": False}, em=True)
     run_scenario("pop4_em_mr", w4, POP4, synth.SubjectGen(cau, 14, pops=POP4).mixed(40), {"UNK_priors": "MR"},
                  hap_pop_pair=True)
 
