@@ -125,12 +125,13 @@ def main():
     # HBM traffic per launch of the dominant kernel: PMC numbers cannot be collected from inside this
     # process; they come from the committed rocprofv3 --pmc passes over this same command
     traffic, traffic_src = None, None
-    pmc_path = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+    pmc_file = "r1b_pmc_traffic.json"  # newest committed PMC passes (tools/profile_round.sh)
+    pmc_path = os.path.join(ROOT, "profiles", pmc_file)
     if os.path.exists(pmc_path) and args.workload == "full" and args.subjects == 10000:
         pmc = json.load(open(pmc_path)).get(names[dom])
         if pmc and "hbm_bytes_raw" in pmc:
             traffic = pmc["hbm_bytes_raw"]
-            traffic_src = "profiles/r1_pmc_traffic.json: (FETCH_SIZE + WRITE_SIZE) KB x 1024 per launch, separate --pmc passes; " \
+            traffic_src = "profiles/" + pmc_file + ": (FETCH_SIZE + WRITE_SIZE) KB x 1024 per launch, separate --pmc passes; " \
                           "with FETCH_SIZE doubled (gfx950 wide-read correction): %d" % pmc["hbm_bytes_fetch_doubled"]
 
     out = None

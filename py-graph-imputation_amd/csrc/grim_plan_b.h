@@ -570,6 +570,7 @@ __device__ inline uint32_t pb_levels(const DevArgs &A, WgShared &sh, const Slot 
     if (tid < GRIM_SIDES) st.memo[tid] = 10;
     __syncthreads();
     for (int m = 0; m < (int)A.prm.planb_rows; ++m) {
+      STAMP_BEGIN();
       for (int s = tid; s < GRIM_COMP_CAP; s += GRIM_WG) S.comp[s] = 0;
       if (tid < GRIM_SIDES) sh.Tn[tid] = 0;
       __syncthreads();
@@ -586,7 +587,9 @@ __device__ inline uint32_t pb_levels(const DevArgs &A, WgShared &sh, const Slot 
         }
       }
       __syncthreads();
+      STAMP(1);
       uint32_t nU = pb_pairs(A, sh, S, prior, mx);
+      STAMP(2);
       if (nU) return nU;
     }
     // rescue loop (impute.py:1490-1558): its six iterations are identical, one suffices
@@ -722,9 +725,12 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_b_kernel(DevArgs A) {
     double mx = 0.0;
     uint8_t status = GRIM_ST_MISS, reason = 0, plan = 'b', plan_haps = 0;
     // ---- the pass on the phases as opened: Plan B (Plan A already failed in the first kernels) --------
+    STAMP_BEGIN();
     uint32_t nU = pb_levels(A, sh, S, wt, st, tok, &mx);
+    STAMP(0);
     if (nU) {
       emit_tables(A, sh, S, nU, sh.out, 3);
+      STAMP(3);
       status = GRIM_ST_OK;
     } else if (!A.prm.out_muug && A.prm.em) {
       // impute_file(em=True): the phased pass stops after Plan B (impute.py:1649); nothing was found
@@ -742,10 +748,12 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_b_kernel(DevArgs A) {
         plan = 'c';
         const bool two_pass = A.prm.out_muug && A.prm.out_haps;
         nU = pb_plan_c(A, sh, S, wt, tok, &mx);
+        STAMP(4);
         if (nU) {
           emit_tables(A, sh, S, nU, sh.out, two_pass ? 1u : 3u);
           status = GRIM_ST_OK;
         }
+        STAMP(3);
         if (two_pass) {
           // the phased pass starts over on the REDUCED phases (impute.py:1645-1654): Plan A with the
           // subject's prior, Plan B's two levels, Plan C again
@@ -753,18 +761,22 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_b_kernel(DevArgs A) {
           pb_absent(A, sh, st, tok);
           plan_haps = 'a';
           uint32_t nH = pb_plan_a(A, sh, S, wt, st, tok, &mx2);
+          STAMP(5);
           if (!nH) {
             plan_haps = 'b';
             nH = pb_levels(A, sh, S, wt, st, tok, &mx2);
           }
+          STAMP(6);
           if (!nH && !A.prm.em) {
             plan_haps = 'c';
             nH = pb_plan_c(A, sh, S, wt, tok, &mx2);
           }
+          STAMP(4);
           if (nH) {
             emit_tables(A, sh, S, nH, sh.out, 2u);
             status = GRIM_ST_OK;
           }
+          STAMP(7);
         }
       }
     }

@@ -17,7 +17,11 @@ def spy(self, subj, tokens, priors, params):
 I.Imputation._run_arrays = spy
 harness.run_product("cau", conf, lines, tag="hv")
 res = keep["res"]
-for plan in (ord('a'), ord('b')):
+npair = res['n_pairs'].astype(np.int64)
+edges = [0, 1, 65, 129, 257, 513, 1025, 2049, 4097, 16385, 1 << 30]
+print('n_pairs histogram:', [(edges[i], int(((npair >= edges[i]) & (npair < edges[i + 1])).sum())) for i in range(len(edges) - 1)])
+print('plans:', {chr(p): int((res['plan'] == p).sum()) for p in np.unique(res['plan'])})
+for plan in (ord('a'), ord('b'), ord('c')):
     idx = np.nonzero(res["plan"] == plan)[0]
     top = idx[np.argsort(-res["n_pairs"][idx].astype(np.int64))[:3]]
     for i in top:
