@@ -220,6 +220,68 @@ __device__ __forceinline__ uint32_t tab_insert(uint64_t *k0, uint64_t *k1, uint3
   }
 }
 
+// N independent inserts per thread with their table accesses in flight together: a thread that walks
+// thousands of pairs is bound by the ~1-2 us of each device-scope atomic, not by their number.  Same protocol
+// and same result as N tab_insert calls (two equal keys of one thread end in the same slot).
+template <bool WIDE, int N>
+__device__ __forceinline__ void tab_insert_n(uint64_t *k0, uint64_t *k1, uint32_t mask, const uint64_t (&a)[N], const uint64_t (&b)[N],
+                                             const bool (&on)[N], uint32_t (&out)[N]) {
+  uint32_t s[N];
+  bool done[N];
+#pragma unroll
+  for (int q = 0; q < N; ++q) {
+    s[q] = (uint32_t)mix64(a[q] ^ (b[q] * 0x9E3779B97F4A7C15ull)) & mask;
+    done[q] = !on[q];
+    out[q] = GRIM_NONE;
+  }
+  for (;;) {
+    bool all = true;
+#pragma unroll
+    for (int q = 0; q < N; ++q) all = all && done[q];
+    if (all) return;
+    uint64_t c0[N], old[N], c1[N];
+    bool claim[N], same[N];
+#pragma unroll
+    for (int q = 0; q < N; ++q) c0[q] = done[q] ? 1ull : ALOAD(&k0[s[q]]);
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+      claim[q] = !done[q] && c0[q] == 0;
+      old[q] = 0;
+      if (claim[q]) old[q] = atomicCAS((unsigned long long *)&k0[s[q]], 0ull, (unsigned long long)a[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < N; ++q)
+      if (claim[q]) {
+        if (old[q] == 0) {
+          if (WIDE) ASTORE(&k1[s[q]], b[q]);
+          out[q] = s[q];
+          done[q] = true;
+        } else {
+          c0[q] = old[q];
+        }
+      }
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+      same[q] = !done[q] && c0[q] == a[q];
+      c1[q] = 0;
+      if (WIDE && same[q]) c1[q] = ALOAD(&k1[s[q]]);
+    }
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+      if (done[q]) continue;
+      if (same[q]) {
+        if (!WIDE || c1[q] == b[q]) {
+          out[q] = s[q];
+          done[q] = true;
+          continue;
+        }
+        if (c1[q] == 0) continue;  // claimed a moment ago, second word not published yet: look again
+      }
+      s[q] = (s[q] + 1) & mask;
+    }
+  }
+}
+
 // ---- wave-level running top-K with stable ties (impute.py:424-442) ---------------------------------
 // Records live in LDS, one set per wave: [0,nrun) is the sorted running list, [nrun,nrun+nbuf) the
 // not yet merged newcomers.  Order: bigger sort key first, then smaller `tie` (= stream position).

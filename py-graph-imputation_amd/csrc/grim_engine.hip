@@ -21,7 +21,7 @@
 // sides (one wave per side, wave64 ballots/prefix scans, LDS-staged running top-K); the whole
 // workgroup then scores haplotype pairs, dedups, sums and ranks.
 // =================================================================================================
-__global__ __launch_bounds__(GRIM_WG) void grim_plan_a_kernel(DevArgs A) {
+__global__ __launch_bounds__(GRIM_WG, 2) void grim_plan_a_kernel(DevArgs A) {
   __shared__ WgShared sh;
   __shared__ WaveTop wt[GRIM_NWAVE];
   const int tid = threadIdx.x;

@@ -17,6 +17,15 @@ struct ListVer {
   uint16_t cnt, wid;
 };
 
+// pairs a thread keeps in flight in the pair pass / in the grouping inserts (register budget: the Plan-B
+// kernel must stay within 256 VGPRs for two workgroups per CU)
+#ifndef GRIM_PAIR_NB
+#define GRIM_PAIR_NB 2
+#endif
+#ifndef GRIM_GROUP_NB
+#define GRIM_GROUP_NB 4
+#endif
+
 struct WgShared {
   grim_subject subj;
   uint32_t toff[GRIM_MAXL][2];
@@ -250,59 +259,97 @@ __device__ inline uint32_t pair_pass(const DevArgs &A, WgShared &sh, const Slot 
     S.tmin[s] = GRIM_NONE;
   }
   __syncthreads();
-  for (uint32_t f = tid; f < np; f += GRIM_WG) {
-    PairRef pr = pair_ref(sh, S, f);
-    double w = prior[ENT_POP(pr.e1) * P + ENT_POP(pr.e2)];
-    if (pair_accept(eps, pr, w)) {
-      uint32_t lo = pr.e1 < pr.e2 ? pr.e1 : pr.e2, hi = pr.e1 < pr.e2 ? pr.e2 : pr.e1;
-      uint64_t key = ((uint64_t)lo << 32) | hi | GRIM_VALID;
-      uint32_t s = tab_insert<false>(S.k0, S.k1, mask, key, 0);
-      atomicMin(&S.tmin[s], f);
+  // Pass 1: accepted pairs claim a slot per unordered entity pair; the smallest pair number wins it.
+  // GRIM_PAIR_NB pairs per thread and step so that their (dependent) top-list gathers and their table
+  // accesses are in flight together; the slot of every accepted pair is parked in sva for pass 2.
+  for (uint32_t f0 = tid; f0 < np; f0 += GRIM_PAIR_NB * GRIM_WG) {
+    PairRef pr[GRIM_PAIR_NB];
+    double w[GRIM_PAIR_NB];
+#pragma unroll
+    for (int q = 0; q < GRIM_PAIR_NB; ++q) {
+      const uint32_t f = f0 + q * GRIM_WG;
+      if (f < np) {
+        pr[q] = pair_ref(sh, S, f);
+        w[q] = prior[ENT_POP(pr[q].e1) * P + ENT_POP(pr[q].e2)];
+      }
+    }
+    uint64_t key[GRIM_PAIR_NB], none[GRIM_PAIR_NB];
+    bool on[GRIM_PAIR_NB];
+    uint32_t slot[GRIM_PAIR_NB];
+#pragma unroll
+    for (int q = 0; q < GRIM_PAIR_NB; ++q) {
+      const uint32_t f = f0 + q * GRIM_WG;
+      key[q] = none[q] = 0;
+      on[q] = f < np && pair_accept(eps, pr[q], w[q]);
+      if (on[q]) {
+        uint32_t lo = pr[q].e1 < pr[q].e2 ? pr[q].e1 : pr[q].e2, hi = pr[q].e1 < pr[q].e2 ? pr[q].e2 : pr[q].e1;
+        key[q] = ((uint64_t)lo << 32) | hi | GRIM_VALID;
+      }
+    }
+    tab_insert_n<false, GRIM_PAIR_NB>(S.k0, S.k1, mask, key, none, on, slot);
+#pragma unroll
+    for (int q = 0; q < GRIM_PAIR_NB; ++q) {
+      const uint32_t f = f0 + q * GRIM_WG;
+      if (on[q]) atomicMin(&S.tmin[slot[q]], f);
+      if (f < np) S.sva[f] = slot[q];
     }
   }
   __syncthreads();
+  // Pass 2: winners in pair order, 4 x 256 pairs per barrier round
   uint32_t nU = 0;
   double mx = 0.0;
-  for (uint32_t f0 = 0; f0 < np; f0 += GRIM_WG) {
-    uint32_t f = f0 + tid;
-    bool win = false;
-    double prob = 0.0;
-    if (f < np) {
-      PairRef pr = pair_ref(sh, S, f);
-      double w = prior[ENT_POP(pr.e1) * P + ENT_POP(pr.e2)];
-      if (pair_accept(eps, pr, w)) {
-        uint32_t lo = pr.e1 < pr.e2 ? pr.e1 : pr.e2, hi = pr.e1 < pr.e2 ? pr.e2 : pr.e1;
-        uint64_t key = ((uint64_t)lo << 32) | hi | GRIM_VALID;
-        uint32_t s = tab_insert<false>(S.k0, S.k1, mask, key, 0);
-        win = (ALOAD(&S.tmin[s]) == f);
-        if (win) {
-          prob = pair_prob(pr, w);
-          if (prob > mx) mx = prob;
-        }
+  for (uint32_t f0 = 0; f0 < np; f0 += 4 * GRIM_WG) {
+    bool win[4];
+    double prob[4];
+    uint32_t slot[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t f = f0 + q * GRIM_WG + tid;
+      slot[q] = f < np ? S.sva[f] : GRIM_NONE;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t f = f0 + q * GRIM_WG + tid;
+      win[q] = slot[q] != GRIM_NONE && ALOAD(&S.tmin[slot[q]]) == f;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      prob[q] = 0.0;
+      if (win[q]) {
+        PairRef pr = pair_ref(sh, S, f0 + q * GRIM_WG + tid);
+        prob[q] = pair_prob(pr, prior[ENT_POP(pr.e1) * P + ENT_POP(pr.e2)]);
+        if (prob[q] > mx) mx = prob[q];
       }
     }
     if (emit) {
-      uint64_t m = __ballot(win);
-      uint32_t wc = (uint32_t)__popcll(m);
-      if (lane_id() == 0) sh.tmp[wave_id()] = wc;
+      uint64_t m[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        m[q] = __ballot(win[q]);
+        if (lane_id() == 0) sh.tmp[q * GRIM_NWAVE + wave_id()] = (uint32_t)__popcll(m[q]);
+      }
       __syncthreads();
-      uint32_t base = nU, tot = 0;
-      for (int w2 = 0; w2 < GRIM_NWAVE; ++w2) {
-        uint32_t t = sh.tmp[w2];
-        if (w2 < wave_id()) base += t;
-        tot += t;
-      }
-      if (win) {
-        uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
-        if (pos < A.pair_cap) {
-          S.Useq[pos] = f;
-          S.Uprob[pos] = prob;
+      uint32_t run = nU, base[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        for (int w2 = 0; w2 < GRIM_NWAVE; ++w2) {
+          if (w2 == wave_id()) base[q] = run;
+          run += sh.tmp[q * GRIM_NWAVE + w2];
         }
-      }
-      nU += tot;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (win[q]) {
+          uint32_t pos = base[q] + (uint32_t)__popcll(m[q] & ((1ull << lane_id()) - 1ull));
+          if (pos < A.pair_cap) {
+            S.Useq[pos] = f0 + q * GRIM_WG + tid;
+            S.Uprob[pos] = prob[q];
+          }
+        }
+      nU = run;
       __syncthreads();
     } else {
-      nU += win ? 1u : 0u;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) nU += win[q] ? 1u : 0u;
     }
   }
   // MaxProb
@@ -338,7 +385,9 @@ __device__ inline uint32_t group_and_rank(const DevArgs &A, WgShared &sh, const 
                                           uint32_t **order_out, uint32_t want) {
   const int tid = threadIdx.x;
   uint32_t ng = 0;
-  if (kind == 2) {
+  // one population: U is already unique per unordered haplotype pair (the dedup key of the pair pass is
+  // {(hap,pop),(hap,pop)}), so every pair is its own group
+  if (kind == 2 || (kind == 1 && A.g.P == 1)) {
     ng = nU;
     for (uint32_t u = tid; u < nU; u += GRIM_WG) {
       S.gsum[u] = S.Uprob[u];
@@ -356,26 +405,49 @@ __device__ inline uint32_t group_and_rank(const DevArgs &A, WgShared &sh, const 
       S.tmin[s] = GRIM_NONE;
     }
     __syncthreads();
-    for (uint32_t u = tid; u < nU; u += GRIM_WG) {
-      PairRef pr = pair_ref(sh, S, S.Useq[u]);
-      uint32_t h1 = ENT_HAP(pr.e1), h2 = ENT_HAP(pr.e2);
-      uint32_t s;
-      if (kind == 1) {
-        uint32_t lo = h1 < h2 ? h1 : h2, hi = h1 < h2 ? h2 : h1;
-        s = tab_insert<false>(S.k0, S.k1, mask, (((uint64_t)lo << 32) | hi) | GRIM_VALID, 0);
-      } else {
-        uint64_t a = hap_key(A.g, S, h1), b = hap_key(A.g, S, h2);
-        uint64_t lo = 0, hi = 0;
+    // GRIM_GROUP_NB pairs per thread and step: their (dependent) key gathers are in flight together, then the inserts
+    for (uint32_t u0 = tid; u0 < nU; u0 += GRIM_GROUP_NB * GRIM_WG) {
+      uint64_t klo[GRIM_GROUP_NB], khi[GRIM_GROUP_NB];
 #pragma unroll
-        for (int l = 0; l < GRIM_MAXL; ++l) {
-          uint64_t x = (a >> (GRIM_ABITS * l)) & 0xFFF, y = (b >> (GRIM_ABITS * l)) & 0xFFF;
-          lo |= (x < y ? x : y) << (GRIM_ABITS * l);
-          hi |= (x < y ? y : x) << (GRIM_ABITS * l);
+      for (int q = 0; q < GRIM_GROUP_NB; ++q) {
+        const uint32_t u = u0 + q * GRIM_WG;
+        klo[q] = khi[q] = 0;
+        if (u < nU) {
+          PairRef pr = pair_ref(sh, S, S.Useq[u]);
+          uint32_t h1 = ENT_HAP(pr.e1), h2 = ENT_HAP(pr.e2);
+          if (kind == 1) {
+            uint32_t lo = h1 < h2 ? h1 : h2, hi = h1 < h2 ? h2 : h1;
+            klo[q] = (((uint64_t)lo << 32) | hi) | GRIM_VALID;
+          } else {
+            uint64_t a = hap_key(A.g, S, h1), b = hap_key(A.g, S, h2);
+            uint64_t lo = 0, hi = 0;
+#pragma unroll
+            for (int l = 0; l < GRIM_MAXL; ++l) {
+              uint64_t x = (a >> (GRIM_ABITS * l)) & 0xFFF, y = (b >> (GRIM_ABITS * l)) & 0xFFF;
+              lo |= (x < y ? x : y) << (GRIM_ABITS * l);
+              hi |= (x < y ? y : x) << (GRIM_ABITS * l);
+            }
+            klo[q] = lo | GRIM_VALID;
+            khi[q] = hi | GRIM_VALID;
+          }
         }
-        s = tab_insert<true>(S.k0, S.k1, mask, lo | GRIM_VALID, hi | GRIM_VALID);
       }
-      S.Uslot[u] = s;
-      atomicMin(&S.tmin[s], u);
+      bool on[GRIM_GROUP_NB];
+      uint32_t slot[GRIM_GROUP_NB];
+#pragma unroll
+      for (int q = 0; q < GRIM_GROUP_NB; ++q) on[q] = u0 + q * GRIM_WG < nU;
+      if (kind == 1)
+        tab_insert_n<false, GRIM_GROUP_NB>(S.k0, S.k1, mask, klo, khi, on, slot);
+      else
+        tab_insert_n<true, GRIM_GROUP_NB>(S.k0, S.k1, mask, klo, khi, on, slot);
+#pragma unroll
+      for (int q = 0; q < GRIM_GROUP_NB; ++q) {
+        const uint32_t u = u0 + q * GRIM_WG;
+        if (on[q]) {
+          S.Uslot[u] = slot[q];
+          atomicMin(&S.tmin[slot[q]], u);
+        }
+      }
     }
     __syncthreads();
     // heads in first-seen order -> dense group ids
@@ -406,11 +478,22 @@ __device__ inline uint32_t group_and_rank(const DevArgs &A, WgShared &sh, const 
       __syncthreads();
     }
     // stable sort of u by group id, then per-group left-to-right sums
-    for (uint32_t u = tid; u < nU; u += GRIM_WG) {
-      uint32_t gid = S.tgid[S.Uslot[u]];
-      S.ska[u] = gid;
-      S.sva[u] = u;
-      atomicAdd(&S.gcnt[gid], 1u);
+    for (uint32_t u0 = tid; u0 < nU; u0 += 4 * GRIM_WG) {
+      uint32_t gid[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t u = u0 + q * GRIM_WG;
+        gid[q] = u < nU ? S.tgid[S.Uslot[u]] : 0;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t u = u0 + q * GRIM_WG;
+        if (u < nU) {
+          S.ska[u] = gid[q];
+          S.sva[u] = u;
+          atomicAdd(&S.gcnt[gid[q]], 1u);
+        }
+      }
     }
     __syncthreads();
     for (uint32_t g = tid; g < ng; g += GRIM_WG) S.gstart[g] = S.gcnt[g];
@@ -459,7 +542,83 @@ __device__ inline uint32_t group_and_rank(const DevArgs &A, WgShared &sh, const 
   }
   __syncthreads();
   if (want > 0 && want <= 1024 && want * 4 <= ng) {
-    // Only rows [0,want) are written.  MSD radix select finds the want-th smallest key T; groups
+    // Only rows [0,want) are written.  First try ONE pass: a 4096-bin histogram over the keys' top 12 bits
+    // (sign and exponent of the sum) in LDS locates the bin B that holds the want-th smallest key; when the
+    // groups of the bins <= B fit the LDS list they are gathered in id order and ranked by counting.
+    {
+      uint32_t *h12 = sh.hist;
+      for (int i = tid; i < 4096; i += GRIM_WG) h12[i] = 0;
+      __syncthreads();
+      for (uint32_t g0 = tid; g0 < ng; g0 += 4 * GRIM_WG) {
+        uint64_t k[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) k[q] = g0 + q * GRIM_WG < ng ? S.ska[g0 + q * GRIM_WG] : 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (g0 + q * GRIM_WG < ng) atomicAdd(&h12[(uint32_t)(k[q] >> 52)], 1u);
+      }
+      __syncthreads();
+      uint32_t part = 0;
+      for (int e = 0; e < 16; ++e) part += h12[tid * 16 + e];
+      uint32_t total;
+      const uint32_t before = wg_excl_scan(part, sh.tmp, total);
+      if (before < want && want <= before + part) {
+        uint32_t cum = before;
+#pragma nounroll
+        for (int e = 0; e < 16; ++e) {
+          const uint32_t c = h12[tid * 16 + e];
+          if (cum + c >= want) {
+            sh.bc[4] = (uint32_t)(tid * 16 + e);
+            sh.bc[5] = cum + c;
+            break;
+          }
+          cum += c;
+        }
+      }
+      __syncthreads();
+      const uint32_t B = sh.bc[4], upto = sh.bc[5];  // groups in bins <= B
+      __syncthreads();
+      if (upto <= 1024) {
+        uint64_t *lk = (uint64_t *)sh.hist;      // [1024] keys (the histogram is spent)
+        uint32_t *lg = (uint32_t *)(lk + 1024);  // [1024] group ids
+        uint32_t taken = 0;
+        for (uint32_t g0 = 0; g0 < ng; g0 += GRIM_WG) {
+          const uint32_t g = g0 + tid;
+          const uint64_t k = g < ng ? S.ska[g] : ~0ull;
+          const bool pick = g < ng && (uint32_t)(k >> 52) <= B;
+          const uint64_t mp = __ballot(pick);
+          if (lane_id() == 0) sh.tmp[wave_id()] = (uint32_t)__popcll(mp);
+          __syncthreads();
+          uint32_t pbase = taken, ptot = 0;
+          for (int w2 = 0; w2 < GRIM_NWAVE; ++w2) {
+            const uint32_t t = sh.tmp[w2];
+            if (w2 < wave_id()) pbase += t;
+            ptot += t;
+          }
+          if (pick) {
+            const uint32_t pos = pbase + (uint32_t)__popcll(mp & ((1ull << lane_id()) - 1ull));
+            lk[pos] = k;
+            lg[pos] = g;
+          }
+          taken += ptot;
+          __syncthreads();
+        }
+        // rank by (key asc, id asc); ids were gathered in ascending order
+        for (uint32_t i = tid; i < taken; i += GRIM_WG) {
+          const uint64_t k = lk[i];
+          uint32_t rank = 0;
+          for (uint32_t j = 0; j < taken; ++j) {
+            const uint64_t k2 = lk[j];
+            rank += (k2 < k || (k2 == k && j < i)) ? 1u : 0u;
+          }
+          if (rank < want) S.svb[rank] = lg[i];
+        }
+        __syncthreads();
+        *order_out = S.svb;
+        return ng;
+      }
+    }
+    // Otherwise MSD radix select finds the want-th smallest key T; groups
     // with key < T plus the first ties (group id order = first-seen order) are gathered in id
     // order and ranked by counting in LDS.
     uint64_t prefix = 0;

@@ -690,7 +690,7 @@ __device__ inline uint32_t pb_plan_c(const DevArgs &A, WgShared &sh, const Slot 
   return pb_pairs(A, sh, S, prior, mx);
 }
 
-__global__ __launch_bounds__(GRIM_WG) void grim_plan_b_kernel(DevArgs A) {
+__global__ __launch_bounds__(GRIM_WG, 2) void grim_plan_b_kernel(DevArgs A) {
   __shared__ WgShared sh;
   __shared__ WaveTop wt[GRIM_NWAVE];
   __shared__ PbState st;
