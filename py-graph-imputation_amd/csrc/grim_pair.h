@@ -747,10 +747,14 @@ __device__ inline void pop_tables(const DevArgs &A, WgShared &sh, const Slot &S,
   for (uint32_t u0 = 0; u0 < nU; u0 += 1024) {
     uint32_t cnt = nU - u0 < 1024 ? nU - u0 : 1024;
     for (uint32_t r = tid; r < cnt; r += GRIM_WG) {
-      PairRef pr = pair_ref(sh, S, S.Useq[u0 + r]);
-      uint32_t a = ENT_POP(pr.e1), b = ENT_POP(pr.e2);
-      uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
-      sh.qcell[r] = (uint16_t)(lo * P + hi);
+      uint32_t cell = 0;
+      if (ncell > 1) {  // one population: the only cell, no need to look the pair up
+        PairRef pr = pair_ref(sh, S, S.Useq[u0 + r]);
+        uint32_t a = ENT_POP(pr.e1), b = ENT_POP(pr.e2);
+        uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+        cell = lo * P + hi;
+      }
+      sh.qcell[r] = (uint16_t)cell;
       sh.qprob[r] = S.Uprob[u0 + r];
     }
     __syncthreads();
