@@ -674,7 +674,8 @@ __device__ inline void pb_reduce_for_plan_c(const DevArgs &A, WgShared &sh, cons
   __syncthreads();
 }
 
-__device__ inline uint32_t pb_plan_c(const DevArgs &A, WgShared &sh, const Slot &S, WaveTop *wt, const uint16_t *tok, double *mx) {
+__device__ inline uint32_t pb_plan_c(const DevArgs &A, WgShared &sh, const Slot &S, WaveTop *wt, const PbState &st, const uint16_t *tok,
+                                     double *mx) {
   const int tid = threadIdx.x;
   const int P = A.g.P;
   const int nph = sh.nph;
@@ -683,6 +684,7 @@ __device__ inline uint32_t pb_plan_c(const DevArgs &A, WgShared &sh, const Slot 
   if (tid < GRIM_SIDES) sh.Tn[tid] = 0;
   __syncthreads();
   for (int s = wave_id(); s < 2 * nph; s += GRIM_NWAVE) {
+    if (!(st.side_any[s] && st.side_any[s ^ 1])) continue;  // phase dropped by open_phases
     SideSpec sp = side_spec(A, sh, s >> 1, s & 1);
     side_plan_c(A, sh, S, prior, wt[wave_id()], sp, tok, s);
   }
@@ -739,15 +741,18 @@ __global__ __launch_bounds__(GRIM_WG, 2) void grim_plan_b_kernel(DevArgs A) {
       // all-ones prior level 1 left behind; every phase opens again
       pb_reduce_for_plan_c(A, sh, tok, A.priors + (uint64_t)A.ones_prior * P * P);
       pb_open(A, sh, st, tok);
+      // A side whose remaining (all unseen) lists still multiply to the options threshold is opened by the
+      // label scan, which finds nothing -- every allele of a graph node is a seen one -- so open_phases
+      // drops its phase (side_any = 0); Plan C runs on the phases that are left, possibly none.
       bool wide = false;
-      for (int s = 0; s < 2 * nph; ++s) wide |= st.side_scan[s] != 0;
+      for (int s = 0; s < 2 * nph; ++s) wide |= st.side_scan[s] != 0 && st.side_any[s] != 0;
       if (wide) {
-        status = GRIM_ST_UNSUPPORTED;  // a list of unseen alleles still above the options threshold
+        status = GRIM_ST_UNSUPPORTED;  // cannot happen by the argument above; never guess
         reason = 3;
       } else {
         plan = 'c';
         const bool two_pass = A.prm.out_muug && A.prm.out_haps;
-        nU = pb_plan_c(A, sh, S, wt, tok, &mx);
+        nU = pb_plan_c(A, sh, S, wt, st, tok, &mx);
         STAMP(4);
         if (nU) {
           emit_tables(A, sh, S, nU, sh.out, two_pass ? 1u : 3u);
@@ -769,7 +774,7 @@ __global__ __launch_bounds__(GRIM_WG, 2) void grim_plan_b_kernel(DevArgs A) {
           STAMP(6);
           if (!nH && !A.prm.em) {
             plan_haps = 'c';
-            nH = pb_plan_c(A, sh, S, wt, tok, &mx2);
+            nH = pb_plan_c(A, sh, S, wt, st, tok, &mx2);
           }
           STAMP(4);
           if (nH) {

@@ -49,6 +49,9 @@ def mutate(line, rng, by_locus):
             ext = [str(e) for e in rng.choice(pool, size=min(max(k1, k2), len(pool)), replace=False)]
             loci2.append("/".join([a] + ext[:k1]) + "+" + "/".join([b] + ext[:k2]))
         loci = loci2
+    elif r < 0.48:  # a wide list of alleles the graph has never seen (Plan C with a side the label scan opens)
+        k = int(rng.integers(len(loci))); a, b = loci[k].split("+"); loc = a.split("*")[0]
+        loci[k] = "/".join("%s*97:%02d" % (loc, j) for j in range(1, int(rng.integers(3, 9)))) + "+" + b
     parts[1] = "^".join(loci)
     return ",".join(parts)
 

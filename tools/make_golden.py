@@ -298,6 +298,10 @@ def main():
                   "priority": {"alpha": 0.128, "eta": 0.09, "beta": 0.168, "gamma": 0.165, "delta": 0.667}, "epsilon": 1e-7}
     run_scenario("pop4_planc_rerun", w4, POP4, rerun, rerun_conf)
     run_scenario("pop4_planc_rerun_em", w4, POP4, rerun[40:100], rerun_conf, hap_pop_pair=True)
+    run_scenario("pop4_planc_wide", w4, POP4, synth.plan_c_wide_cases("AFA") + synth.plan_c_wide_cases("UNK") + rerun[100:140],
+                 dict(rerun_conf, UNK_priors="MR"))
+    run_scenario("cau_planc_wide_muug", w1, ["CAU"], synth.plan_c_wide_cases("CAU") + synth.plan_c_cases("CAU"),
+                 {"number_of_options_threshold": 5, "output_haplotypes": False})
     run_scenario("pop4_planc_em", w4, POP4, synth.plan_c_cases("API") + rerun[:60], dict(rerun_conf, UNK_priors="SR"), em=True)
     run_scenario("pop4_planc_em_haps", w4, POP4, synth.plan_c_cases("HIS"), {"UNK_priors": "MR", "output_MUUG": False}, em=True)
     run_scenario("pop4_em_mr", w4, POP4, synth.SubjectGen(cau, 14, pops=POP4).mixed(40), {"UNK_priors": "MR"},

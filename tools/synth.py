@@ -172,6 +172,25 @@ def plan_c_cases(pop="CAU"):
     ]
 
 
+def plan_c_wide_cases(pop="CAU"):
+    """Plan C subjects with a list of unseen alleles at least as wide as a small number_of_options_threshold
+    (5 in the scenario): after Plan C's reduction such a side is opened by the label scan, which finds
+    nothing, so its phase is dropped (impute.py:1637-1643, 914-989)."""
+    w5 = "/".join("A*97:%02d" % j for j in range(1, 6))
+    w7 = "/".join("B*97:%02d" % j for j in range(1, 8))
+    w3 = "/".join("C*97:%02d" % j for j in range(1, 4))
+    return [
+        "W0,%s+A*01:01^B*07:02+B*08:01,%s,%s" % (w5, pop, pop),
+        "W1,%s+%s^B*07:02+B*08:01^C*07:01+C*07:02,%s,%s" % (w5, w5, pop, pop),
+        "W2,A*01:01+A*02:01^%s+B*08:01^DRB1*15:01+DRB1*03:01,%s,%s" % (w7, pop, pop),
+        "W3,A*98:01+A*02:01^%s+B*98:01^C*07:01+C*07:02,%s,%s" % (w7, pop, pop),
+        "W4,%s+A*98:09^%s+B*08:01,UNK,%s" % (w5, w7, pop),
+        "W5,%s+C*07:02^A*01:01+A*02:01^B*07:02/B*08:01+B*44:02,%s,%s" % (w3, pop, pop),
+        "W6,%s+C*98:02^A*01:01/A*02:01/A*03:01+A*02:01^B*07:02+B*44:02,%s,%s" % (w3, pop, pop),
+        "W7,%s+%s,%s,%s" % (w7, w7, pop, pop),
+    ]
+
+
 def edge_cases(pop="CAU"):
     """Hand-written edge cases (SURVEY appendix A.6 + a few more)."""
     return [
