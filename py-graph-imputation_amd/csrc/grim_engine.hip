@@ -541,7 +541,8 @@ static int enqueue_stage1(grim_batch *b) {
   }
   HIPCHK(hipEventRecord(b->ev[3], c->stream), c, -1);
   if (b->n_medium) {
-    uint32_t grid = (uint32_t)c->n_cu * 10;
+    static const int waves_per_cu = getenv("GRIM_MEDIUM_WAVES") ? atoi(getenv("GRIM_MEDIUM_WAVES")) : GRIM_MEDIUM_WAVES_PER_CU;
+    uint32_t grid = (uint32_t)c->n_cu * (uint32_t)(waves_per_cu > 0 ? waves_per_cu : GRIM_MEDIUM_WAVES_PER_CU);
     if (grid > b->n_medium) grid = b->n_medium;
     hipLaunchKernelGGL(grim_plan_a_medium_kernel, dim3(grid), dim3(64), 0, c->stream, A, (const uint32_t *)b->order_m,
                        b->n_medium, A.bail_list);

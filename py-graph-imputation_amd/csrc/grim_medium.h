@@ -14,8 +14,14 @@
 #pragma once
 #include "grim_pair.h"
 
+#ifndef MW_E
 #define MW_E 384
+#endif
 #define MW_NP 512
+// resident one-wave workgroups per CU: bounded by the LDS each needs (sizeof(WaveMed) of 160 KB)
+#ifndef GRIM_MEDIUM_WAVES_PER_CU
+#define GRIM_MEDIUM_WAVES_PER_CU 10
+#endif
 
 struct WaveMed {
   // entries in stream order; the area is reused for the pair keys once the lists are built
@@ -44,11 +50,6 @@ struct WaveMed {
   uint8_t ph_pat[GRIM_MAXPH];
   int nph;
   uint32_t cnt_side[GRIM_SIDES];
-};
-
-struct MedPair {
-  double p1, p2, m2;
-  uint32_t e1, e2;
 };
 
 __device__ __forceinline__ PairRef med_pair(const WaveMed &M, uint32_t f) {
