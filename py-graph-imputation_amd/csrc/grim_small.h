@@ -58,6 +58,10 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_a_small_kernel(DevArgs A, c
   const int hl = threadIdx.x & 31;            // lane inside the half wave = combination
   const uint32_t w = blockIdx.x * (GRIM_WG / 32) + (threadIdx.x >> 5);
   const bool live = w < n;
+  const int n_ladder = A.prm.n_ladder;
+  double lad[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) lad[i] = A.prm.ladder[i];
   // ---- candidate of this lane: one 32-byte record (same address for the half wave), one probe ----
   uint32_t node = GRIM_NONE;
   uint64_t mykey = 0;
@@ -110,12 +114,16 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_a_small_kernel(DevArgs A, c
     bool need_lo = (okb & 0xFFFFull) != 0, need_hi = ((okb >> 32) & 0xFFFFull) != 0;
     bool got_lo = false, got_hi = false;
     double eps_lo = 0.0, eps_hi = 0.0;
-    for (int idx = 0; idx < A.prm.n_ladder && (need_lo || need_hi); ++idx) {
-      const double e = A.prm.ladder[idx];
+    auto step = [&](double e) {
       const uint64_t b = __ballot(pair_ok && pair_accept(e, pr, w_prior));
       if (need_lo && (b & 0xFFFFull)) { need_lo = false; got_lo = true; eps_lo = e; }
       if (need_hi && ((b >> 32) & 0xFFFFull)) { need_hi = false; got_hi = true; eps_hi = e; }
-    }
+    };
+    // the first eight steps sit in scalar registers (loaded at kernel start, under the probe's latency)
+#pragma unroll
+    for (int idx = 0; idx < 8; ++idx)
+      if (idx < n_ladder && (need_lo || need_hi)) step(lad[idx]);
+    for (int idx = 8; idx < n_ladder && (need_lo || need_hi); ++idx) step(A.prm.ladder[idx]);
     eps = hi_half ? eps_hi : eps_lo;
     found = hi_half ? got_hi : got_lo;
   }
