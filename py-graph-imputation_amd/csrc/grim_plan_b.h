@@ -752,16 +752,12 @@ __global__ __launch_bounds__(GRIM_WG, 2) void grim_plan_b_kernel(DevArgs A) {
       } else {
         plan = 'c';
         const bool two_pass = A.prm.out_muug && A.prm.out_haps;
-        nU = pb_plan_c(A, sh, S, wt, st, tok, &mx);
-        STAMP(4);
-        if (nU) {
-          emit_tables(A, sh, S, nU, sh.out, two_pass ? 1u : 3u);
-          status = GRIM_ST_OK;
-        }
-        STAMP(3);
+        // With both outputs on, the phased pass starts over on the REDUCED phases (impute.py:1645-1654): Plan A
+        // with the subject's prior, Plan B's two levels, then Plan C again.  The two passes do not depend on
+        // each other, so the (cheap) phased Plan A / Plan B attempts run first; when they find nothing the one
+        // Plan-C pass below serves both halves instead of being computed twice.
+        bool phased_done = false;
         if (two_pass) {
-          // the phased pass starts over on the REDUCED phases (impute.py:1645-1654): Plan A with the
-          // subject's prior, Plan B's two levels, Plan C again
           double mx2 = 0.0;
           pb_absent(A, sh, st, tok);
           plan_haps = 'a';
@@ -772,17 +768,23 @@ __global__ __launch_bounds__(GRIM_WG, 2) void grim_plan_b_kernel(DevArgs A) {
             nH = pb_levels(A, sh, S, wt, st, tok, &mx2);
           }
           STAMP(6);
-          if (!nH && !A.prm.em) {
-            plan_haps = 'c';
-            nH = pb_plan_c(A, sh, S, wt, st, tok, &mx2);
-          }
-          STAMP(4);
           if (nH) {
             emit_tables(A, sh, S, nH, sh.out, 2u);
             status = GRIM_ST_OK;
+            phased_done = true;
+          } else if (!A.prm.em) {
+            plan_haps = 'c';
           }
           STAMP(7);
         }
+        nU = pb_plan_c(A, sh, S, wt, st, tok, &mx);
+        STAMP(4);
+        if (nU) {
+          const uint32_t halves = !two_pass ? 3u : (phased_done || A.prm.em) ? 1u : 3u;
+          emit_tables(A, sh, S, nU, sh.out, halves);
+          status = GRIM_ST_OK;
+        }
+        STAMP(3);
       }
     }
     __syncthreads();
