@@ -72,7 +72,7 @@ struct DevArgs {
   const uint32_t *order;  // subject indices this launch works on
   uint32_t n_work;
   uint32_t *queue;        // [0] general work counter [1] row head [2] plan-B list length [3] plan-B work counter
-                          // [4] one-wave kernel work counter [5] its hand-over count
+                          // [4] one-wave kernel work counter [5] its hand-over count [6] heavy plan-B subjects
   grim_subject_result *res;
   grim_row *rows;
   uint32_t *row_head;
@@ -83,9 +83,19 @@ struct DevArgs {
   uint32_t *small_ctr;           // half-wave kernel: per wave {probes, frequency vectors}, plain stores; summed on request
   unsigned long long *counters;  // [0] probes [1] nbr ids [2] freq vectors [3] rows [4] overflow flag
   uint32_t *bail_list;           // subjects the one-wave kernel hands to the general kernel (count: queue[5])
-  uint32_t *next_list;           // subjects handed to the next kernel (plan B)
-  uint32_t *next_count;
+  uint32_t *next_list;           // subjects handed to the next kernel (plan B): light ones from the front
+  uint32_t *next_count;          // (count queue[2]), heavy ones from the back (count queue[6]) -- heavy first
+  uint32_t next_cap;             // entries in next_list
 };
+
+// hand a subject to the Plan-B kernel.  Subjects with few typed loci (their sides saturate the top lists: tens
+// of thousands of pairs) go to the head of its queue so that they do not start last and become the tail.
+__device__ __forceinline__ void push_next(const DevArgs &A, uint32_t si, bool heavy) {
+  if (heavy)
+    A.next_list[A.next_cap - 1u - atomicAdd(A.queue + 6, 1u)] = si;
+  else
+    A.next_list[atomicAdd(A.next_count, 1u)] = si;
+}
 
 // ---- optional stage timers (diagnostic build only: hipcc -DGRIM_STAMPS; never in the shipped .so) ----
 #define GRIM_NCTR (8 + 4 * 64 + 16)

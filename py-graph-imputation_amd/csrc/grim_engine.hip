@@ -94,7 +94,7 @@ __global__ __launch_bounds__(GRIM_WG, 2) void grim_plan_a_kernel(DevArgs A) {
       } else if (A.prm.planb) {
         status = GRIM_ST_UNSUPPORTED;  // replaced by the plan-B kernel's verdict when it runs
         reason = 2;
-        if (tid == 0 && A.next_list) A.next_list[atomicAdd(A.next_count, 1u)] = si;
+        if (tid == 0 && A.next_list) push_next(A, si, sh.subj.n_loci <= 3);
       }
     }
     __syncthreads();
@@ -447,6 +447,7 @@ extern "C" grim_batch *grim_batch_upload(grim_ctx *c, const grim_graph *g, const
   b->hstate = nullptr;
   if (hipHostMalloc((void **)&b->hstate, 8 * (GRIM_NCTR + 4)) != hipSuccess) b->hstate = nullptr;
   A.next_list = upload<uint32_t>(c, b->bufs, nullptr, d->n_subjects, &bytes);
+  A.next_cap = d->n_subjects;
   A.res = upload<grim_subject_result>(c, b->bufs, nullptr, d->n_subjects, &bytes);
   // rows: enough for every subject to fill all four tables
   uint64_t per = 2ull * p->n_results + 2ull * (p->n_pop_results < (uint64_t)P * P ? p->n_pop_results : (uint64_t)P * P);
@@ -596,9 +597,9 @@ extern "C" int grim_batch_run(grim_batch *b) {
   uint32_t head[8];
   memcpy(head, b->hstate + GRIM_NCTR, 32);
   // ---- stage 2: Plan B / C only when the first stage left subjects for it ------------------------
-  if (A.prm.planb && head[2] > 0) {
+  if (A.prm.planb && head[2] + head[6] > 0) {
     HIPCHK(hipEventRecord(b->ev[4], c->stream), c, -1);
-    uint32_t grid = b->n_slots < head[2] ? b->n_slots : head[2];
+    uint32_t grid = b->n_slots < head[2] + head[6] ? b->n_slots : head[2] + head[6];
     if (grim_launch_plan_b(A, grid, c->stream) != 0) { c->err = "plan-B launch failed"; return -1; }
     HIPCHK(hipEventRecord(b->ev[2], c->stream), c, -1);
     HIPCHK(hipMemcpyAsync(b->hstate, A.counters, 8 * (GRIM_NCTR + 4), hipMemcpyDeviceToHost, c->stream), c, -1);

@@ -348,7 +348,7 @@ __device__ inline int medium_subject(const DevArgs &A, WaveMed &M, uint32_t si) 
   } else if (A.prm.planb) {
     out.status = GRIM_ST_UNSUPPORTED;  // replaced by the plan-B kernel's verdict
     out.reason = 2;
-    if (lane == 0) A.next_list[atomicAdd(A.next_count, 1u)] = si;
+    if (lane == 0) push_next(A, si, n <= 3);
   } else {
     out.status = GRIM_ST_MISS;
   }

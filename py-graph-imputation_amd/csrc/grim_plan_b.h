@@ -698,14 +698,14 @@ __global__ __launch_bounds__(GRIM_WG, 2) void grim_plan_b_kernel(DevArgs A) {
   __shared__ PbState st;
   const int tid = threadIdx.x;
   const int P = A.g.P;
-  const uint32_t n_work = *A.next_count;
+  const uint32_t n_heavy = A.queue[6], n_work = *A.next_count + n_heavy;
   Slot S = make_slot(A, blockIdx.x);
   for (;;) {
     if (tid == 0) sh.bc[3] = atomicAdd(A.queue + 3, 1u);  // own counter: no reset between kernels
     __syncthreads();
     const uint32_t w = sh.bc[3];
     if (w >= n_work) break;
-    const uint32_t si = A.next_list[w];
+    const uint32_t si = w < n_heavy ? A.next_list[A.next_cap - 1u - w] : A.next_list[w - n_heavy];  // heavy ones first
     if (tid < 16) ((uint32_t *)&sh.subj)[tid] = ((const uint32_t *)&A.subj[si])[tid];
     if (tid < (int)(sizeof(grim_subject_result) / 4)) ((uint32_t *)&sh.out)[tid] = 0;
     if (tid == 0) sh.reduced = 0;

@@ -209,7 +209,7 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_a_small_kernel(DevArgs A, c
     if (A.prm.planb) {
       out.status = GRIM_ST_UNSUPPORTED;  // overwritten by the plan-B kernel
       out.reason = 2;
-      A.next_list[atomicAdd(A.next_count, 1u)] = si;
+      push_next(A, si, false);  // every locus typed: never a heavy one
     } else {
       out.status = GRIM_ST_MISS;
     }
