@@ -607,6 +607,9 @@ extern "C" int grim_batch_run(grim_batch *b) {
     HIPCHK(hipEventElapsedTime(&b->ms_b, b->ev[4], b->ev[2]), c, -1);
     memcpy(head, b->hstate + GRIM_NCTR, 32);
   }
+  if (getenv("GRIM_DEBUG_CLASSES"))
+    fprintf(stderr, "grim classes: small %u medium %u general %u | medium->general %u, to plan B %u (+%u heavy)\n", b->n_small,
+            b->n_medium, b->n_general, head[5], head[2], head[6]);
   memcpy(b->counters, b->hstate, 64);
   b->small_ctr_pending = b->n_small > 0;
   for (int sh = 0; sh < 64; ++sh)
