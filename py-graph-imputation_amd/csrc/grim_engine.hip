@@ -4,6 +4,7 @@
 // (-ffp-contract=off is REQUIRED: an fma in P1*P2*prior would change the last bit and with it
 //  rankings that the reference decides on exact ties).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -161,10 +162,13 @@ struct grim_batch {
   uint32_t *order_s, *order_g, *order_m;  // subjects of the half-wave / general / one-wave kernels
   uint32_t n_medium;
   uint32_t n_small, n_general, small_stride;
-  hipEvent_t ev[5];
+  hipEvent_t ev[8];  // timing mode, kernel start/stop: [3]/[5] half-wave, [0]/[1] one-wave, [6]/[7] general, [4]/[2] Plan B
+  bool timing;       // GRIM_TIMING=1 or grim_batch_set_timing: direct launches with per-kernel events instead of the graph replay
   hipGraphExec_t gexec;
   int graph_state;  // 0 not tried, 1 captured, -1 direct launches
-  float ms_a, ms_b, ms_s;
+  float ms_a, ms_b, ms_s, ms_g, ms_m;
+  double acc_ms[6];   // sums over the timed runs since timing was switched on (index = `which`)
+  uint32_t n_timed;
   uint32_t rows_used;
   unsigned long long counters[8];
 };
@@ -517,7 +521,8 @@ extern "C" grim_batch *grim_batch_upload(grim_ctx *c, const grim_graph *g, const
   bool ok = A.subj && A.tok && A.priors && b->order_s && b->order_g && b->order_m && A.bail_list && b->small_recs && b->hstate && A.queue && A.next_list && A.res && A.counters && A.rows && A.scratch;
   b->gexec = nullptr;
   b->graph_state = 0;
-  for (int i = 0; i < 5 && ok; ++i) ok = hipEventCreate(&b->ev[i]) == hipSuccess;
+  for (int i = 0; i < 8 && ok; ++i) ok = hipEventCreate(&b->ev[i]) == hipSuccess;
+  b->timing = getenv("GRIM_TIMING") && atoi(getenv("GRIM_TIMING")) != 0;
   if (!ok) {
     c->err = "grim_batch_upload: device allocation or copy failed (" + std::to_string((unsigned long long)(L.stride * slots >> 20)) + " MiB scratch)";
     for (void *q : b->bufs) hipFree(q);
@@ -527,34 +532,53 @@ extern "C" grim_batch *grim_batch_upload(grim_ctx *c, const grim_graph *g, const
   return b;
 }
 
-// Stage 1 of a run: reset, half-wave kernel, general plan-A kernel, state read-back.  Enqueued
-// either directly or into a stream capture (the sequence is replayed as one hipGraph launch).
-static int enqueue_stage1(grim_batch *b) {
+// Stage 1 of a run: reset, half-wave kernel, one-wave kernel, general plan-A kernel, state read-back.
+// Default: launched directly (three API calls and the state copy).  GRIM_GRAPH=1: captured once per batch and
+// replayed as ONE hipGraph launch (no event nodes: they carry no timestamps when replayed on this runtime).
+// Timing mode: launched directly, every kernel bracketed by its own start/stop events (hipExtLaunchKernelGGL).
+static int enqueue_stage1(grim_batch *b, bool timing) {
   grim_ctx *c = b->ctx;
   DevArgs &A = b->a;
   hipLaunchKernelGGL(grim_reset_kernel, dim3(1), dim3(GRIM_WG), 0, c->stream, A.counters, A.queue,
                      b->n_small * b->small_stride);
-  HIPCHK(hipEventRecord(b->ev[0], c->stream), c, -1);
   if (b->n_small) {
     uint32_t per_block = GRIM_WG / 32;
-    hipLaunchKernelGGL(grim_plan_a_small_kernel, dim3((b->n_small + per_block - 1) / per_block), dim3(GRIM_WG), 0, c->stream,
-                       A, (const SmallRec *)b->small_recs, b->n_small, 0u, b->small_stride);
+    const dim3 grid((b->n_small + per_block - 1) / per_block), block(GRIM_WG);
+    if (timing)
+      hipExtLaunchKernelGGL(grim_plan_a_small_kernel, grid, block, 0, c->stream, b->ev[3], b->ev[5], 0, A,
+                            (const SmallRec *)b->small_recs, b->n_small, 0u, b->small_stride);
+    else
+      hipLaunchKernelGGL(grim_plan_a_small_kernel, grid, block, 0, c->stream, A, (const SmallRec *)b->small_recs, b->n_small, 0u,
+                         b->small_stride);
   }
-  HIPCHK(hipEventRecord(b->ev[3], c->stream), c, -1);
   if (b->n_medium) {
     static const int waves_per_cu = getenv("GRIM_MEDIUM_WAVES") ? atoi(getenv("GRIM_MEDIUM_WAVES")) : GRIM_MEDIUM_WAVES_PER_CU;
     uint32_t grid = (uint32_t)c->n_cu * (uint32_t)(waves_per_cu > 0 ? waves_per_cu : GRIM_MEDIUM_WAVES_PER_CU);
     if (grid > b->n_medium) grid = b->n_medium;
-    hipLaunchKernelGGL(grim_plan_a_medium_kernel, dim3(grid), dim3(64), 0, c->stream, A, (const uint32_t *)b->order_m,
-                       b->n_medium, A.bail_list);
+    if (timing)
+      hipExtLaunchKernelGGL(grim_plan_a_medium_kernel, dim3(grid), dim3(64), 0, c->stream, b->ev[0], b->ev[1], 0, A,
+                            (const uint32_t *)b->order_m, b->n_medium, A.bail_list);
+    else
+      hipLaunchKernelGGL(grim_plan_a_medium_kernel, dim3(grid), dim3(64), 0, c->stream, A, (const uint32_t *)b->order_m,
+                         b->n_medium, A.bail_list);
   }
   if (b->n_general + b->n_medium) {
     uint32_t want = b->n_general + b->n_medium;
-    uint32_t grid = b->n_slots < want ? b->n_slots : want;
-    hipLaunchKernelGGL(grim_plan_a_kernel, dim3(grid), dim3(GRIM_WG), 0, c->stream, A);
+    const dim3 grid(b->n_slots < want ? b->n_slots : want), block(GRIM_WG);
+    if (timing)
+      hipExtLaunchKernelGGL(grim_plan_a_kernel, grid, block, 0, c->stream, b->ev[6], b->ev[7], 0, A);
+    else
+      hipLaunchKernelGGL(grim_plan_a_kernel, grid, block, 0, c->stream, A);
   }
-  HIPCHK(hipEventRecord(b->ev[1], c->stream), c, -1);
   HIPCHK(hipMemcpyAsync(b->hstate, A.counters, 8 * (GRIM_NCTR + 4), hipMemcpyDeviceToHost, c->stream), c, -1);
+  return 0;
+}
+
+extern "C" int grim_batch_set_timing(grim_batch *b, int on) {
+  if (!b) return -1;
+  b->timing = on != 0;
+  memset(b->acc_ms, 0, sizeof(b->acc_ms));
+  b->n_timed = 0;
   return 0;
 }
 
@@ -564,52 +588,62 @@ extern "C" int grim_batch_run(grim_batch *b) {
   hipSetDevice(c->device);
   DevArgs &A = b->a;
   // ---- stage 1 (captured once per batch, then replayed: one API call instead of eight) ----------
-  if (b->graph_state == 0) {
-    b->graph_state = -1;
-    if (!getenv("GRIM_NO_GRAPH") && hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-      int rc = enqueue_stage1(b);
-      hipGraph_t gr = nullptr;
-      hipError_t e = hipStreamEndCapture(c->stream, &gr);
-      if (rc == 0 && e == hipSuccess && gr && hipGraphInstantiate(&b->gexec, gr, nullptr, nullptr, 0) == hipSuccess)
-        b->graph_state = 1;
-      if (gr) hipGraphDestroy(gr);
-      (void)hipGetLastError();
-    }
-  }
-  if (b->graph_state == 1) {
-    HIPCHK(hipGraphLaunch(b->gexec, c->stream), c, -1);
-  } else {
-    if (enqueue_stage1(b) != 0) return -1;
+  b->ms_s = b->ms_a = b->ms_g = b->ms_m = 0;
+  if (b->timing) {
+    if (enqueue_stage1(b, true) != 0) return -1;
     HIPCHK(hipGetLastError(), c, -1);
-  }
-  HIPCHK(hipStreamSynchronize(c->stream), c, -1);
-  if (hipEventElapsedTime(&b->ms_s, b->ev[0], b->ev[3]) != hipSuccess || hipEventElapsedTime(&b->ms_a, b->ev[0], b->ev[1]) != hipSuccess) {
-    // event nodes of a replayed graph carry no timestamps on this runtime: fall back to direct launches
-    (void)hipGetLastError();
-    if (b->graph_state == 1) {
+    HIPCHK(hipStreamSynchronize(c->stream), c, -1);
+    if (b->n_small) HIPCHK(hipEventElapsedTime(&b->ms_s, b->ev[3], b->ev[5]), c, -1);
+    if (b->n_medium) HIPCHK(hipEventElapsedTime(&b->ms_m, b->ev[0], b->ev[1]), c, -1);
+    if (b->n_general + b->n_medium) HIPCHK(hipEventElapsedTime(&b->ms_g, b->ev[6], b->ev[7]), c, -1);
+    b->ms_a = b->ms_s + b->ms_m + b->ms_g;
+  } else {
+    if (b->graph_state == 0) {
       b->graph_state = -1;
-      return grim_batch_run(b);
+      // measured on MI355X / ROCm 7.2 (tools/step_time.py, 10k-subject batch): replaying the captured stage costs
+      // 31.7 us per synchronous run, launching its three nodes directly 27.2 us -- so the replay is opt-in
+      if (getenv("GRIM_GRAPH") && atoi(getenv("GRIM_GRAPH")) != 0 &&
+          hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        int rc = enqueue_stage1(b, false);
+        hipGraph_t gr = nullptr;
+        hipError_t e = hipStreamEndCapture(c->stream, &gr);
+        if (rc == 0 && e == hipSuccess && gr && hipGraphInstantiate(&b->gexec, gr, nullptr, nullptr, 0) == hipSuccess)
+          b->graph_state = 1;
+        if (gr) hipGraphDestroy(gr);
+        (void)hipGetLastError();
+      }
     }
-    c->err = "grim_batch_run: hipEventElapsedTime failed";
-    return -1;
+    if (b->graph_state == 1) {
+      HIPCHK(hipGraphLaunch(b->gexec, c->stream), c, -1);
+    } else {
+      if (enqueue_stage1(b, false) != 0) return -1;
+      HIPCHK(hipGetLastError(), c, -1);
+    }
+    HIPCHK(hipStreamSynchronize(c->stream), c, -1);
   }
   b->ms_b = 0;
   uint32_t head[8];
   memcpy(head, b->hstate + GRIM_NCTR, 32);
   // ---- stage 2: Plan B / C only when the first stage left subjects for it ------------------------
   if (A.prm.planb && head[2] + head[6] > 0) {
-    HIPCHK(hipEventRecord(b->ev[4], c->stream), c, -1);
     uint32_t grid = b->n_slots < head[2] + head[6] ? b->n_slots : head[2] + head[6];
-    if (grim_launch_plan_b(A, grid, c->stream) != 0) { c->err = "plan-B launch failed"; return -1; }
-    HIPCHK(hipEventRecord(b->ev[2], c->stream), c, -1);
+    if (grim_launch_plan_b(A, grid, c->stream, b->timing ? b->ev[4] : nullptr, b->timing ? b->ev[2] : nullptr) != 0) {
+      c->err = "plan-B launch failed";
+      return -1;
+    }
     HIPCHK(hipMemcpyAsync(b->hstate, A.counters, 8 * (GRIM_NCTR + 4), hipMemcpyDeviceToHost, c->stream), c, -1);
     HIPCHK(hipStreamSynchronize(c->stream), c, -1);
-    HIPCHK(hipEventElapsedTime(&b->ms_b, b->ev[4], b->ev[2]), c, -1);
+    if (b->timing) HIPCHK(hipEventElapsedTime(&b->ms_b, b->ev[4], b->ev[2]), c, -1);
     memcpy(head, b->hstate + GRIM_NCTR, 32);
   }
+  if (b->timing) {
+    const double v[6] = {(double)b->ms_a + b->ms_b, b->ms_a, b->ms_b, b->ms_s, b->ms_g, b->ms_m};
+    for (int k = 0; k < 6; ++k) b->acc_ms[k] += v[k];
+    b->n_timed++;
+  }
   if (getenv("GRIM_DEBUG_CLASSES"))
-    fprintf(stderr, "grim classes: small %u medium %u general %u | medium->general %u, to plan B %u (+%u heavy)\n", b->n_small,
-            b->n_medium, b->n_general, head[5], head[2], head[6]);
+    fprintf(stderr, "grim classes: small %u medium %u general %u | medium->general %u, to plan B %u (+%u heavy) | stage 1 %s\n",
+            b->n_small, b->n_medium, b->n_general, head[5], head[2], head[6], b->graph_state == 1 ? "replayed as a hipGraph" : "launched directly");
   memcpy(b->counters, b->hstate, 64);
   b->small_ctr_pending = b->n_small > 0;
   for (int sh = 0; sh < 64; ++sh)
@@ -629,9 +663,15 @@ extern "C" int grim_batch_run(grim_batch *b) {
 
 extern "C" double grim_batch_kernel_ms(const grim_batch *b, int which) {
   if (!b) return 0.0;
+  if (which & 0x10) {  // mean over the timed runs since grim_batch_set_timing(b, 1)
+    const int k = which & 0xF;
+    return (k < 6 && b->n_timed) ? b->acc_ms[k] / b->n_timed : 0.0;
+  }
   if (which == 1) return b->ms_a;
   if (which == 2) return b->ms_b;
   if (which == 3) return b->ms_s;
+  if (which == 4) return b->ms_g;
+  if (which == 5) return b->ms_m;
   return (double)b->ms_a + (double)b->ms_b;
 }
 
@@ -670,7 +710,7 @@ extern "C" int grim_batch_results(grim_batch *b, grim_subject_result *res, grim_
 extern "C" void grim_batch_free(grim_batch *b) {
   if (!b) return;
   hipSetDevice(b->ctx->device);
-  for (int i = 0; i < 5; ++i) hipEventDestroy(b->ev[i]);
+  for (int i = 0; i < 8; ++i) hipEventDestroy(b->ev[i]);
   if (b->gexec) hipGraphExecDestroy(b->gexec);
   for (void *p : b->bufs) hipFree(p);
   if (b->hstate) hipHostFree(b->hstate);

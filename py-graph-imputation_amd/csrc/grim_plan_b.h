@@ -800,8 +800,11 @@ __global__ __launch_bounds__(GRIM_WG, 2) void grim_plan_b_kernel(DevArgs A) {
   }
 }
 
-static int grim_launch_plan_b(DevArgs &A, uint32_t n_slots, hipStream_t stream) {
+static int grim_launch_plan_b(DevArgs &A, uint32_t n_slots, hipStream_t stream, hipEvent_t start, hipEvent_t stop) {
   // the plan-A kernels leave the list of subjects in next_list/next_count
-  hipLaunchKernelGGL(grim_plan_b_kernel, dim3(n_slots), dim3(GRIM_WG), 0, stream, A);
+  if (start && stop)
+    hipExtLaunchKernelGGL(grim_plan_b_kernel, dim3(n_slots), dim3(GRIM_WG), 0, stream, start, stop, 0, A);
+  else
+    hipLaunchKernelGGL(grim_plan_b_kernel, dim3(n_slots), dim3(GRIM_WG), 0, stream, A);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -132,6 +132,8 @@ def lib():
     L.grim_batch_results.restype = C.c_int
     L.grim_batch_results.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.grim_batch_free.argtypes = [C.c_void_p]
+    L.grim_batch_set_timing.restype = C.c_int
+    L.grim_batch_set_timing.argtypes = [C.c_void_p, C.c_int]
     _lib = L
     return L
 
@@ -139,7 +141,7 @@ def lib():
 EXPORTS = [
     "grim_create", "grim_destroy", "grim_last_error", "grim_device_count", "grim_graph_upload", "grim_graph_free",
     "grim_graph_device_bytes", "grim_batch_upload", "grim_batch_run", "grim_batch_kernel_ms", "grim_batch_counters",
-    "grim_batch_total_rows", "grim_batch_results", "grim_batch_free",
+    "grim_batch_total_rows", "grim_batch_results", "grim_batch_free", "grim_batch_set_timing",
 ]
 
 
@@ -248,6 +250,10 @@ class DeviceBatch:
         rc = lib().grim_batch_run(self.h)
         if rc != 0:
             raise NativeError("grim_batch_run failed (%d): %s" % (rc, self.ctx.error()))
+
+    def set_timing(self, on=True):
+        """start/stop hipEvents around every kernel of a run (resets the accumulated means); see grim_batch_set_timing"""
+        lib().grim_batch_set_timing(self.h, 1 if on else 0)
 
     def kernel_ms(self, which=0):
         return float(lib().grim_batch_kernel_ms(self.h, which))

@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import harness, 
 sys.path.insert(0, harness.ROOT)
 import numpy as np
 os.environ["GRIM_QUIET"] = "1"
+os.environ.setdefault("GRIM_TIMING", "1")  # per-kernel events
 import grim.imputation.impute as I
 rows = synth.read_freqs(synth.CAU_FREQS)
 gen = synth.SubjectGen(rows, 5, pops=["CAU"])

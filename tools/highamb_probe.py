@@ -4,6 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import harness, synth
 sys.path.insert(0, harness.ROOT)
 os.environ["GRIM_QUIET"] = "1"
+os.environ.setdefault("GRIM_TIMING", "1")  # per-kernel events
 rows = synth.read_freqs(synth.CAU_FREQS)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 lines = synth.SubjectGen(rows, 50).high_ambiguity(n, width=8)

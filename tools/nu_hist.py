@@ -3,6 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import harness, 
 sys.path.insert(0, harness.ROOT)
 import numpy as np
 os.environ["GRIM_QUIET"]="1"
+os.environ.setdefault("GRIM_TIMING", "1")
 rows = synth.read_freqs(synth.CAU_FREQS)
 for pops, gname in ((["CAU"], "cau"), (harness.POPS["pop4"], "pop4")):
     gen = synth.SubjectGen(rows, 5, pops=pops)

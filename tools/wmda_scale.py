@@ -62,6 +62,7 @@ def main():
     import __graft_entry__ as ge
     ge.build()
     os.environ["GRIM_QUIET"] = "1"
+    os.environ.setdefault("GRIM_TIMING", "1")  # per-kernel events
     name = "wmda%d" % n_haps
     work = os.path.join(harness.WORK, name)
     t0 = time.time()
