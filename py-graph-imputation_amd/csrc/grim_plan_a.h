@@ -7,6 +7,11 @@
 #pragma once
 #include "grim_pair.h"
 
+// A side is opened by walking its label instead of probing its cartesian product when the product has more
+// than half as many candidates as the label has nodes: measured on 512 subjects with w alternatives per locus
+// and side on the CAU graph (3 380 full haplotypes, tools/highamb_probe.py), probing costs 0.76 / 1.68 / 3.35 ms
+// at w = 5 / 6 / 7 (3 125 / 7 776 / 16 807 candidates per side), walking the label 0.44 - 0.57 ms at any w.
+
 // phases kept by gen_phases: pattern bit l set = position l takes side-2's allele list for H1.
 // same_mask bit l set = the two side STRINGS of position l are identical (flipping is a no-op).
 __device__ inline void enumerate_phases(WgShared &sh) {
@@ -293,7 +298,7 @@ __device__ inline void build_side_plan_a(const DevArgs &A, WgShared &sh, const S
     // (coalesced key stream, one LDS bit per position) and give each hit its position in the cartesian
     // order; the ranked top-K then yields the list the in-order probe stream would.
     const uint32_t la = g.lab_start[mask], lb = g.lab_start[mask + 1];
-    const bool intersect = g.scan_ok && in_lds && ncand >= 2048u && ncand < (1u << 28) && (uint64_t)ncand > 8ull * (lb - la);
+    const bool intersect = g.scan_ok && in_lds && ncand >= 1024u && ncand < (1u << 28) && 2ull * ncand > (uint64_t)(lb - la);
     if (intersect) {
       st.ge = true;
       for (uint32_t i0 = la; i0 < lb; i0 += 64) {
