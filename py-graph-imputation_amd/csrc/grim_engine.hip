@@ -257,8 +257,10 @@ extern "C" grim_graph *grim_graph_upload(grim_ctx *c, const grim_graph_desc *d) 
   g->ctx = c;
   g->bytes = 0;
   // exact-name index: open addressing over the 64-bit node keys
+  // load <= 0.5; a graph whose index is far beyond the L2 anyway (every probe is a memory round trip, and the
+  // rounds of linear probing are what a 64-lane wave waits for) gets load <= 0.25
   uint32_t cap = 64;
-  while (cap < 2 * (uint64_t)d->n_nodes) cap <<= 1;
+  while (cap < (d->n_nodes > (1u << 18) ? 4 : 2) * (uint64_t)d->n_nodes) cap <<= 1;
   std::vector<uint64_t> hk(cap, 0);
   std::vector<uint32_t> hv(cap, 0);
   bool unique_names = true;

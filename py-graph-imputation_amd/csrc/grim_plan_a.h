@@ -353,21 +353,51 @@ __device__ inline void build_side_plan_a(const DevArgs &A, WgShared &sh, const S
           }
         }
       }
+      uint32_t hq[NQ], nodeq[NQ];
+      bool pend[NQ];
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) entq[q] = g.ht[(uint32_t)mix64(keyq[q]) & g.ht_mask];
+      for (int q = 0; q < NQ; ++q) {
+        hq[q] = (uint32_t)mix64(keyq[q]) & g.ht_mask;
+        entq[q] = g.ht[hq[q]];
+      }
+      // Resolve the NQ chunks together: a lane whose slot holds another key walks on (linear probing), and with
+      // 64 lanes per chunk some lane almost always does.  The follow-up probes of ALL chunks are issued before
+      // any is waited for -- one memory round trip per probing round instead of one per round and chunk.
+      bool any_pending = false;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const bool valid = c0 + 64u * q + lane < ncand;
+        nodeq[q] = (valid && entq[q].key == keyq[q]) ? entq[q].val : GRIM_NONE;
+        pend[q] = valid && entq[q].key != keyq[q] && entq[q].key != 0;
+        any_pending |= pend[q];
+      }
+      while (__ballot(any_pending)) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+          if (pend[q]) {
+            hq[q] = (hq[q] + 1) & g.ht_mask;
+            entq[q] = g.ht[hq[q]];
+          }
+        any_pending = false;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+          if (pend[q]) {
+            if (entq[q].key == keyq[q]) {
+              nodeq[q] = entq[q].val;
+              pend[q] = false;
+            } else if (entq[q].key == 0) {
+              pend[q] = false;
+            }
+            any_pending |= pend[q];
+          }
+      }
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         const uint32_t cq = c0 + 64u * q;
         if (cq >= ncand) break;
-        const uint32_t c = cq + lane;
-        uint32_t node = GRIM_NONE;
-        if (c < ncand) {
-          if (entq[q].key == keyq[q]) node = entq[q].val;
-          else if (entq[q].key != 0) node = graph_lookup_from(g, keyq[q], (((uint32_t)mix64(keyq[q]) & g.ht_mask) + 1) & g.ht_mask);
-        }
         c_probe += (ncand - cq) < 64 ? (ncand - cq) : 64;
-        if (__ballot(node != GRIM_NONE) == 0) continue;  // nothing found in this chunk (the usual case)
-        expand_chunk<false>(A, prior, L, st, node, full_nodes, g.a_start, g.a_nbr, 1.0, 0, item_base, c_nbr, c_freq);
+        if (__ballot(nodeq[q] != GRIM_NONE) == 0) continue;  // nothing found in this chunk (the usual case)
+        expand_chunk<false>(A, prior, L, st, nodeq[q], full_nodes, g.a_start, g.a_nbr, 1.0, 0, item_base, c_nbr, c_freq);
       }
     }
   } else {
