@@ -18,12 +18,10 @@
 
 // ---- graph as the kernels see it --------------------------------------------------------------
 // full-label nodes only, with the first population's frequency inline: the half-wave kernel's
-// whole look-up is one 32-byte entry (grim_small.h)
+// whole look-up is one 16-byte entry (grim_small.h)
 struct FullEnt {
   uint64_t key;
-  uint64_t node;
   double f0;
-  double reserved;
 };
 
 struct HtEnt {

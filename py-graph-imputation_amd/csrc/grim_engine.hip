@@ -260,7 +260,8 @@ extern "C" grim_graph *grim_graph_upload(grim_ctx *c, const grim_graph_desc *d) 
   // load <= 0.5; a graph whose index is far beyond the L2 anyway (every probe is a memory round trip, and the
   // rounds of linear probing are what a 64-lane wave waits for) gets load <= 0.25
   uint32_t cap = 64;
-  while (cap < (d->n_nodes > (1u << 18) ? 4 : 2) * (uint64_t)d->n_nodes) cap <<= 1;
+  static const int ht_factor = getenv("GRIM_HT_FACTOR") ? atoi(getenv("GRIM_HT_FACTOR")) : 0;
+  while (cap < (uint64_t)(ht_factor > 1 ? ht_factor : (d->n_nodes > (1u << 18) ? 4 : 2)) * (uint64_t)d->n_nodes) cap <<= 1;
   std::vector<uint64_t> hk(cap, 0);
   std::vector<uint32_t> hv(cap, 0);
   bool unique_names = true;
@@ -317,7 +318,11 @@ extern "C" grim_graph *grim_graph_upload(grim_ctx *c, const grim_graph_desc *d) 
   {  // full-haplotype table
     uint32_t nfull = d->lab_start[d->full_mask + 1] - d->lab_start[d->full_mask];
     uint32_t fcap = 64;
-    while (fcap < 2 * (uint64_t)nfull) fcap <<= 1;
+    // load <= 1/8: every lane of a wave probes at once and the wave waits for its unluckiest lane, so the
+    // number of linear-probing rounds matters more than the table's footprint (1 MB for the CAU graph);
+    // measured on the bench kernel: 10.8 / 8.8 / 8.2 / 8.5 us at load 1/2, 1/4, 1/8, 1/16
+    static const int fht_factor = getenv("GRIM_FHT_FACTOR") ? atoi(getenv("GRIM_FHT_FACTOR")) : 8;
+    while (fcap < (uint64_t)(fht_factor > 1 ? fht_factor : 2) * (uint64_t)nfull) fcap <<= 1;
     std::vector<FullEnt> ft(fcap);
     memset(ft.data(), 0, sizeof(FullEnt) * fcap);
     for (uint32_t i = 0; i < d->n_nodes; ++i) {
@@ -326,7 +331,6 @@ extern "C" grim_graph *grim_graph_upload(grim_ctx *c, const grim_graph_desc *d) 
       uint32_t h = (uint32_t)host_mix64(k) & (fcap - 1);
       while (ft[h].key != 0 && ft[h].key != k) h = (h + 1) & (fcap - 1);
       ft[h].key = k;
-      ft[h].node = i;
       ft[h].f0 = d->freq[(size_t)i * d->n_pops];
     }
     D.fht = upload(c, g->bufs, ft.data(), fcap, &g->bytes);

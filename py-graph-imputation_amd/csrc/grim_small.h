@@ -63,7 +63,7 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_a_small_kernel(DevArgs A, c
 #pragma unroll
   for (int i = 0; i < 8; ++i) lad[i] = A.prm.ladder[i];
   // ---- candidate of this lane: one 32-byte record (same address for the half wave), one probe ----
-  uint32_t node = GRIM_NONE;
+  bool hit = false;  // this lane's combination is a haplotype of the graph
   uint64_t mykey = 0;
   double f = 0.0;
   uint32_t same = 0, si = 0;
@@ -86,20 +86,20 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_a_small_kernel(DevArgs A, c
     uint32_t h = (uint32_t)mix64(mykey) & g.fht_mask;
     for (;;) {
       const FullEnt e = g.fht[h];
-      if (e.key == mykey) { node = (uint32_t)e.node; f = e.f0; break; }
+      if (e.key == mykey) { hit = true; f = e.f0; break; }
       if (e.key == 0) break;
       h = (h + 1) & g.fht_mask;
     }
   }
   // ---- phases: lane i < 16 is phase i, its partner is the complementary combination ---------
-  const uint32_t node2 = half_shfl_u(node, hl ^ 31);
+  const bool hit2 = half_shfl_u(hit ? 1u : 0u, hl ^ 31) != 0;
   const double f2 = half_shfl_d(f, hl ^ 31);
   const uint64_t key2 = ((uint64_t)half_shfl_u((uint32_t)(mykey >> 32), hl ^ 31) << 32) | half_shfl_u((uint32_t)mykey, hl ^ 31);
   const uint32_t het4 = 15u & ~same;
   bool kept = hl < 16 && ((uint32_t)hl & ~het4 & 15u) == 0 && (!((same >> 4) & 1u) || ((uint32_t)hl ^ het4) >= (uint32_t)hl);
   // entries need p > 0 (impute.py:430); a missing node has f == 0
   const bool pair_ok = live && kept && f > 0.0 && f2 > 0.0;
-  const bool same_hap = node == node2;
+  const bool same_hap = mykey == key2;  // names are unique: same key, same haplotype
   PairRef pr;
   pr.p1 = f; pr.p2 = f2; pr.m2 = f2;
   pr.e1 = same_hap ? 0u : 1u; pr.e2 = 0u;  // only equality of the two haplotypes matters below
@@ -159,8 +159,8 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_a_small_kernel(DevArgs A, c
   // its own cell (atomics on shared cells serialised at the L2 and cost a third of the kernel).
   {
     // a kept phase looks up its two sides; combinations of dropped (duplicate) phases do not count
-    const uint64_t need = __ballot(live && kept), needp = __ballot(live && kept && node != GRIM_NONE),
-                   needq = __ballot(live && kept && node2 != GRIM_NONE);
+    const uint64_t need = __ballot(live && kept), needp = __ballot(live && kept && hit),
+                   needq = __ballot(live && kept && hit2);
     if ((threadIdx.x & 63) == 0) {
       const uint32_t gw = blockIdx.x * (GRIM_WG / 64) + (threadIdx.x >> 6);
       *(uint2 *)(A.small_ctr + 2 * gw) = make_uint2(2u * (uint32_t)__popcll(need), (uint32_t)(__popcll(needp) + __popcll(needq)));
