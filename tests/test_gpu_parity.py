@@ -241,3 +241,27 @@ def test_label_scan_heavy_workload_vs_oracle(threshold):
     conf4 = dict(harness.base_conf(harness.POPS["pop4"]), number_of_options_threshold=threshold, UNK_priors="MR")
     lines4 = synth.SubjectGen(rows, 62, pops=harness.POPS["pop4"]).mixed(300, amb=0.7, miss=0.1, recomb=0.5)
     _against_oracle("pop4", conf4, lines4, "scan4_%d" % threshold)
+
+
+def test_empty_and_degenerate_inputs():
+    """an empty subject file, a file of blank / unparsable lines only, and a single subject: no device work for the
+    first two, same six outputs as the oracle in all cases"""
+    from grim.imputation.impute import Imputation
+    from grim.imputation.networkx_graph import Graph
+    from grim.run_impute_def import load_config
+
+    conf = harness.base_conf(["CAU"])
+    for tag, lines in (("blank", [""]), ("only_problem", ["X1,A*01:01", "X2,", "X3"]),
+                       ("one", ["D1,A*01:01+A*02:01^B*08:01+B*07:02,CAU,CAU"])):
+        _against_oracle("cau", conf, lines, "t_edge_" + tag)
+    # zero lines: the reference loops over nothing and leaves six empty files
+    work = harness.ensure_graph("cau")
+    cwd = os.getcwd()
+    os.chdir(work)
+    try:
+        cfg, _ = load_config("graph_conf.json")
+        g = Graph(cfg).build_graph(cfg["node_file"], cfg["top_links_file"], cfg["edges_file"])
+        texts = Imputation(g, cfg).impute_lines([], cfg)
+    finally:
+        os.chdir(cwd)
+    assert all(v == "" for v in texts.values()), texts
