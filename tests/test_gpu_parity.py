@@ -265,3 +265,14 @@ def test_empty_and_degenerate_inputs():
     finally:
         os.chdir(cwd)
     assert all(v == "" for v in texts.values()), texts
+
+
+def test_nine_populations_vs_oracle():
+    """P = 9: 81 prior cells, 45 population-pair cells (more than one wave of them), multi-race subjects"""
+    rows = synth.read_freqs(synth.CAU_FREQS)
+    pops = harness.POPS["pop9"]
+    conf = dict(harness.base_conf(pops), UNK_priors="MR")
+    lines = synth.SubjectGen(rows, 91, pops=pops).mixed(250, amb=0.3, miss=0.15, recomb=0.2)
+    _against_oracle("pop9", conf, lines, "r_pop9")
+    conf2 = dict(conf, number_of_pop_results=7, number_of_results=25, UNK_priors="SR")
+    _against_oracle("pop9", conf2, synth.SubjectGen(rows, 92, pops=pops).full(150), "r_pop9_full")

@@ -63,7 +63,7 @@ def main():
     rows = synth.read_freqs(synth.CAU_FREQS)
     t0 = time.time()
     for rd in range(rounds):
-        gname = "cau" if rng.random() < 0.5 else "pop4"
+        gname = str(rng.choice(["cau", "pop4", "pop9"], p=[0.45, 0.4, 0.15]))
         pops = harness.POPS[gname]
         conf = harness.base_conf(pops)
         conf["UNK_priors"] = "MR" if rng.random() < 0.5 else "SR"
@@ -89,6 +89,7 @@ def main():
         lines = [mutate(l, rng, gen.by_locus) if rng.random() < 0.35 else l for l in lines]
         binf = None
         if rng.random() < 0.2:  # per-subject phase masks (bin_imputation_in_file, impute.py:2001-2020)
+            os.makedirs(harness.WORK, exist_ok=True)
             binf = os.path.join(harness.WORK, "fuzz_bin.json")
             ids = [l.split(",")[0] for l in lines]
             json.dump({sid: [int(x) for x in rng.integers(0, 2, 4)] for sid in ids[: max(1, len(ids) - 2)]}, open(binf, "w"))

@@ -20,7 +20,9 @@ for p in (PKG, os.path.join(ROOT, "oracle"), HERE):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-POPS = {"cau": ["CAU"], "pop4": ["CAU", "AFA", "HIS", "API"]}
+POPS = {"cau": ["CAU"], "pop4": ["CAU", "AFA", "HIS", "API"],
+        # nine populations: CAU plus eight synthesised on the fly (seed 9); oracle-checked only, no golden files
+        "pop9": ["CAU", "AFA", "HIS", "API", "NAM", "MENA", "SAS", "EAS", "OCE"]}
 OUT_FILES = {"umug": "don.umug", "umug_pops": "don.umug.pops", "pmug": "don.pmug", "pmug_pops": "don.pmug.pops",
              "miss": "don.miss", "problem": "don.problem"}
 
@@ -43,8 +45,19 @@ def ensure_graph(name):
         return work
     os.makedirs(os.path.join(work, "data", "freqs"), exist_ok=True)
     os.makedirs(os.path.join(work, "data", "subjects"), exist_ok=True)
+    extra_rng = None
     for p in POPS[name]:
-        shutil.copy(os.path.join(GOLD, "data", "freqs", p + ".freqs.gz"), os.path.join(work, "data", "freqs"))
+        src = os.path.join(GOLD, "data", "freqs", p + ".freqs.gz")
+        if os.path.exists(src):
+            shutil.copy(src, os.path.join(work, "data", "freqs"))
+        else:  # a population without a committed file: synthesised from CAU like the committed ones
+            import numpy as np
+            import synth
+
+            if extra_rng is None:
+                extra_rng = np.random.default_rng(9)
+            synth.write_freqs(os.path.join(work, "data", "freqs", p + ".freqs.gz"),
+                              synth.synth_population(synth.read_freqs(synth.CAU_FREQS), extra_rng, drop=0.5))
     conf = base_conf(POPS[name])
     with open(os.path.join(work, "graph_conf.json"), "w") as fh:
         json.dump(conf, fh)
