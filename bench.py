@@ -165,9 +165,11 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            sample = lines + synth.SubjectGen(rows, 1000).full(args.subjects if args.workload == "full" else 0)
-            if args.workload != "full":
-                sample = lines[: min(len(lines), 2000)]
+            # bounded sample, about 15 s of single-core work: the batch itself plus more of the same generator
+            if args.workload == "full":
+                sample = lines[:10000] + synth.SubjectGen(rows, 1000).full(50000)
+            else:
+                sample = lines[: min(len(lines), 8000)]
             t1 = time.perf_counter()
             harness.run_oracle("cau", conf, sample, tag="bench_cpu")
             dt = time.perf_counter() - t1
