@@ -462,7 +462,10 @@ extern "C" grim_batch *grim_batch_upload(grim_ctx *c, const grim_graph *g, const
   // rows: enough for every subject to fill all four tables
   uint64_t per = 2ull * p->n_results + 2ull * (p->n_pop_results < (uint64_t)P * P ? p->n_pop_results : (uint64_t)P * P);
   // (fast-path subjects that fall through to Plan B take their rows from the dynamic part)
-  uint64_t want = per * d->n_subjects + (uint64_t)b->small_stride * b->n_small + 1024;
+  // (+ the gaps of the one-wave kernel's private row blocks: at most as much again as its subjects use, plus
+  //  one unfinished GRIM_ROW_GRAB block per resident wave)
+  uint64_t want = per * d->n_subjects + per * b->n_medium + (uint64_t)b->small_stride * b->n_small + 1024 +
+                  (uint64_t)GRIM_ROW_GRAB * c->n_cu * 32;
   const char *env_rows = getenv("GRIM_ROW_CAP");
   if (env_rows) want = strtoull(env_rows, nullptr, 10);
   if (want > 0x7FFFFFF0ull) want = 0x7FFFFFF0ull;
