@@ -39,6 +39,20 @@ def main():
     os.environ["GRIM_QUIET"] = "1"
 
     import __graft_entry__ as ge
+
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        n_dev = torch.cuda.device_count()  # does not initialise the GPU
+        backend = os.environ.get("GRIM_BENCH_BACKEND") or ("nccl" if n_dev > 0 else "gloo")
+        if n_dev > 0:
+            torch.cuda.set_device(local_rank % n_dev)  # ranks > devices only in rehearsals (gloo)
+        dist.init_process_group(backend=backend)
+        if rank == 0:
+            ge.build()  # one rank (re)builds the library if it is stale; the others wait
+        dist.barrier()
     ge.build()
     import harness
     import synth
@@ -46,17 +60,6 @@ def main():
     from grim.imputation.impute import Imputation
     from grim.imputation.networkx_graph import Graph
     from grim.run_impute_def import load_config
-
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        n_dev = nat.lib().grim_device_count()
-        backend = os.environ.get("GRIM_BENCH_BACKEND") or ("nccl" if n_dev > 0 else "gloo")
-        if n_dev > 0:
-            torch.cuda.set_device(local_rank % n_dev)  # ranks > devices only in rehearsals (gloo)
-        dist.init_process_group(backend=backend)
 
     # ---- graph + subjects (host work, outside the timed region) -----------------------------------
     if rank == 0:
