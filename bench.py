@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--subjects", type=int, default=10000, help="subjects per GPU (config 2: 10000)")
     ap.add_argument("--workload", default="full", choices=["full", "mixed"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-workers", type=int, default=8, help="processes of the CPU baseline (cpu_baseline.cores)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -168,18 +169,34 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            # bounded sample, about 15 s of single-core work: the batch itself plus more of the same generator
+            # bounded sample, about 15 s of wall time: the batch itself plus more of the same generator, split over
+            # worker processes the way the reference's scripts/runfile_mp.py splits a file (one oracle per chunk,
+            # each loading the graph itself); the workers never touch the GPU
+            import subprocess
+
+            workers = max(1, min(args.cpu_workers, os.cpu_count() or 1))
             if args.workload == "full":
-                sample = lines[:10000] + synth.SubjectGen(rows, 1000).full(50000)
+                sample = lines[:10000] + synth.SubjectGen(rows, 1000).full(50000 * workers)
             else:
-                sample = lines[: min(len(lines), 8000)]
+                sample = lines[: min(len(lines), 8000 * workers)]
+            spath = os.path.join(work, "data", "subjects", "bench_cpu.csv")
+            with open(spath, "w") as fh:
+                fh.write("\n".join(sample) + "\n")
+            cjson = os.path.join(work, "conf_bench_cpu.json")
+            json.dump(conf, open(cjson, "w"))
             t1 = time.perf_counter()
-            harness.run_oracle("cau", conf, sample, tag="bench_cpu")
+            procs = []
+            for k in range(workers):
+                lo, hi = len(sample) * k // workers, len(sample) * (k + 1) // workers
+                procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "cpu_baseline_worker.py"), "cau", cjson, spath,
+                                               str(lo), str(hi)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL))
+            done = [json.loads(p.communicate()[0].decode().strip().splitlines()[-1]) for p in procs]
             dt = time.perf_counter() - t1
             out["cpu_baseline"] = {
-                "value": len(sample) / dt, "unit": "subjects/s", "cores": 1, "kind": "port",
-                "sample": "%d subjects of the same generator through oracle/grim_oracle.py (single-thread Python "
-                          "restatement of the reference), %.1f s" % (len(sample), dt),
+                "value": len(sample) / dt, "unit": "subjects/s", "cores": workers, "kind": "port",
+                "sample": "%d subjects of the same generator through oracle/grim_oracle.py (Python restatement of the reference), "
+                          "%d worker processes with a contiguous chunk each as in scripts/runfile_mp.py, %.1f s wall including each "
+                          "worker's graph load; slowest worker %.1f s of imputation" % (len(sample), workers, dt, max(d["s"] for d in done)),
             }
         print(json.dumps(out))
     batch.close()
