@@ -26,8 +26,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--subjects", type=int, default=10000, help="subjects per GPU (config 2: 10000)")
     ap.add_argument("--workload", default="full", choices=["full", "mixed"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -104,8 +104,7 @@ def main():
     batch.set_timing(True)
     sync_barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        batch.run()  # enqueues the kernels and waits for the stream (device sync)
+    batch.run_repeat(args.steps)  # K complete synchronous runs (kernels, stream synchronise, state check) in one C call
     sync_barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:

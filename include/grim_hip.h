@@ -177,6 +177,9 @@ typedef struct {
 grim_batch *grim_batch_upload(grim_ctx *ctx, const grim_graph *g, const grim_params *p,
                               const grim_batch_desc *d);
 int grim_batch_run(grim_batch *b);
+/* n complete synchronous runs back to back (what a caller's loop around grim_batch_run does, without the
+ * caller's per-iteration overhead); stops at the first failing run and returns its code */
+int grim_batch_run_repeat(grim_batch *b, uint32_t n);
 /* Timing mode (also GRIM_TIMING=1 in the environment): every kernel of a run is bracketed by its own start/stop
  * hipEvents on the launch stream (hipExtLaunchKernelGGL).  Off by default: a synchronous 10k-subject run costs
  * 22 us without, 29 us with the events. */

@@ -684,6 +684,14 @@ extern "C" int grim_batch_run(grim_batch *b) {
   return 0;
 }
 
+extern "C" int grim_batch_run_repeat(grim_batch *b, uint32_t n) {
+  for (uint32_t i = 0; i < n; ++i) {
+    const int rc = grim_batch_run(b);
+    if (rc != 0) return rc;
+  }
+  return 0;
+}
+
 extern "C" double grim_batch_kernel_ms(const grim_batch *b, int which) {
   if (!b) return 0.0;
   if (which & 0x10) {  // mean over the timed runs since grim_batch_set_timing(b, 1)

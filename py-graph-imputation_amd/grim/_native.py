@@ -132,6 +132,8 @@ def lib():
     L.grim_batch_results.restype = C.c_int
     L.grim_batch_results.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.grim_batch_free.argtypes = [C.c_void_p]
+    L.grim_batch_run_repeat.restype = C.c_int
+    L.grim_batch_run_repeat.argtypes = [C.c_void_p, C.c_uint32]
     L.grim_batch_set_timing.restype = C.c_int
     L.grim_batch_set_timing.argtypes = [C.c_void_p, C.c_int]
     _lib = L
@@ -141,7 +143,7 @@ def lib():
 EXPORTS = [
     "grim_create", "grim_destroy", "grim_last_error", "grim_device_count", "grim_graph_upload", "grim_graph_free",
     "grim_graph_device_bytes", "grim_batch_upload", "grim_batch_run", "grim_batch_kernel_ms", "grim_batch_counters",
-    "grim_batch_total_rows", "grim_batch_results", "grim_batch_free", "grim_batch_set_timing",
+    "grim_batch_total_rows", "grim_batch_results", "grim_batch_free", "grim_batch_set_timing", "grim_batch_run_repeat",
 ]
 
 
@@ -248,6 +250,11 @@ class DeviceBatch:
 
     def run(self):
         rc = lib().grim_batch_run(self.h)
+        if rc != 0:
+            raise NativeError("grim_batch_run failed (%d): %s" % (rc, self.ctx.error()))
+
+    def run_repeat(self, n):
+        rc = lib().grim_batch_run_repeat(self.h, int(n))
         if rc != 0:
             raise NativeError("grim_batch_run failed (%d): %s" % (rc, self.ctx.error()))
 
