@@ -129,7 +129,7 @@ def main():
     # HBM traffic per launch of the dominant kernel: PMC numbers cannot be collected from inside this
     # process; they come from the committed rocprofv3 --pmc passes over this same command
     traffic, traffic_src = None, None
-    pmc_file = "r1e_pmc_traffic.json"  # newest committed PMC passes (tools/profile_round.sh)
+    pmc_file = "r1f_pmc_traffic.json"  # newest committed PMC passes (tools/profile_round.sh)
     pmc_path = os.path.join(ROOT, "profiles", pmc_file)
     if os.path.exists(pmc_path) and args.workload == "full" and args.subjects == 10000:
         pmc = json.load(open(pmc_path)).get(names[dom])
