@@ -461,7 +461,7 @@ class Parsed:
         ptr = host_lib().grim_parsed_id(self.h, line, C.byref(n))
         return C.string_at(ptr, n.value).decode() if ptr else None
 
-    def format(self, adict, params, pops, res, rows, line_offset=0, skip=None):
+    def format(self, adict, params, pops, res, rows, line_offset=0, skip=None, as_bytes=False):
         L = host_lib()
         names = (C.c_char_p * len(pops))(*[p.encode() for p in pops])
         res = np.ascontiguousarray(res)
@@ -478,7 +478,10 @@ class Parsed:
         for k, key in enumerate(("umug", "umug_pops", "pmug", "pmug_pops", "miss", "problem")):
             n = C.c_uint64(0)
             ptr = L.grim_text_get(t, k, C.byref(n))
-            out[key] = C.string_at(ptr, n.value).decode() if n.value else ""
+            if as_bytes:
+                out[key] = C.string_at(ptr, n.value) if n.value else b""
+            else:
+                out[key] = C.string_at(ptr, n.value).decode() if n.value else ""
         L.grim_text_free(t)
         return out
 

@@ -422,9 +422,15 @@ class Imputation(object):
         return self.open_phases_for_em(phases, chrom["N_Loc"], cutoff)
 
     def impute_file(self, config, planb=None, em_mr=False, em=False):
-        with open(config["imputation_input_file"], "r") as fh:
-            lines = fh.readlines()
-        texts = self.impute_lines(lines, config, planb=planb, em_mr=em_mr, em=em)
+        # the file goes to the library's tokenizer as it is and the six outputs come back as bytes: no per-line
+        # Python strings on the way in or out
+        with open(config["imputation_input_file"], "rb") as fh:
+            raw = fh.read()
+        if b"\r" in raw:  # let Python's universal newlines split the lines exactly as the reference's open() does
+            raw = raw.decode().replace("\r\n", "\n").replace("\r", "\n").encode()
+        if raw and not raw.endswith(b"\n"):
+            raw += b"\n"
+        texts = self.impute_lines(None, config, planb=planb, em_mr=em_mr, em=em, _raw=raw)
         self.write_outputs(config, texts)
 
     @staticmethod
@@ -437,10 +443,11 @@ class Imputation(object):
         for key, path_key, flag in names:
             if flag is not None and not config[flag]:
                 continue
-            with open(config[path_key], "w") as fh:
-                fh.write(texts[key])
+            data = texts[key]
+            with open(config[path_key], "wb" if isinstance(data, bytes) else "w") as fh:
+                fh.write(data)
 
-    def impute_lines(self, lines, config, planb=None, em_mr=False, line_offset=0, em=False):
+    def impute_lines(self, lines, config, planb=None, em_mr=False, line_offset=0, em=False, _raw=None):
         """The body of impute_file on a list of input lines.  Returns the six output texts keyed
         'umug','umug_pops','pmug','pmug_pops','miss','problem'.  `line_offset` is the global index
         of lines[0] (multi-GPU shards keep the reference's line numbers in .miss/.problem).
@@ -456,7 +463,7 @@ class Imputation(object):
             raise NotImplementedError("epsilon <= 0: the reference returns its 'NaN' sentinel and fails every subject")
         self.unsupported = []
         tm = [timeit.default_timer()]
-        text = "".join(l if l.endswith("\n") else l + "\n" for l in lines).encode()
+        text = _raw if _raw is not None else "".join(l if l.endswith("\n") else l + "\n" for l in lines).encode()
         tm.append(timeit.default_timer())
         parsed = nat.Parsed(self.netGraph.adict, text, planb)
         tm.append(timeit.default_timer())
@@ -510,7 +517,8 @@ class Imputation(object):
                 skip = np.zeros(len(kinds), dtype=np.uint8)
                 skip[bad_lines] = 1
             tm.append(timeit.default_timer())
-            texts = parsed.format(self.netGraph.adict, params, self.populations, res, rows, line_offset, skip)
+            texts = parsed.format(self.netGraph.adict, params, self.populations, res, rows, line_offset, skip,
+                                  as_bytes=_raw is not None)
             tm.append(timeit.default_timer())
             self.last_stats["host_s"] = {"join": tm[1] - tm[0], "tokenize": tm[2] - tm[1], "device_total": tm[3] - tm[2],
                                          "format": tm[4] - tm[3]}

@@ -276,3 +276,30 @@ def test_nine_populations_vs_oracle():
     _against_oracle("pop9", conf, lines, "r_pop9")
     conf2 = dict(conf, number_of_pop_results=7, number_of_results=25, UNK_priors="SR")
     _against_oracle("pop9", conf2, synth.SubjectGen(rows, 92, pops=pops).full(150), "r_pop9_full")
+
+
+def test_crlf_input_file_equals_lf():
+    """impute_file hands the file's bytes to the tokenizer; a CRLF file must give what Python's universal
+    newlines would have given the reference (the same outputs as the LF file)"""
+    from grim.imputation.impute import Imputation
+    from grim.imputation.networkx_graph import Graph
+    from grim.run_impute_def import load_config
+
+    gname, conf, lines, exp, elog, em = harness.golden("cau_edge")
+    work = harness.ensure_graph(gname)
+    got_lf, _, _ = _run(gname, conf, lines, "t_crlf_ref", em)
+    cwd = os.getcwd()
+    os.chdir(work)
+    try:
+        cfg, out_dir = load_config(os.path.join(work, "conf_t_crlf_ref.json"))
+        path = os.path.join(work, "data", "subjects", "t_crlf.csv")
+        with open(path, "wb") as fh:
+            fh.write(("\r\n".join(lines) + "\r\n").encode())
+        cfg["imputation_input_file"] = path
+        g = Graph(cfg).build_graph(cfg["node_file"], cfg["top_links_file"], cfg["edges_file"])
+        imp = Imputation(g, cfg)
+        imp.quiet = True
+        imp.impute_file(cfg)
+    finally:
+        os.chdir(cwd)
+    assert harness.read_outputs(work, "t_crlf_ref") == got_lf
