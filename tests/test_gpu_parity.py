@@ -303,3 +303,50 @@ def test_crlf_input_file_equals_lf():
     finally:
         os.chdir(cwd)
     assert harness.read_outputs(work, "t_crlf_ref") == got_lf
+
+
+def test_timing_mode_and_repeat():
+    """grim_batch_set_timing / grim_batch_kernel_ms / grim_batch_run_repeat through the binding: kernel times appear
+    only in timing mode, the accumulated mean is the mean, results do not depend on the mode"""
+    from grim import _native as nat
+    from grim.imputation.impute import Imputation
+    from grim.imputation.networkx_graph import Graph
+    from grim.run_impute_def import load_config
+
+    work = harness.ensure_graph("cau")
+    cwd = os.getcwd()
+    os.chdir(work)
+    try:
+        cfg, _ = load_config("graph_conf.json")
+        g = Graph(cfg).build_graph(cfg["node_file"], cfg["top_links_file"], cfg["edges_file"])
+        imp = Imputation(g, cfg)
+        rows = synth.read_freqs(synth.CAU_FREQS)
+        lines = synth.SubjectGen(rows, 5).full(2000) + synth.SubjectGen(rows, 6).mixed(300)
+        parsed = nat.Parsed(g.adict, ("\n".join(lines) + "\n").encode(), cfg["planb"])
+        priors = np.stack([imp._prior_matrix(r1, r2, cfg["priority"]) for r1, r2 in parsed.races()])
+        ctx = nat.default_context(0)
+        batch = nat.DeviceBatch(ctx, g.device(ctx), imp._params(cfg, cfg["planb"], False), parsed.subjects(), parsed.tokens(), priors)
+        batch.set_timing(False)
+        batch.run()
+        res0, rows0 = batch.results()
+        assert batch.kernel_ms(0) == 0.0
+        batch.set_timing(True)
+        batch.run_repeat(5)
+        res1, rows1 = batch.results()
+        assert batch.kernel_ms(3) > 0.0 and batch.kernel_ms(2) > 0.0  # half-wave kernel and Plan B both ran
+        total = sum(batch.kernel_ms(w) for w in (3, 5, 4, 2))
+        assert abs(batch.kernel_ms(0) - total) < 1e-6
+        assert batch.kernel_ms(0x10 | 3) > 0.0
+
+        def tables(res, rows):  # row offsets depend on the order in which workgroups took rows; contents must not
+            out = []
+            for r in res:
+                out.append((int(r["status"]), int(r["plan"]), int(r["n_pairs"]), int(r["n_genotypes"]), float(r["max_prob"]),
+                            [rows[int(o):int(o) + int(n)].tobytes() for o, n in zip(r["row_off"], r["n_rows"])]))
+            return out
+
+        assert tables(res0, rows0) == tables(res1, rows1)
+        assert int(res0["n_rows"].sum()) > 0
+        batch.close()
+    finally:
+        os.chdir(cwd)
