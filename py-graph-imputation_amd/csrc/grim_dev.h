@@ -71,6 +71,7 @@ struct DevArgs {
   uint32_t n_work;
   uint32_t *queue;        // [0] general work counter [1] row head [2] plan-B list length [3] plan-B work counter
                           // [4] one-wave kernel work counter [5] its hand-over count [6] heavy plan-B subjects
+                          // [7] its heavier hand-overs
   grim_subject_result *res;
   grim_row *rows;
   uint32_t *row_head;
@@ -80,7 +81,9 @@ struct DevArgs {
   uint32_t pair_cap, tab_cap, bset_cap, proj_cap;
   uint32_t *small_ctr;           // half-wave kernel: per wave {probes, frequency vectors}, plain stores; summed on request
   unsigned long long *counters;  // [0] probes [1] nbr ids [2] freq vectors [3] rows [4] overflow flag
-  uint32_t *bail_list;           // subjects the one-wave kernel hands to the general kernel (count: queue[5])
+  uint32_t *bail_list;           // subjects the one-wave kernel hands to the general kernel: light ones from the front
+                                 // (count queue[5]), heavier ones from the back (count queue[7]); n_medium entries
+  uint32_t n_medium;
   uint32_t *next_list;           // subjects handed to the next kernel (plan B): light ones from the front
   uint32_t *next_count;          // (count queue[2]), heavy ones from the back (count queue[6]) -- heavy first
   uint32_t next_cap;             // entries in next_list

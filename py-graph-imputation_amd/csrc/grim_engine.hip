@@ -28,15 +28,23 @@ __global__ __launch_bounds__(GRIM_WG, 2) void grim_plan_a_kernel(DevArgs A) {
   const int tid = threadIdx.x;
   const int P = A.g.P;
   Slot S = make_slot(A, blockIdx.x);
-  const uint32_t n_bail = A.bail_list ? A.queue[5] : 0;  // written by the one-wave kernel, earlier in the stream
+  // hand-overs of the one-wave kernel (earlier in the stream): the heavier ones, at the back of its list, are
+  // taken first, then this kernel's own subjects (heaviest first), then the light hand-overs
+  const uint32_t n_bail = A.bail_list ? A.queue[5] : 0, n_bail_heavy = A.bail_list ? A.queue[7] : 0;
   if (tid < GRIM_NWAVE * 4) ((unsigned long long *)sh.wctr)[tid] = 0;
   __syncthreads();
   for (;;) {
     if (tid == 0) sh.bc[3] = atomicAdd(A.queue, 1u);
     __syncthreads();
     const uint32_t w = sh.bc[3];
-    if (w >= A.n_work + n_bail) break;
-    const uint32_t si = w < A.n_work ? A.order[w] : A.bail_list[w - A.n_work];
+    if (w >= A.n_work + n_bail + n_bail_heavy) break;
+    uint32_t si;
+    if (w < n_bail_heavy)
+      si = A.bail_list[A.n_medium - 1u - w];
+    else if (w - n_bail_heavy < A.n_work)
+      si = A.order[w - n_bail_heavy];
+    else
+      si = A.bail_list[w - n_bail_heavy - A.n_work];
     if (tid < 16) ((uint32_t *)&sh.subj)[tid] = ((const uint32_t *)&A.subj[si])[tid];
     if (tid < GRIM_SIDES) {
       sh.Tn[tid] = 0;
@@ -460,6 +468,7 @@ extern "C" grim_batch *grim_batch_upload(grim_ctx *c, const grim_graph *g, const
   b->order_m = upload(c, b->bufs, om.data(), om.size(), &bytes);
   b->n_medium = (uint32_t)om.size();
   A.bail_list = upload<uint32_t>(c, b->bufs, nullptr, om.size(), &bytes);
+  A.n_medium = (uint32_t)om.size();
   A.order = b->order_g;
   A.n_work = b->n_general;
   // one state block: counters (8 + 4*64 u64) followed by queue[4] (u32): work counter, row head,
@@ -665,8 +674,8 @@ extern "C" int grim_batch_run(grim_batch *b) {
     b->n_timed++;
   }
   if (getenv("GRIM_DEBUG_CLASSES"))
-    fprintf(stderr, "grim classes: small %u medium %u general %u | medium->general %u, to plan B %u (+%u heavy) | stage 1 %s\n",
-            b->n_small, b->n_medium, b->n_general, head[5], head[2], head[6], b->graph_state == 1 ? "replayed as a hipGraph" : "launched directly");
+    fprintf(stderr, "grim classes: small %u medium %u general %u | medium->general %u (+%u heavier), to plan B %u (+%u heavy) | stage 1 %s\n",
+            b->n_small, b->n_medium, b->n_general, head[5], head[7], head[2], head[6], b->graph_state == 1 ? "replayed as a hipGraph" : "launched directly");
   memcpy(b->counters, b->hstate, 64);
   b->small_ctr_pending = b->n_small > 0;
   for (int sh = 0; sh < 64; ++sh)

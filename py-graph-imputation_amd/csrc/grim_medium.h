@@ -70,7 +70,8 @@ __device__ __forceinline__ PairRef med_pair(const WaveMed &M, uint32_t f) {
   return pr;
 }
 
-// returns 0 = done (result written), 1 = hand over to the general kernel
+// returns 0 = done (result written), 1 / 2 = hand over to the general kernel (1: only the number of accepted
+// pairs was too large, a light subject for that kernel; 2: a size limit before that, a heavier one)
 // acc: the wave's algorithmic-byte counts (probes, CSR ids, frequency vectors) of the subjects it completed
 __device__ inline int medium_subject(const DevArgs &A, WaveMed &M, uint32_t si, unsigned long long (&acc)[3], RowBlock &rb) {
   const DevGraph &g = A.g;
@@ -127,10 +128,10 @@ __device__ inline int medium_subject(const DevArgs &A, WaveMed &M, uint32_t si, 
     }
     bad = !(options < A.prm.opt_threshold) || my_nc > 4096;
   }
-  if (__ballot(bad)) return 1;
+  if (__ballot(bad)) return 2;
   uint32_t inc = wave_incl_scan(my_nc);
   const uint32_t C = __shfl(inc, 63);
-  if (C > 4096) return 1;
+  if (C > 4096) return 2;
   if (lane <= nsides && lane < 64) M.cand_start[lane] = (uint16_t)(lane == 0 ? 0 : 0);
   WAVE_SYNC();
   if (lane < nsides) M.cand_start[lane + 1] = (uint16_t)inc;
@@ -194,7 +195,7 @@ __device__ inline int medium_subject(const DevArgs &A, WaveMed &M, uint32_t si, 
       const uint32_t ec = (uint32_t)__popcll(mask);
       uint32_t einc = wave_incl_scan(ec);
       const uint32_t etot = __shfl(einc, 63);
-      if (E + etot > MW_E) return 1;
+      if (E + etot > MW_E) return 2;
       uint32_t pos = E + einc - ec;
       while (mask) {
         int j = __ffsll((unsigned long long)mask) - 1;
@@ -215,7 +216,7 @@ __device__ inline int medium_subject(const DevArgs &A, WaveMed &M, uint32_t si, 
   // ---- segments and per-side lists (convert_list_to_one_dim, impute.py:424-442) ------------------
   const uint32_t K = A.prm.top_n;
   uint32_t sc = lane < nsides ? M.cnt_side[lane] : 0;
-  if (__ballot(sc > 64)) return 1;
+  if (__ballot(sc > 64)) return 2;
   uint32_t sinc = wave_incl_scan(sc);
   if (lane < nsides) {
     M.seg[lane] = (uint16_t)(sinc - sc);
@@ -259,7 +260,7 @@ __device__ inline int medium_subject(const DevArgs &A, WaveMed &M, uint32_t si, 
   }
   WAVE_SYNC();
   const uint32_t np = M.poff[GRIM_MAXPH];
-  if (np > MW_NP) return 1;
+  if (np > MW_NP) return 2;
   // ---- ladder (impute.py:1665-1687) ----------------------------------------------------------------
   int best = A.prm.n_ladder;
   for (uint32_t f = lane; f < np && best > 0; f += 64) {
@@ -380,8 +381,13 @@ __global__ __launch_bounds__(64) void grim_plan_a_medium_kernel(DevArgs A, const
     const uint32_t w1 = w0 + CH < n ? w0 + CH : n;
     for (uint32_t w = w0; w < w1; ++w) {
       const uint32_t si = order[w];
-      if (medium_subject(A, M, si, acc, rb) != 0) {
-        if (lane_id() == 0) bail_list[atomicAdd(A.queue + 5, 1u)] = si;
+      const int rc = medium_subject(A, M, si, acc, rb);
+      if (rc != 0 && lane_id() == 0) {
+        // the heavier hand-overs from the back of the list: the general kernel takes them first
+        if (rc == 2)
+          bail_list[n - 1u - atomicAdd(A.queue + 7, 1u)] = si;
+        else
+          bail_list[atomicAdd(A.queue + 5, 1u)] = si;
       }
       WAVE_SYNC();
     }
