@@ -329,7 +329,7 @@ __device__ inline int medium_subject(const DevArgs &A, WaveMed &M, uint32_t si, 
       eps = mx / 100000.0;
       WAVE_SYNC();
     }
-    if (nU > 64) return 1;
+    if (nU > 64) return nU > 256 ? 2 : 1;  // the count is exact: hundreds of accepted pairs are not a light subject
   }
   WAVE_SYNC();
   // ---- result ----------------------------------------------------------------------------------------
