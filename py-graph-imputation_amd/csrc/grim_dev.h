@@ -89,6 +89,9 @@ struct DevArgs {
   uint32_t next_cap;             // entries in next_list
 };
 
+#ifndef GRIM_HEAVY_LOCI
+#define GRIM_HEAVY_LOCI 3
+#endif
 // hand a subject to the Plan-B kernel.  Subjects with few typed loci (their sides saturate the top lists: tens
 // of thousands of pairs) go to the head of its queue so that they do not start last and become the tail.
 __device__ __forceinline__ void push_next(const DevArgs &A, uint32_t si, bool heavy) {

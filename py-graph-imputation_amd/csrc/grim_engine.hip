@@ -103,7 +103,7 @@ __global__ __launch_bounds__(GRIM_WG, 2) void grim_plan_a_kernel(DevArgs A) {
       } else if (A.prm.planb) {
         status = GRIM_ST_UNSUPPORTED;  // replaced by the plan-B kernel's verdict when it runs
         reason = 2;
-        if (tid == 0 && A.next_list) push_next(A, si, sh.subj.n_loci <= 3);
+        if (tid == 0 && A.next_list) push_next(A, si, sh.subj.n_loci <= GRIM_HEAVY_LOCI);
       }
     }
     __syncthreads();

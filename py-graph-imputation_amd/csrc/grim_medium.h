@@ -352,7 +352,7 @@ __device__ inline int medium_subject(const DevArgs &A, WaveMed &M, uint32_t si, 
   } else if (A.prm.planb) {
     out.status = GRIM_ST_UNSUPPORTED;  // replaced by the plan-B kernel's verdict
     out.reason = 2;
-    if (lane == 0) push_next(A, si, n <= 3);
+    if (lane == 0) push_next(A, si, n <= GRIM_HEAVY_LOCI);
   } else {
     out.status = GRIM_ST_MISS;
   }
