@@ -450,31 +450,44 @@ __device__ inline uint32_t group_and_rank(const DevArgs &A, WgShared &sh, const 
       }
     }
     __syncthreads();
-    // heads in first-seen order -> dense group ids
-    for (uint32_t u0 = 0; u0 < nU; u0 += GRIM_WG) {
-      uint32_t u = u0 + tid;
-      bool head = false;
-      uint32_t s = 0;
-      if (u < nU) {
-        s = S.Uslot[u];
-        head = (ALOAD(&S.tmin[s]) == u);
+    // heads in first-seen order -> dense group ids; 4 x 256 pairs per barrier round, their (dependent) slot and
+    // tmin reads in flight together
+    for (uint32_t u0 = 0; u0 < nU; u0 += 4 * GRIM_WG) {
+      uint32_t slot[4];
+      bool head[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t u = u0 + q * GRIM_WG + tid;
+        slot[q] = u < nU ? S.Uslot[u] : 0;
       }
-      uint64_t m = __ballot(head);
-      if (lane_id() == 0) sh.tmp[wave_id()] = (uint32_t)__popcll(m);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t u = u0 + q * GRIM_WG + tid;
+        head[q] = u < nU && ALOAD(&S.tmin[slot[q]]) == u;
+      }
+      uint64_t m[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        m[q] = __ballot(head[q]);
+        if (lane_id() == 0) sh.tmp[q * GRIM_NWAVE + wave_id()] = (uint32_t)__popcll(m[q]);
+      }
       __syncthreads();
-      uint32_t base = ng, tot = 0;
-      for (int w2 = 0; w2 < GRIM_NWAVE; ++w2) {
-        uint32_t t = sh.tmp[w2];
-        if (w2 < wave_id()) base += t;
-        tot += t;
-      }
-      if (head) {
-        uint32_t gid = base + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
-        S.tgid[s] = gid;
-        S.ghead[gid] = u;
-        S.gcnt[gid] = 0;
-      }
-      ng += tot;
+      uint32_t run = ng, base[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        for (int w2 = 0; w2 < GRIM_NWAVE; ++w2) {
+          if (w2 == wave_id()) base[q] = run;
+          run += sh.tmp[q * GRIM_NWAVE + w2];
+        }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (head[q]) {
+          const uint32_t gid = base[q] + (uint32_t)__popcll(m[q] & ((1ull << lane_id()) - 1ull));
+          S.tgid[slot[q]] = gid;
+          S.ghead[gid] = u0 + q * GRIM_WG + tid;
+          S.gcnt[gid] = 0;
+        }
+      ng = run;
       __syncthreads();
     }
     // stable sort of u by group id, then per-group left-to-right sums
