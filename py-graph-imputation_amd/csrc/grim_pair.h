@@ -757,7 +757,44 @@ __device__ inline void pop_tables(const DevArgs &A, WgShared &sh, const Slot &S,
     S.qfirst[c] = GRIM_NONE;
   }
   __syncthreads();
-  for (uint32_t u0 = 0; u0 < nU; u0 += 1024) {
+  if (ncell == 1) {
+    // One population: every pair falls into the single cell -- one strict left-to-right chain of nU fp64 adds.
+    // Wave 0 runs the chain over one half of the staging buffer (16 broadcast LDS reads issued ahead of their 16
+    // dependent adds) while the other three waves fetch the next 512 probabilities into the other half.
+    constexpr uint32_t HALF = 512;
+    for (uint32_t r = tid; r < HALF && r < nU; r += GRIM_WG) sh.qprob[r] = S.Uprob[r];
+    double s = 0.0;
+    for (uint32_t u0 = 0, half = 0; u0 < nU; u0 += HALF, half ^= 1) {
+      __syncthreads();  // this half is filled, the other one is free
+      const uint32_t cnt = nU - u0 < HALF ? nU - u0 : HALF;
+      if (wave_id() == 0) {
+        const double *v = sh.qprob + half * HALF;
+        uint32_t r = 0;
+        if (u0 == 0) {
+          s = v[0];
+          r = 1;
+        }
+        for (; r + 16 <= cnt; r += 16) {
+          double x[16];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) x[j] = v[r + j];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) s = s + x[j];
+        }
+        for (; r < cnt; ++r) s = s + v[r];
+      } else {
+        const uint32_t n0 = u0 + HALF;
+        double *dst = sh.qprob + (half ^ 1) * HALF;
+        for (uint32_t r = tid - 64; r < HALF && n0 + r < nU; r += GRIM_WG - 64) dst[r] = S.Uprob[n0 + r];
+      }
+    }
+    if (tid == 0) {
+      S.qsum[0] = s;
+      S.qfirst[0] = 0;
+    }
+    __syncthreads();
+  }
+  for (uint32_t u0 = 0; ncell > 1 && u0 < nU; u0 += 1024) {
     uint32_t cnt = nU - u0 < 1024 ? nU - u0 : 1024;
     for (uint32_t r = tid; r < cnt; r += GRIM_WG) {
       uint32_t cell = 0;
@@ -774,35 +811,6 @@ __device__ inline void pop_tables(const DevArgs &A, WgShared &sh, const Slot &S,
     // walk the chunk in order.  Each wave takes 64 entries into registers (one per lane) and replays
     // them through v_readlane, so the strict left-to-right fp64 chain of a cell runs at register
     // speed instead of LDS latency; lane = cell (waves whose cells do not exist skip the walk).
-    if (ncell == 1) {
-      // one population: every pair falls into the single cell -- a bare add chain (a lone wave is
-      // issue bound at ~4 cycles per instruction, so the loop body is kept to readlane + add)
-      if (wave_id() == 0) {
-        double s = S.qsum[0];
-        uint32_t r0 = 0;
-        if (u0 == 0) {
-          s = sh.qprob[0];
-          r0 = 1;
-        }
-        for (uint32_t b0 = 0; b0 < cnt; b0 += 64) {
-          const uint32_t r = b0 + lane_id();
-          const double pv = r < cnt ? sh.qprob[r] : 0.0;
-          const int lo = (int)(r0 > b0 ? r0 - b0 : 0), hi = (cnt - b0) < 64 ? (int)(cnt - b0) : 64;
-          if (lo == 0 && hi == 64) {
-#pragma unroll
-            for (int j = 0; j < 64; ++j) s = s + lane_get(pv, j);
-          } else {
-            for (int j = lo; j < hi; ++j) s = s + lane_get(pv, j);
-          }
-        }
-        if (lane_id() == 0) {
-          S.qsum[0] = s;
-          S.qfirst[0] = 0;
-        }
-      }
-      __syncthreads();
-      continue;
-    }
     for (int c0 = wave_id() * 64; c0 < ncell; c0 += GRIM_WG) {
       const int c = c0 + lane_id();
       const bool mine = c < ncell && (c / P) <= (c % P);
