@@ -401,7 +401,17 @@ __device__ inline int wg_radix_sort(uint64_t *ka, uint32_t *va, uint64_t *kb, ui
     uint64_t *sk = cur ? kb : ka, *dk = cur ? ka : kb;
     uint32_t *sv = cur ? vb : va, *dv = cur ? va : vb;
     for (int d = 0; d < 16; ++d) hist[d * GRIM_WG + tid] = 0;
-    for (uint32_t i = b0; i < b1; ++i) hist[((sk[i] >> sh) & 15) * GRIM_WG + tid]++;
+    {  // eight keys per step: the loads are in flight together (a thread's block is contiguous)
+      uint32_t i = b0;
+      for (; i + 8 <= b1; i += 8) {
+        uint64_t k[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) k[q] = sk[i + q];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) hist[((k[q] >> sh) & 15) * GRIM_WG + tid]++;
+      }
+      for (; i < b1; ++i) hist[((sk[i] >> sh) & 15) * GRIM_WG + tid]++;
+    }
     __syncthreads();
     // thread t owns flattened entries [16t,16t+16): digit t/16, threads (t%16)*16..
     uint32_t part = 0;
@@ -425,11 +435,29 @@ __device__ inline int wg_radix_sort(uint64_t *ka, uint32_t *va, uint64_t *kb, ui
       base += c;
     }
     __syncthreads();
-    for (uint32_t i = b0; i < b1; ++i) {
-      uint64_t k = sk[i];
-      uint32_t pos = hist[((k >> sh) & 15) * GRIM_WG + tid]++;
-      dk[pos] = k;
-      dv[pos] = sv[i];
+    {
+      uint32_t i = b0;
+      for (; i + 8 <= b1; i += 8) {
+        uint64_t k[8];
+        uint32_t v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          k[q] = sk[i + q];
+          v[q] = sv[i + q];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {  // in order: equal digits keep their order
+          const uint32_t pos = hist[((k[q] >> sh) & 15) * GRIM_WG + tid]++;
+          dk[pos] = k[q];
+          dv[pos] = v[q];
+        }
+      }
+      for (; i < b1; ++i) {
+        const uint64_t k = sk[i];
+        const uint32_t pos = hist[((k >> sh) & 15) * GRIM_WG + tid]++;
+        dk[pos] = k;
+        dv[pos] = sv[i];
+      }
     }
     __syncthreads();
     cur ^= 1;
