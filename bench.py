@@ -104,7 +104,8 @@ def main():
     batch.set_timing(True)
     sync_barrier()
     t0 = time.perf_counter()
-    batch.run_repeat(args.steps)  # K complete synchronous runs (kernels, stream synchronise, state check) in one C call
+    for _ in range(args.steps):
+        batch.run()  # one complete synchronous run: kernels, stream synchronise, state check
     sync_barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -129,7 +130,7 @@ def main():
     # HBM traffic per launch of the dominant kernel: PMC numbers cannot be collected from inside this
     # process; they come from the committed rocprofv3 --pmc passes over this same command
     traffic, traffic_src = None, None
-    pmc_file = "r1f_pmc_traffic.json"  # newest committed PMC passes (tools/profile_round.sh)
+    pmc_file = "r1g_pmc_traffic.json"  # newest committed PMC passes (tools/profile_round.sh)
     pmc_path = os.path.join(ROOT, "profiles", pmc_file)
     if os.path.exists(pmc_path) and args.workload == "full" and args.subjects == 10000:
         pmc = json.load(open(pmc_path)).get(names[dom])
