@@ -213,12 +213,14 @@ int32_t grim_dict_find(const grim_dict *d, uint32_t slot, const char *allele);
 const char *grim_dict_name(const grim_dict *d, uint32_t slot, uint32_t id);
 uint32_t grim_dict_count(const grim_dict *d, uint32_t slot);
 
-/* per-line outcome kinds */
-enum { GRIM_K_DEVICE = 0, GRIM_K_PROBLEM_ID = 1, GRIM_K_PROBLEM_RAW = 2, GRIM_K_MISS_NO_DEVICE = 3 };
+/* per-line outcome kinds; GRIM_K_UNSUPPORTED: more distinct alleles at one locus of one subject than a key field
+ * holds (reported like a GRIM_ST_UNSUPPORTED subject, reason 5) */
+enum { GRIM_K_DEVICE = 0, GRIM_K_PROBLEM_ID = 1, GRIM_K_PROBLEM_RAW = 2, GRIM_K_MISS_NO_DEVICE = 3, GRIM_K_UNSUPPORTED = 4 };
 
-/* text: '\n'-separated input lines ("id,GL[,race1,race2]" or '%'-separated).  Unknown alleles are
- * added to the dictionary.  subjects[i].prior_idx = index of the line's (race1, race2) pair in
- * grim_parsed_race(); the caller supplies one prior matrix per pair in that order. */
+/* text: '\n'-separated input lines ("id,GL[,race1,race2]" or '%'-separated).  The dictionary is only READ:
+ * alleles it does not know get ids from grim_dict_count(slot) upwards that are private to the subject that
+ * brought them (grim_parsed_allele gives their text).  subjects[i].prior_idx = index of the line's
+ * (race1, race2) pair in grim_parsed_race(); the caller supplies one prior matrix per pair in that order. */
 grim_parsed *grim_tokenize(grim_dict *d, const char *text, uint64_t len, int planb, int n_threads);
 void grim_parsed_free(grim_parsed *p);
 uint32_t grim_parsed_lines(const grim_parsed *p);
@@ -230,13 +232,16 @@ const int32_t *grim_parsed_dev_index(const grim_parsed *p);  /* [lines] subject 
 uint32_t grim_parsed_n_races(const grim_parsed *p);
 const char *grim_parsed_race(const grim_parsed *p, uint32_t i, int which);
 const char *grim_parsed_id(const grim_parsed *p, uint32_t line, uint32_t *len);
+/* text (not NUL terminated) of allele `id` at locus slot `slot` as line `line` uses it; NULL if there is none */
+const char *grim_parsed_allele(const grim_parsed *p, uint32_t line, uint32_t slot, uint32_t id, uint32_t *len);
 /* host-language overrides: force a line's outcome kind; set a subject's `flags` = bitmask of positions
  * that must NOT switch sides when phases are enumerated (bin_imputation_in_file, impute.py:277-290) */
 int grim_parsed_set_kind(grim_parsed *p, uint32_t line, uint8_t kind);
 int grim_parsed_set_flags(grim_parsed *p, uint32_t line, uint8_t flags);
 
 /* res/rows as returned by grim_batch_results for the subjects of `p`.  line_offset = global index
- * of the first line (multi-GPU shards); skip = optional [lines] mask of lines to leave out.
+ * of the first line (multi-GPU shards); skip = optional [lines] mask of lines to leave out; subjects with
+ * status GRIM_ST_UNSUPPORTED are left out of every text.
  * Texts: 0 .umug, 1 .umug.pops, 2 .pmug, 3 .pmug.pops, 4 .miss, 5 .problem. */
 grim_text *grim_format(const grim_dict *d, const grim_parsed *p, const grim_params *prm, const char *const *pop_names,
                        uint32_t n_pops, const grim_subject_result *res, const grim_row *rows, uint64_t line_offset,
@@ -244,6 +249,93 @@ grim_text *grim_format(const grim_dict *d, const grim_parsed *p, const grim_para
 const char *grim_text_get(const grim_text *t, int which, uint64_t *len);
 void grim_text_free(grim_text *t);
 int grim_format_double(double x, char *buf, int cap); /* CPython str(float) */
+
+/* ---- prior matrices: calc_priority_matrix (impute.py:1844-1924) --------------------------------------------------
+ * One P x P matrix per (race1, race2) pair of an input line: alpha/beta/gamma/delta/eta weights of the conf's
+ * "priority", the UNK_priors base matrix ("MR" all ones, else identity) for lines without a known population,
+ * population counts of pops_count_file (impute.py:205-212; NULL = all 1).  Every operation in the reference's
+ * order: the matrices are bit-identical to numpy's. */
+typedef struct {
+  double alpha, eta, beta, gamma, delta;
+  uint8_t unk_mr;
+  const double *count_by_prob; /* [n_pops] or NULL */
+} grim_prior_spec;
+int grim_prior_matrix(const grim_prior_spec *spec, const char *const *pop_names, uint32_t n_pops, const char *race1,
+                      const char *race2, double *out /* [n_pops * n_pops] */);
+
+/* ======================= streaming pipeline: impute_file's loop (impute.py:2019-2144) =================================
+ * Input text goes in as it comes (any split, lines may straddle calls); the library cuts it into chunks of
+ * chunk_lines lines and runs, per chunk and overlapped between chunks:
+ *     tokenizer threads -> pinned staging -> H2D -> kernels -> D2H -> formatter threads -> ordered output
+ * on `n_threads` host threads plus one device thread.  Output: the six texts, appended to the files named in
+ * out_path (parallel pwrite at offsets known from the chunk order) or kept in memory; optionally the per-subject
+ * stdout lines of impute_file (text 6); optionally the raw result records of every chunk (grim_stream_next_records).
+ * The row pool of a chunk is bounded (rows_per_chunk); a chunk that overflows it is split and its halves are run
+ * again, down to single subjects, so no configuration needs a worst-case allocation.
+ * One stream per grim_ctx at a time; the calling thread may block in grim_stream_write while `depth` chunks are in
+ * flight. */
+typedef struct grim_stream grim_stream;
+typedef struct {
+  uint32_t chunk_lines;     /* lines per device batch; 0 = 131072 */
+  uint32_t depth;           /* chunks in flight; 0 = 3 */
+  int32_t n_threads;        /* tokenizer / formatter threads; 0 = all cores (at most 32) */
+  uint64_t line_offset;     /* global index of the first line (multi-GPU shards keep the reference's line numbers) */
+  uint64_t rows_per_chunk;  /* row pool of one chunk; 0 = 32 rows per line (never less than one subject's worst case) */
+  uint8_t want_text;        /* format the six output texts */
+  uint8_t want_log;         /* also text 6: the lines impute_file prints per subject */
+  uint8_t want_records;     /* hand every chunk's records to grim_stream_next_records (the caller must drain them) */
+  uint8_t timing;           /* per-kernel HIP events (grim_batch_set_timing) */
+  const char *out_path[6];  /* per text: file to create and fill, or NULL = keep in memory (grim_stream_text) */
+  /* bin_imputation_in_file phase masks (impute.py:2001-2005, 2030-2032): n_masks ids (NUL-terminated, back to back
+   * in mask_ids) and per id the bitmask of positions that keep their side; an id missing from the table sends its
+   * line to .problem.  NULL = no masks. */
+  const char *mask_ids;
+  const uint8_t *mask_fixed;
+  uint32_t n_masks;
+} grim_stream_opts;
+
+typedef struct {
+  uint64_t lines, subjects, chunks, reruns;          /* reruns: sub-batches run again after a row-pool overflow */
+  uint64_t unsupported;                              /* subjects left out (grim_stream_unsupported) */
+  double wall_s;                                     /* open -> finish */
+  double tokenize_cpu_s, format_cpu_s, write_cpu_s;  /* summed over the worker threads */
+  double device_s;                                   /* device thread busy: copies + kernels + waits */
+  double kernel_ms[6];                               /* sums of grim_batch_kernel_ms(which) over the chunks (timing mode) */
+  uint64_t counters[4];                              /* sums of grim_batch_counters */
+  uint64_t text_bytes[7];
+  uint64_t bytes_h2d, bytes_d2h;
+} grim_stream_stats;
+
+grim_stream *grim_stream_open(grim_ctx *ctx, const grim_graph *g, const grim_dict *dict, const grim_params *prm,
+                              const grim_prior_spec *priors, const char *const *pop_names, uint32_t n_pops,
+                              const grim_stream_opts *opts);
+int grim_stream_write(grim_stream *s, const char *text, uint64_t len);
+/* reads the file in blocks and feeds it (universal newlines: "\r\n" and "\r" end a line too, as Python's open()) */
+int grim_stream_write_file(grim_stream *s, const char *path);
+/* end of input: processes the last partial chunk and waits until every chunk is written; 0 or <0 (grim_stream_error) */
+int grim_stream_finish(grim_stream *s);
+const char *grim_stream_error(const grim_stream *s);
+/* in-memory texts after grim_stream_finish (which: 0..5 as grim_format, 6 = log) */
+const char *grim_stream_text(grim_stream *s, int which, uint64_t *len);
+int grim_stream_get_stats(const grim_stream *s, grim_stream_stats *out);
+/* subjects the device could not resolve (GRIM_ST_UNSUPPORTED / GRIM_K_UNSUPPORTED): global line index, reason, id */
+uint64_t grim_stream_n_unsupported(const grim_stream *s);
+int grim_stream_unsupported(const grim_stream *s, uint64_t k, uint64_t *line, uint32_t *reason, const char **id, uint32_t *id_len);
+/* records mode: blocks until the next chunk (in input order) is done; 1 = a chunk, 0 = end of stream, <0 = error.
+ * kinds[n_lines]; the subject of line j (kind GRIM_K_DEVICE) is res[j]; its rows are rows[res[j].row_off[t] ...].
+ * The pointers stay valid until grim_stream_release_records; the chunk's buffers are not reused before that, so a
+ * caller that never releases stalls the stream after `depth` chunks. */
+typedef struct {
+  uint64_t first_line;
+  uint32_t n_lines;
+  const uint8_t *kinds;
+  const grim_subject_result *res;
+  const grim_row *rows;
+  void *chunk;
+} grim_stream_records;
+int grim_stream_next_records(grim_stream *s, grim_stream_records *out);
+int grim_stream_release_records(grim_stream *s, grim_stream_records *rec);
+void grim_stream_free(grim_stream *s);
 
 #ifdef __cplusplus
 }

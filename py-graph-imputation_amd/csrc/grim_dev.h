@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/grim_hip.h"
+#include "grim_layout.h"
 
 #define GRIM_WG 256
 #define GRIM_NWAVE 4

@@ -16,6 +16,7 @@
 #include "grim_plan_b.h"
 #include "grim_small.h"
 #include "grim_medium.h"
+#include "grim_engine_internal.h"
 
 // =================================================================================================
 // Plan-A kernel: one workgroup per subject, pulled from a work counter.  Waves build the phase
@@ -175,15 +176,26 @@ struct grim_batch {
   grim_ctx *ctx;
   const grim_graph *g;
   DevArgs a;
-  std::vector<void *> bufs;
+  // capacities of the device buffers (a batch made by grim_batch_upload is sized exactly; a stream slot is sized for
+  // the biggest chunk and reloaded chunk after chunk)
+  EngineCaps cap;
+  grim_subject *d_subj;
+  uint16_t *d_tok;
+  double *d_priors;
+  SmallRec *d_small;
+  uint32_t *d_os, *d_om, *d_og, *d_bail, *d_next, *d_small_ctr;
+  grim_subject_result *d_res;
+  grim_row *d_rows;
+  unsigned long long *d_state;
+  EngineHost h;        // pinned staging (inputs) and landing area (results)
+  uint64_t h_rows_cap; // rows the pinned landing area holds
   uint32_t n_subj, n_slots;
-  SmallRec *small_recs;
   uint32_t n_small_waves;
   bool small_ctr_pending;  // the half-wave kernel's per-wave counts have not been added to `counters` yet
   unsigned long long *hstate;  // pinned: counters + work/row heads of the last run
-  uint32_t *order_s, *order_g, *order_m;  // subjects of the half-wave / general / one-wave kernels
   uint32_t n_medium;
   uint32_t n_small, n_general, small_stride;
+  uint64_t scratch_need;  // bytes of per-workgroup scratch this batch's runs need (bound at run time)
   hipEvent_t ev[8];  // timing mode, kernel start/stop: [3]/[5] half-wave, [0]/[1] one-wave, [6]/[7] general, [4]/[2] Plan B
   bool timing;       // GRIM_TIMING=1 or grim_batch_set_timing: direct launches with per-kernel events instead of the graph replay
   hipGraphExec_t gexec;
@@ -377,130 +389,117 @@ extern "C" void grim_graph_free(grim_graph *g) {
 
 extern "C" uint64_t grim_graph_device_bytes(const grim_graph *g) { return g ? g->bytes : 0; }
 
+
 static uint64_t align256(uint64_t x) { return (x + 255) & ~255ull; }
 
-extern "C" grim_batch *grim_batch_upload(grim_ctx *c, const grim_graph *g, const grim_params *p, const grim_batch_desc *d) {
-  if (!c || !g || !p || !d) return nullptr;
-  hipSetDevice(c->device);
-  if (p->top_n == 0 || p->top_n > GRIM_TOPCAP) { c->err = "grim_batch_upload: max_haplotypes_number_in_phase must be 1..128"; return nullptr; }
-  if (p->n_ladder < 0 || p->n_ladder > GRIM_MAXLADDER) { c->err = "grim_batch_upload: epsilon ladder too long"; return nullptr; }
-  grim_batch *b = new grim_batch();
-  b->ctx = c;
-  b->g = g;
-  b->n_subj = d->n_subjects;
-  b->ms_a = b->ms_b = b->ms_s = 0;
-  b->rows_used = 0;
-  memset(b->counters, 0, sizeof(b->counters));
+static thread_local int tl_device = -1;
+static inline void use_device(int dev) {
+  if (tl_device != dev) {
+    hipSetDevice(dev);
+    tl_device = dev;
+  }
+}
+
+static int env_int(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
+uint32_t engine_small_stride(const grim_params *p) { return GRIM_SMALL_ROWS_FIXED + (p->n_results < 16 ? p->n_results : 16); }
+
+uint64_t engine_rows_per_subject(const grim_params *p, uint32_t P) {
+  return 2ull * p->n_results + 2ull * (p->n_pop_results < (uint64_t)P * P ? p->n_pop_results : (uint64_t)P * P);
+}
+
+template <typename T>
+static bool dev_realloc(T *&ptr, uint64_t n) {
+  if (ptr) hipFree(ptr);
+  ptr = nullptr;
+  return hipMalloc((void **)&ptr, (n ? n : 1) * sizeof(T)) == hipSuccess;
+}
+template <typename T>
+static bool pin_realloc(T *&ptr, uint64_t n) {
+  if (ptr) hipHostFree(ptr);
+  ptr = nullptr;
+  return hipHostMalloc((void **)&ptr, (n ? n : 1) * sizeof(T), hipHostMallocDefault) == hipSuccess;
+}
+
+static uint64_t g_moved[2];
+
+// (re)allocate whatever is smaller than `want`; contents are not kept
+static bool batch_reserve(grim_batch *b, const EngineCaps &want) {
+  grim_ctx *c = b->ctx;
+  bool ok = true;
+  if (want.subj > b->cap.subj || !b->d_subj) {
+    const uint32_t n = want.subj > b->cap.subj ? want.subj : b->cap.subj;
+    const uint64_t small_waves = (((uint64_t)n + GRIM_WG / 32 - 1) / (GRIM_WG / 32)) * (GRIM_WG / 64);
+    ok = ok && dev_realloc(b->d_subj, n) && dev_realloc(b->d_small, n) && dev_realloc(b->d_os, n) && dev_realloc(b->d_om, n) &&
+         dev_realloc(b->d_og, n) && dev_realloc(b->d_bail, n) && dev_realloc(b->d_next, n) && dev_realloc(b->d_res, n) &&
+         dev_realloc(b->d_small_ctr, 2 * small_waves + 2);
+    ok = ok && pin_realloc(b->h.subj, n) && pin_realloc(b->h.small, n) && pin_realloc(b->h.order_s, n) &&
+         pin_realloc(b->h.order_m, n) && pin_realloc(b->h.order_g, n) && pin_realloc(b->h.res, n);
+    b->cap.subj = n;
+  }
+  if (want.tok > b->cap.tok || !b->d_tok) {
+    const uint64_t n = want.tok > b->cap.tok ? want.tok : b->cap.tok;
+    ok = ok && dev_realloc(b->d_tok, n) && pin_realloc(b->h.tok, n);
+    b->cap.tok = n;
+  }
+  if (want.priors > b->cap.priors || !b->d_priors) {
+    const uint32_t n = want.priors > b->cap.priors ? want.priors : b->cap.priors;
+    const uint64_t PP = (uint64_t)b->g->d.P * b->g->d.P;
+    ok = ok && dev_realloc(b->d_priors, ((uint64_t)n + 1) * PP) && pin_realloc(b->h.priors, ((uint64_t)n + 1) * PP);
+    b->cap.priors = n;
+  }
+  if (want.rows > b->cap.rows || !b->d_rows) {
+    uint64_t n = want.rows > b->cap.rows ? want.rows : b->cap.rows;
+    if (n > 0x7FFFFFF0ull) n = 0x7FFFFFF0ull;
+    ok = ok && dev_realloc(b->d_rows, n);
+    b->cap.rows = n;
+  }
+  (void)c;
+  return ok;
+}
+
+static void batch_bind(grim_batch *b) {
   DevArgs &A = b->a;
-  memset(&A, 0, sizeof(A));
-  A.g = g->d;
-  A.prm = *p;
-  const uint32_t P = g->d.P;
-  uint64_t bytes = 0;
-  A.subj = upload(c, b->bufs, d->subjects, d->n_subjects, &bytes);
-  A.tok = upload(c, b->bufs, d->tokens, d->n_tokens, &bytes);
-  {  // the batch's prior matrices + one all-ones matrix for Plan B's second level (impute.py:1696-1700)
-    std::vector<double> pr((size_t)(d->n_priors + 1) * P * P, 1.0);
-    if (d->n_priors) memcpy(pr.data(), d->priors, sizeof(double) * (size_t)d->n_priors * P * P);
-    A.priors = upload(c, b->bufs, pr.data(), pr.size(), &bytes);
-    A.ones_prior = d->n_priors;
-  }
-  // subject classes: fully typed + unambiguous + one population -> half-wave kernel (grim_small.h)
-  std::vector<uint32_t> os, om, og;
-  const bool small_ok = (P == 1) && p->opt_threshold > 1 && !getenv("GRIM_NO_SMALL");
-  for (uint32_t i = 0; i < d->n_subjects; ++i) {
-    const grim_subject &sj = d->subjects[i];
-    bool sm = small_ok && sj.n_loci == GRIM_MAXL && g->d.n_loci == GRIM_MAXL && sj.flags == 0;
-    for (int l = 0; l < GRIM_MAXL && sm; ++l)
-      sm = sj.cnt[l][0] == 1 && sj.cnt[l][1] == 1 && sj.wid[l][0] == 1 && sj.wid[l][1] == 1;
-    if (sm) {
-      os.push_back(i);
-      continue;
-    }
-    // one-wave kernel: all sides opened by the cartesian branch and few candidates in total
-    bool md = !getenv("GRIM_NO_MEDIUM") && sj.n_loci >= 1;
-    double cand = (double)(1u << sj.n_loci), opts = 1.0;
-    for (int l = 0; l < sj.n_loci; ++l) {
-      cand *= (double)(sj.cnt[l][0] > sj.cnt[l][1] ? sj.cnt[l][0] : sj.cnt[l][1]);
-      opts *= (double)(sj.wid[l][0] > sj.wid[l][1] ? sj.wid[l][0] : sj.wid[l][1]);
-    }
-    md = md && cand <= 2048.0 && opts < (double)p->opt_threshold;
-    (md ? om : og).push_back(i);
-  }
-  {  // longest-processing-time-first: heavy subjects (many candidates) start first so that the
-     // work-queue tail is short; stable so equal-cost subjects stay in input order
-    auto cost = [&](uint32_t i) {
-      const grim_subject &sj = d->subjects[i];
-      double c = 1.0;
-      for (int l = 0; l < sj.n_loci; ++l) c *= (double)(sj.cnt[l][0] > sj.cnt[l][1] ? sj.cnt[l][0] : sj.cnt[l][1]);
-      // untyped loci multiply the neighbour fan-out
-      for (int l = sj.n_loci; l < GRIM_MAXL; ++l) c *= 8.0;
-      return c * (double)(1u << (sj.n_loci ? sj.n_loci - 1 : 0));
-    };
-    std::vector<double> cs(d->n_subjects);
-    for (uint32_t i : og) cs[i] = cost(i);
-    std::stable_sort(og.begin(), og.end(), [&](uint32_t a, uint32_t b2) { return cs[a] > cs[b2]; });
-  }
-  b->n_small = (uint32_t)os.size();
-  b->n_general = (uint32_t)og.size();
-  b->small_stride = GRIM_SMALL_ROWS_FIXED + (p->n_results < 16 ? p->n_results : 16);
-  {
-    std::vector<SmallRec> recs(os.size());
-    for (size_t k = 0; k < os.size(); ++k) {
-      const grim_subject &sj = d->subjects[os[k]];
-      SmallRec &r = recs[k];
-      for (int l = 0; l < GRIM_MAXL; ++l) {
-        r.tok[2 * l] = d->tokens[sj.tok_off + 2 * l];
-        r.tok[2 * l + 1] = d->tokens[sj.tok_off + 2 * l + 1];
-        r.slot[l] = sj.slot[l];
-      }
-      r.same = sj.pad[0];
-      r.prior_idx = sj.prior_idx;
-      r.si = os[k];
-    }
-    b->small_recs = upload(c, b->bufs, recs.data(), recs.size(), &bytes);
-    const uint32_t per_block = GRIM_WG / 32;
-    b->n_small_waves = ((b->n_small + per_block - 1) / per_block) * (GRIM_WG / 64);
-    A.small_ctr = upload<uint32_t>(c, b->bufs, nullptr, 2 * (size_t)b->n_small_waves + 2, &bytes);
-  }
-  b->order_s = upload(c, b->bufs, os.data(), os.size(), &bytes);
-  b->order_g = upload(c, b->bufs, og.data(), og.size(), &bytes);
-  b->order_m = upload(c, b->bufs, om.data(), om.size(), &bytes);
-  b->n_medium = (uint32_t)om.size();
-  A.bail_list = upload<uint32_t>(c, b->bufs, nullptr, om.size(), &bytes);
-  A.n_medium = (uint32_t)om.size();
-  A.order = b->order_g;
-  A.n_work = b->n_general;
-  // one state block: counters (8 + 4*64 u64) followed by queue[4] (u32): work counter, row head,
-  // plan-B list length, plan-B work counter
-  A.counters = upload<unsigned long long>(c, b->bufs, nullptr, GRIM_NCTR + 4, &bytes);
+  A.subj = b->d_subj;
+  A.tok = b->d_tok;
+  A.priors = b->d_priors;
+  A.order = b->d_og;
+  A.bail_list = b->d_bail;
+  A.next_list = b->d_next;
+  A.res = b->d_res;
+  A.rows = b->d_rows;
+  A.row_cap = (uint32_t)b->cap.rows;
+  A.small_ctr = b->d_small_ctr;
+  A.counters = b->d_state;
   A.queue = (uint32_t *)(A.counters + GRIM_NCTR);
   A.row_head = A.queue + 1;
   A.next_count = A.queue + 2;
-  b->hstate = nullptr;
-  if (hipHostMalloc((void **)&b->hstate, 8 * (GRIM_NCTR + 4)) != hipSuccess) b->hstate = nullptr;
-  A.next_list = upload<uint32_t>(c, b->bufs, nullptr, d->n_subjects, &bytes);
-  A.next_cap = d->n_subjects;
-  A.res = upload<grim_subject_result>(c, b->bufs, nullptr, d->n_subjects, &bytes);
-  // rows: enough for every subject to fill all four tables
-  uint64_t per = 2ull * p->n_results + 2ull * (p->n_pop_results < (uint64_t)P * P ? p->n_pop_results : (uint64_t)P * P);
-  // (fast-path subjects that fall through to Plan B take their rows from the dynamic part)
-  // (+ the gaps of the one-wave kernel's private row blocks: at most as much again as its subjects use, plus
-  //  one unfinished GRIM_ROW_GRAB block per resident wave)
-  uint64_t want = per * d->n_subjects + per * b->n_medium + (uint64_t)b->small_stride * b->n_small + 1024 +
-                  (uint64_t)GRIM_ROW_GRAB * c->n_cu * 32;
-  const char *env_rows = getenv("GRIM_ROW_CAP");
-  if (env_rows) want = strtoull(env_rows, nullptr, 10);
-  if (want > 0x7FFFFFF0ull) want = 0x7FFFFFF0ull;
-  A.row_cap = (uint32_t)want;
-  A.rows = upload<grim_row>(c, b->bufs, nullptr, A.row_cap, &bytes);
-  // scratch slots
-  uint32_t slots = (uint32_t)c->n_cu * 2;
-  const char *env_slots = getenv("GRIM_SLOTS");
-  if (env_slots) slots = (uint32_t)atoi(env_slots);
-  if (slots > d->n_subjects) slots = d->n_subjects;
-  if (slots == 0) slots = 1;
-  b->n_slots = slots;
+}
+
+grim_batch *engine_batch_create(grim_ctx *c, const grim_graph *g, const grim_params *p, const EngineCaps *caps) {
+  if (!c || !g || !p || !caps) return nullptr;
+  use_device(c->device);
+  if (p->top_n == 0 || p->top_n > GRIM_TOPCAP) { c->err = "grim_batch_upload: max_haplotypes_number_in_phase must be 1..128"; return nullptr; }
+  if (p->n_ladder < 0 || p->n_ladder > GRIM_MAXLADDER) { c->err = "grim_batch_upload: epsilon ladder too long"; return nullptr; }
+  grim_batch *b = new grim_batch();
+  memset((void *)b, 0, sizeof(*b));
+  b->ctx = c;
+  b->g = g;
+  DevArgs &A = b->a;
+  A.g = g->d;
+  A.prm = *p;
+  const uint32_t P = g->d.P;
+  b->small_stride = engine_small_stride(p);
+  bool ok = dev_realloc(b->d_state, GRIM_NCTR + 4);
+  if (hipHostMalloc((void **)&b->hstate, 8 * (GRIM_NCTR + 4)) != hipSuccess) {
+    b->hstate = nullptr;
+    ok = false;
+  }
+  ok = ok && batch_reserve(b, *caps);
+  // per-workgroup scratch layout (bytes per slot); the block itself belongs to the context and is bound at run time
   A.pair_cap = GRIM_MAXPH * p->top_n * p->top_n;
   uint32_t tab = 64;
   while (tab < 2 * A.pair_cap) tab <<= 1;
@@ -540,30 +539,165 @@ extern "C" grim_batch *grim_batch_upload(grim_ctx *c, const grim_graph *g, const
   L.proj_p = take(4ull * GRIM_NWAVE * A.proj_cap);
   L.rtok = take(2ull * GRIM_RTOK_CAP);
   L.stride = align256(o);
-  {
-    uint64_t need = (uint64_t)L.stride * slots;
-    if (need > c->scratch_bytes) {
-      if (c->scratch) hipFree(c->scratch);
-      c->scratch = nullptr;
-      c->scratch_bytes = 0;
-      if (hipMalloc(&c->scratch, need) == hipSuccess) c->scratch_bytes = need;
-    }
-    A.scratch = (uint8_t *)c->scratch;
-  }
-  bool ok = A.subj && A.tok && A.priors && b->order_s && b->order_g && b->order_m && A.bail_list && b->small_recs && b->hstate && A.queue && A.next_list && A.res && A.counters && A.rows && A.scratch;
-  b->gexec = nullptr;
-  b->graph_state = 0;
   for (int i = 0; i < 8 && ok; ++i) ok = hipEventCreate(&b->ev[i]) == hipSuccess;
-  b->timing = getenv("GRIM_TIMING") && atoi(getenv("GRIM_TIMING")) != 0;
+  b->timing = env_int("GRIM_TIMING", 0) != 0;
   if (!ok) {
-    c->err = "grim_batch_upload: device allocation or copy failed (" + std::to_string((unsigned long long)(L.stride * slots >> 20)) + " MiB scratch)";
-    for (void *q : b->bufs) hipFree(q);
-    delete b;
+    c->err = "grim_batch: device or pinned-host allocation failed";
+    grim_batch_free(b);
     return nullptr;
   }
-  // heads and counters start clean; after that every run leaves them clean for the next one (grim_finish_kernel)
-  hipLaunchKernelGGL(grim_reset_kernel, dim3(1), dim3(GRIM_WG), 0, c->stream, A.counters, A.queue, b->n_small * b->small_stride);
+  batch_bind(b);
   return b;
+}
+
+int engine_batch_reserve(grim_batch *b, const EngineCaps *caps) {
+  if (!b || !caps) return -1;
+  use_device(b->ctx->device);
+  if (!batch_reserve(b, *caps)) {
+    b->ctx->err = "grim_batch: device or pinned-host allocation failed while growing a batch";
+    return -1;
+  }
+  batch_bind(b);
+  return 0;
+}
+
+void engine_set_error(grim_ctx *c, const char *msg) {
+  if (c) c->err = msg;
+  g_err = msg;
+}
+const EngineHost *engine_batch_host(grim_batch *b) { return b ? &b->h : nullptr; }
+EngineCaps engine_batch_caps(const grim_batch *b) { return b->cap; }
+uint64_t engine_bytes_moved(const grim_batch *, int dir) { return g_moved[dir ? 1 : 0]; }
+
+int engine_batch_load(grim_batch *b, const EngineLoad *ld) {
+  if (!b || !ld) return -1;
+  grim_ctx *c = b->ctx;
+  use_device(c->device);
+  DevArgs &A = b->a;
+  if (ld->n_subj > b->cap.subj || ld->n_priors > b->cap.priors) {
+    c->err = "engine_batch_load: beyond the batch's capacity";
+    return -1;
+  }
+  const uint32_t P = b->g->d.P;
+  const uint64_t PP = (uint64_t)P * P;
+  for (uint64_t k = 0; k < PP; ++k) b->h.priors[(uint64_t)ld->n_priors * PP + k] = 1.0;  // Plan B's second level (impute.py:1696-1700)
+  A.ones_prior = ld->n_priors;
+  hipStream_t st = c->stream;
+  auto up = [&](void *dst, const void *src, uint64_t bytes) {
+    if (!bytes) return true;
+    g_moved[0] += bytes;
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st) == hipSuccess;
+  };
+  bool ok = up(b->d_subj, b->h.subj, sizeof(grim_subject) * (uint64_t)ld->n_subj) &&
+            up(b->d_priors, b->h.priors, 8ull * ((uint64_t)ld->n_priors + 1) * PP) &&
+            up(b->d_small, b->h.small, sizeof(SmallRec) * (uint64_t)ld->n_small) && up(b->d_os, b->h.order_s, 4ull * ld->n_small) &&
+            up(b->d_om, b->h.order_m, 4ull * ld->n_medium) && up(b->d_og, b->h.order_g, 4ull * ld->n_general);
+  for (uint32_t k = 0; k < ld->n_tok_spans && ok; ++k) {
+    if (ld->tok_span_off[k] + ld->tok_span_len[k] > b->cap.tok) ok = false;
+    else ok = up(b->d_tok + ld->tok_span_off[k], b->h.tok + ld->tok_span_off[k], 2ull * ld->tok_span_len[k]);
+  }
+  if (!ok) {
+    c->err = "engine_batch_load: host-to-device copy failed";
+    return -1;
+  }
+  b->n_subj = ld->n_subj;
+  b->n_small = ld->n_small;
+  b->n_medium = ld->n_medium;
+  b->n_general = ld->n_general;
+  A.n_medium = ld->n_medium;
+  A.n_work = ld->n_general;
+  A.next_cap = b->cap.subj;
+  const uint32_t per_block = GRIM_WG / 32;
+  b->n_small_waves = ((b->n_small + per_block - 1) / per_block) * (GRIM_WG / 64);
+  uint32_t slots = (uint32_t)c->n_cu * 2;
+  static const int env_slots = env_int("GRIM_SLOTS", 0);
+  if (env_slots > 0) slots = (uint32_t)env_slots;
+  const uint32_t heavy = ld->n_subj;
+  if (slots > heavy) slots = heavy;
+  if (slots == 0) slots = 1;
+  b->n_slots = slots;
+  b->scratch_need = (uint64_t)A.lay.stride * slots;
+  if (b->gexec) {
+    hipGraphExecDestroy(b->gexec);
+    b->gexec = nullptr;
+  }
+  b->graph_state = 0;
+  b->rows_used = 0;
+  b->small_ctr_pending = false;
+  // heads and counters start clean; after that every run leaves them clean for the next one (grim_finish_kernel)
+  hipLaunchKernelGGL(grim_reset_kernel, dim3(1), dim3(GRIM_WG), 0, st, A.counters, A.queue, b->n_small * b->small_stride);
+  HIPCHK(hipGetLastError(), c, -1);
+  return 0;
+}
+
+extern "C" grim_batch *grim_batch_upload(grim_ctx *c, const grim_graph *g, const grim_params *p, const grim_batch_desc *d) {
+  if (!c || !g || !p || !d) return nullptr;
+  use_device(c->device);
+  const uint32_t P = g->d.P;
+  // subject classes
+  ClassRule rule;
+  rule.small_ok = (P == 1) && p->opt_threshold > 1 && !getenv("GRIM_NO_SMALL");
+  rule.medium_ok = !getenv("GRIM_NO_MEDIUM");
+  rule.graph_loci = g->d.n_loci;
+  rule.opt_threshold = p->opt_threshold;
+  std::vector<uint32_t> os, om, og;
+  for (uint32_t i = 0; i < d->n_subjects; ++i) {
+    const int cls = grim_classify(rule, d->subjects[i]);
+    (cls == GRIM_CLS_SMALL ? os : cls == GRIM_CLS_MEDIUM ? om : og).push_back(i);
+  }
+  {  // longest-processing-time-first; stable so equal-cost subjects stay in input order
+    std::vector<double> cs(d->n_subjects);
+    for (uint32_t i : og) cs[i] = grim_cost(d->subjects[i]);
+    std::stable_sort(og.begin(), og.end(), [&](uint32_t a, uint32_t b2) { return cs[a] > cs[b2]; });
+  }
+  // rows: enough for every subject to fill all four tables (+ the gaps of the one-wave kernel's private row blocks:
+  // at most as much again as its subjects use, plus one unfinished GRIM_ROW_GRAB block per resident wave)
+  const uint64_t per = engine_rows_per_subject(p, P);
+  uint64_t want = per * d->n_subjects + per * om.size() + (uint64_t)engine_small_stride(p) * os.size() + 1024 +
+                  (uint64_t)GRIM_ROW_GRAB * c->n_cu * 32;
+  const char *env_rows = getenv("GRIM_ROW_CAP");
+  if (env_rows) want = strtoull(env_rows, nullptr, 10);
+  if (want > 0x7FFFFFF0ull) want = 0x7FFFFFF0ull;
+  EngineCaps caps{d->n_subjects ? d->n_subjects : 1u, d->n_tokens ? d->n_tokens : 1ull, d->n_priors ? d->n_priors : 1u, want};
+  grim_batch *b = engine_batch_create(c, g, p, &caps);
+  if (!b) return nullptr;
+  if (d->n_subjects) memcpy(b->h.subj, d->subjects, sizeof(grim_subject) * (size_t)d->n_subjects);
+  if (d->n_tokens) memcpy(b->h.tok, d->tokens, 2 * (size_t)d->n_tokens);
+  if (d->n_priors) memcpy(b->h.priors, d->priors, 8 * (size_t)d->n_priors * P * P);
+  for (size_t k = 0; k < os.size(); ++k) {
+    const grim_subject &sj = d->subjects[os[k]];
+    grim_small_rec(sj, d->tokens + sj.tok_off, os[k], b->h.small[k]);
+    b->h.order_s[k] = os[k];
+  }
+  if (!om.empty()) memcpy(b->h.order_m, om.data(), 4 * om.size());
+  if (!og.empty()) memcpy(b->h.order_g, og.data(), 4 * og.size());
+  const uint64_t span_off = 0, span_len = d->n_tokens;
+  EngineLoad ld{d->n_subjects, d->n_priors, (uint32_t)os.size(), (uint32_t)om.size(), (uint32_t)og.size(), 1, &span_off, &span_len};
+  if (engine_batch_load(b, &ld) != 0 || hipStreamSynchronize(c->stream) != hipSuccess) {
+    if (c->err.empty()) c->err = "grim_batch_upload: copy failed";
+    grim_batch_free(b);
+    return nullptr;
+  }
+  return b;
+}
+
+// the context's scratch block: bound when a run starts (never while kernels of this context are in flight: every run
+// of a context is synchronous and a context is used by one thread at a time), so a batch never keeps a stale pointer
+static int bind_scratch(grim_batch *b) {
+  grim_ctx *c = b->ctx;
+  if (b->scratch_need > c->scratch_bytes) {
+    if (c->scratch) hipFree(c->scratch);
+    c->scratch = nullptr;
+    c->scratch_bytes = 0;
+    if (hipMalloc(&c->scratch, b->scratch_need) != hipSuccess) {
+      (void)hipGetLastError();
+      c->err = "grim_batch_run: cannot allocate " + std::to_string((unsigned long long)(b->scratch_need >> 20)) + " MiB of scratch";
+      return -1;
+    }
+    c->scratch_bytes = b->scratch_need;
+  }
+  b->a.scratch = (uint8_t *)c->scratch;
+  return 0;
 }
 
 // Stage 1 of a run: half-wave kernel, one-wave kernel, general plan-A kernel, finish kernel (state to the pinned
@@ -578,20 +712,20 @@ static int enqueue_stage1(grim_batch *b, bool timing) {
     const dim3 grid((b->n_small + per_block - 1) / per_block), block(GRIM_WG);
     if (timing)
       hipExtLaunchKernelGGL(grim_plan_a_small_kernel, grid, block, 0, c->stream, b->ev[3], b->ev[5], 0, A,
-                            (const SmallRec *)b->small_recs, b->n_small, 0u, b->small_stride);
+                            (const SmallRec *)b->d_small, b->n_small, 0u, b->small_stride);
     else
-      hipLaunchKernelGGL(grim_plan_a_small_kernel, grid, block, 0, c->stream, A, (const SmallRec *)b->small_recs, b->n_small, 0u,
+      hipLaunchKernelGGL(grim_plan_a_small_kernel, grid, block, 0, c->stream, A, (const SmallRec *)b->d_small, b->n_small, 0u,
                          b->small_stride);
   }
   if (b->n_medium) {
-    static const int waves_per_cu = getenv("GRIM_MEDIUM_WAVES") ? atoi(getenv("GRIM_MEDIUM_WAVES")) : GRIM_MEDIUM_WAVES_PER_CU;
+    static const int waves_per_cu = env_int("GRIM_MEDIUM_WAVES", GRIM_MEDIUM_WAVES_PER_CU);
     uint32_t grid = (uint32_t)c->n_cu * (uint32_t)(waves_per_cu > 0 ? waves_per_cu : GRIM_MEDIUM_WAVES_PER_CU);
     if (grid > b->n_medium) grid = b->n_medium;
     if (timing)
       hipExtLaunchKernelGGL(grim_plan_a_medium_kernel, dim3(grid), dim3(64), 0, c->stream, b->ev[0], b->ev[1], 0, A,
-                            (const uint32_t *)b->order_m, b->n_medium, A.bail_list);
+                            (const uint32_t *)b->d_om, b->n_medium, A.bail_list);
     else
-      hipLaunchKernelGGL(grim_plan_a_medium_kernel, dim3(grid), dim3(64), 0, c->stream, A, (const uint32_t *)b->order_m,
+      hipLaunchKernelGGL(grim_plan_a_medium_kernel, dim3(grid), dim3(64), 0, c->stream, A, (const uint32_t *)b->d_om,
                          b->n_medium, A.bail_list);
   }
   if (b->n_general + b->n_medium) {
@@ -603,7 +737,7 @@ static int enqueue_stage1(grim_batch *b, bool timing) {
       hipLaunchKernelGGL(grim_plan_a_kernel, grid, block, 0, c->stream, A);
   }
   hipLaunchKernelGGL(grim_finish_kernel, dim3(1), dim3(GRIM_WG), 0, c->stream, A.counters, b->hstate, b->n_small * b->small_stride, 0);
-  return 0;
+  return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 extern "C" int grim_batch_set_timing(grim_batch *b, int on) {
@@ -617,13 +751,15 @@ extern "C" int grim_batch_set_timing(grim_batch *b, int on) {
 extern "C" int grim_batch_run(grim_batch *b) {
   if (!b) return -1;
   grim_ctx *c = b->ctx;
-  hipSetDevice(c->device);
+  use_device(c->device);
   DevArgs &A = b->a;
-  // ---- stage 1 (captured once per batch, then replayed: one API call instead of eight) ----------
+  if (bind_scratch(b) != 0) return -1;
   b->ms_s = b->ms_a = b->ms_g = b->ms_m = 0;
   if (b->timing) {
-    if (enqueue_stage1(b, true) != 0) return -1;
-    HIPCHK(hipGetLastError(), c, -1);
+    if (enqueue_stage1(b, true) != 0) {
+      c->err = "grim_batch_run: kernel launch failed";
+      return -1;
+    }
     HIPCHK(hipStreamSynchronize(c->stream), c, -1);
     if (b->n_small) HIPCHK(hipEventElapsedTime(&b->ms_s, b->ev[3], b->ev[5]), c, -1);
     if (b->n_medium) HIPCHK(hipEventElapsedTime(&b->ms_m, b->ev[0], b->ev[1]), c, -1);
@@ -634,8 +770,8 @@ extern "C" int grim_batch_run(grim_batch *b) {
       b->graph_state = -1;
       // measured on MI355X / ROCm 7.2 (tools/step_time.py, 10k-subject batch): replaying the captured stage costs
       // 26.9 us per synchronous run, launching its two kernels directly 21.8 us -- so the replay is opt-in
-      if (getenv("GRIM_GRAPH") && atoi(getenv("GRIM_GRAPH")) != 0 &&
-          hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+      static const int use_graph = env_int("GRIM_GRAPH", 0);
+      if (use_graph && hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
         int rc = enqueue_stage1(b, false);
         hipGraph_t gr = nullptr;
         hipError_t e = hipStreamEndCapture(c->stream, &gr);
@@ -647,9 +783,9 @@ extern "C" int grim_batch_run(grim_batch *b) {
     }
     if (b->graph_state == 1) {
       HIPCHK(hipGraphLaunch(b->gexec, c->stream), c, -1);
-    } else {
-      if (enqueue_stage1(b, false) != 0) return -1;
-      HIPCHK(hipGetLastError(), c, -1);
+    } else if (enqueue_stage1(b, false) != 0) {
+      c->err = "grim_batch_run: kernel launch failed";
+      return -1;
     }
     HIPCHK(hipStreamSynchronize(c->stream), c, -1);
   }
@@ -660,10 +796,11 @@ extern "C" int grim_batch_run(grim_batch *b) {
   if (A.prm.planb && head[2] + head[6] > 0) {
     uint32_t grid = b->n_slots < head[2] + head[6] ? b->n_slots : head[2] + head[6];
     if (grim_launch_plan_b(A, grid, c->stream, b->timing ? b->ev[4] : nullptr, b->timing ? b->ev[2] : nullptr) != 0) {
-      c->err = "plan-B launch failed";
+      c->err = "grim_batch_run: plan-B launch failed";
       return -1;
     }
     hipLaunchKernelGGL(grim_finish_kernel, dim3(1), dim3(GRIM_WG), 0, c->stream, A.counters, b->hstate, b->n_small * b->small_stride, 1);
+    HIPCHK(hipGetLastError(), c, -1);
     HIPCHK(hipStreamSynchronize(c->stream), c, -1);
     if (b->timing) HIPCHK(hipEventElapsedTime(&b->ms_b, b->ev[4], b->ev[2]), c, -1);
     memcpy(head, b->hstate + GRIM_NCTR, 32);
@@ -673,7 +810,8 @@ extern "C" int grim_batch_run(grim_batch *b) {
     for (int k = 0; k < 6; ++k) b->acc_ms[k] += v[k];
     b->n_timed++;
   }
-  if (getenv("GRIM_DEBUG_CLASSES"))
+  static const int dbg_classes = env_int("GRIM_DEBUG_CLASSES", 0);
+  if (dbg_classes)
     fprintf(stderr, "grim classes: small %u medium %u general %u | medium->general %u (+%u heavier), to plan B %u (+%u heavy) | stage 1 %s\n",
             b->n_small, b->n_medium, b->n_general, head[5], head[7], head[2], head[6], b->graph_state == 1 ? "replayed as a hipGraph" : "launched directly");
   memcpy(b->counters, b->hstate, 64);
@@ -687,6 +825,7 @@ extern "C" int grim_batch_run(grim_batch *b) {
   fprintf(stderr, "\n");
 #endif
   if (b->counters[4] != 0 || head[1] > A.row_cap) {
+    if (b->rows_used > A.row_cap) b->rows_used = A.row_cap;
     c->err = "grim_batch_run: output row pool exhausted (raise GRIM_ROW_CAP or lower the batch size)";
     return -2;
   }
@@ -720,7 +859,7 @@ extern "C" int grim_batch_counters(const grim_batch *cb, uint64_t out[4]) {
   grim_batch *b = const_cast<grim_batch *>(cb);  // lazily folds the half-wave kernel's per-wave counts in
   if (b->small_ctr_pending) {
     grim_ctx *c = b->ctx;
-    hipSetDevice(c->device);
+    use_device(c->device);
     std::vector<uint32_t> h(2 * (size_t)b->n_small_waves);
     HIPCHK(hipMemcpy(h.data(), b->a.small_ctr, 4 * h.size(), hipMemcpyDeviceToHost), c, -1);
     for (size_t i = 0; i < h.size(); i += 2) {
@@ -738,21 +877,60 @@ extern "C" int grim_batch_counters(const grim_batch *cb, uint64_t out[4]) {
 
 extern "C" uint32_t grim_batch_total_rows(const grim_batch *b) { return b ? b->rows_used : 0; }
 
+int engine_batch_fetch(grim_batch *b, uint32_t res_lo, uint32_t res_hi, grim_row *rows_dst) {
+  if (!b) return -1;
+  grim_ctx *c = b->ctx;
+  use_device(c->device);
+  if (res_hi > b->n_subj) res_hi = b->n_subj;
+  if (res_hi > res_lo) {
+    HIPCHK(hipMemcpyAsync(b->h.res + res_lo, b->d_res + res_lo, sizeof(grim_subject_result) * (uint64_t)(res_hi - res_lo),
+                          hipMemcpyDeviceToHost, c->stream), c, -1);
+    g_moved[1] += sizeof(grim_subject_result) * (uint64_t)(res_hi - res_lo);
+  }
+  if (b->rows_used) {
+    if (!rows_dst) {
+      if (b->rows_used > b->h_rows_cap) {
+        uint64_t n = b->h_rows_cap ? b->h_rows_cap : 1024;
+        while (n < b->rows_used) n *= 2;
+        if (n > b->cap.rows) n = b->cap.rows;
+        if (!pin_realloc(b->h.rows, n)) {
+          b->h_rows_cap = 0;
+          c->err = "engine_batch_fetch: pinned allocation failed";
+          return -1;
+        }
+        b->h_rows_cap = n;
+      }
+      rows_dst = b->h.rows;
+    }
+    HIPCHK(hipMemcpyAsync(rows_dst, b->d_rows, sizeof(grim_row) * (uint64_t)b->rows_used, hipMemcpyDeviceToHost, c->stream), c, -1);
+    g_moved[1] += sizeof(grim_row) * (uint64_t)b->rows_used;
+  }
+  HIPCHK(hipStreamSynchronize(c->stream), c, -1);
+  return 0;
+}
+
 extern "C" int grim_batch_results(grim_batch *b, grim_subject_result *res, grim_row *rows) {
   if (!b) return -1;
   grim_ctx *c = b->ctx;
-  hipSetDevice(c->device);
-  if (b->n_subj) HIPCHK(hipMemcpy(res, b->a.res, sizeof(grim_subject_result) * (size_t)b->n_subj, hipMemcpyDeviceToHost), c, -1);
-  if (b->rows_used) HIPCHK(hipMemcpy(rows, b->a.rows, sizeof(grim_row) * (size_t)b->rows_used, hipMemcpyDeviceToHost), c, -1);
+  use_device(c->device);
+  if (b->n_subj) HIPCHK(hipMemcpy(res, b->d_res, sizeof(grim_subject_result) * (size_t)b->n_subj, hipMemcpyDeviceToHost), c, -1);
+  if (b->rows_used) HIPCHK(hipMemcpy(rows, b->d_rows, sizeof(grim_row) * (size_t)b->rows_used, hipMemcpyDeviceToHost), c, -1);
   return 0;
 }
 
 extern "C" void grim_batch_free(grim_batch *b) {
   if (!b) return;
-  hipSetDevice(b->ctx->device);
-  for (int i = 0; i < 8; ++i) hipEventDestroy(b->ev[i]);
+  use_device(b->ctx->device);
+  hipStreamSynchronize(b->ctx->stream);
+  for (int i = 0; i < 8; ++i)
+    if (b->ev[i]) hipEventDestroy(b->ev[i]);
   if (b->gexec) hipGraphExecDestroy(b->gexec);
-  for (void *p : b->bufs) hipFree(p);
-  if (b->hstate) hipHostFree(b->hstate);
+  void *dev[] = {b->d_subj, b->d_tok, b->d_priors, b->d_small, b->d_os, b->d_om, b->d_og, b->d_bail, b->d_next, b->d_small_ctr,
+                 b->d_res, b->d_rows, b->d_state};
+  for (void *p : dev)
+    if (p) hipFree(p);
+  void *pin[] = {b->h.subj, b->h.tok, b->h.priors, b->h.small, b->h.order_s, b->h.order_m, b->h.order_g, b->h.res, b->h.rows, b->hstate};
+  for (void *p : pin)
+    if (p) hipHostFree(p);
   delete b;
 }

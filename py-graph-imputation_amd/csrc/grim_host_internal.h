@@ -1,6 +1,7 @@
 // grim_host_internal.h -- shared by the host-side translation units of the library (no GPU code)
 #pragma once
 #include <stdint.h>
+#include <string.h>
 
 #include <string>
 #include <string_view>
@@ -8,6 +9,7 @@
 #include <vector>
 
 #include "../../include/grim_hip.h"
+#include "grim_layout.h"
 
 using sv = std::string_view;
 
@@ -22,3 +24,202 @@ struct grim_dict {
 
 int32_t dict_intern(grim_dict *d, uint32_t slot, sv a);  // -1 when the locus has run out of ids
 void py_float(double x, std::string &out);               // CPython str(float)
+char *py_float_to(double x, char *out);                  // same, into a buffer with >= 32 bytes of room; returns the end
+
+// ---- frozen view of a dictionary: what the tokenizer and the formatter threads read (never mutated) --------------
+// Alleles a subject brings that the dictionary does not know are NOT added to it (the dictionary belongs to the
+// graph and lives as long as the graph does): they get ids base[slot], base[slot]+1, ... that are private to that
+// one subject (an "overlay"), which is all the device needs -- it never compares alleles of different subjects.
+struct DictSnap {
+  struct Ent {
+    uint64_t h;
+    uint32_t id, off, len, used;
+  };
+  struct Locus {
+    std::string name;
+    uint32_t slot;
+  };
+  uint32_t n_loci = 0;
+  uint32_t base[GRIM_MAXL] = {0, 0, 0, 0, 0};
+  std::string pool;
+  std::vector<uint32_t> name_off[GRIM_MAXL];  // [base + 1]
+  std::vector<Ent> tab[GRIM_MAXL];
+  uint32_t mask[GRIM_MAXL] = {0, 0, 0, 0, 0};
+  std::vector<Locus> loci;
+  uint8_t order[GRIM_MAXL] = {0, 1, 2, 3, 4};  // slots in the order sorted() puts a haplotype's allele names
+  bool fixed_order = false;                    // ... which is the same for every haplotype (locus names are alphanumeric)
+
+  static inline uint64_t hash(sv s) {
+    const char *p = s.data();
+    const size_t n = s.size();
+    uint64_t a, b;
+    if (n >= 8) {
+      memcpy(&a, p, 8);
+      memcpy(&b, p + n - 8, 8);
+      for (size_t i = 8; i + 8 < n; i += 8) {
+        uint64_t c;
+        memcpy(&c, p + i, 8);
+        a = (a ^ c) * 0x9E3779B97F4A7C15ull;
+        a ^= a >> 29;
+      }
+    } else if (n >= 4) {
+      uint32_t x, y;
+      memcpy(&x, p, 4);
+      memcpy(&y, p + n - 4, 4);
+      a = x;
+      b = y;
+    } else if (n > 0) {
+      a = (uint8_t)p[0] | ((uint64_t)(uint8_t)p[n >> 1] << 8) | ((uint64_t)(uint8_t)p[n - 1] << 16);
+      b = 0;
+    } else {
+      a = b = 0;
+    }
+    uint64_t h = (a ^ 0xff51afd7ed558ccdULL) * (b ^ 0xc4ceb9fe1a85ec53ULL ^ (uint64_t)n);
+    h ^= h >> 32;
+    h *= 0x9E3779B97F4A7C15ull;
+    h ^= h >> 29;
+    return h;
+  }
+  inline int32_t find(uint32_t slot, sv a) const {
+    const uint64_t h = hash(a);
+    const uint32_t m = mask[slot];
+    const Ent *t = tab[slot].data();
+    for (uint32_t i = (uint32_t)h & m;; i = (i + 1) & m) {
+      const Ent &e = t[i];
+      if (!e.used) return -1;
+      if (e.h == h && e.len == a.size() && memcmp(pool.data() + e.off, a.data(), a.size()) == 0) return (int32_t)e.id;
+    }
+  }
+  inline sv name(uint32_t slot, uint32_t id) const {
+    const uint32_t o = name_off[slot][id];
+    return sv(pool.data() + o, name_off[slot][id + 1] - o);
+  }
+  inline int32_t find_locus(sv l) const {
+    for (const Locus &x : loci)
+      if (x.name.size() == l.size() && memcmp(x.name.data(), l.data(), l.size()) == 0) return (int32_t)x.slot;
+    return -1;
+  }
+};
+void dict_snapshot(const grim_dict *d, DictSnap &out);
+
+// ---- tokenizer core: a byte range of whole lines -> per-line outcome, subject records, tokens -----------------------
+enum { K_DEV = 0, K_PROBLEM_ID = 1, K_PROBLEM_RAW = 2, K_MISS_NO_DEVICE = 3, K_UNSUPPORTED = 4 };
+
+struct LineInfo {
+  uint64_t off;     // start of the line in the text
+  uint32_t len;     // without trailing white space
+  uint32_t id_len;  // the subject id is the first id_len bytes
+};
+
+struct OvEnt {  // an allele outside the dictionary: (line, slot, id) -> its text (a copy in the range's ov_pool)
+  uint32_t line;  // line number inside the range
+  uint16_t id;
+  uint8_t slot;
+  uint8_t pad;
+  uint32_t len;
+  uint64_t off;
+};
+
+// resolves a (race1, race2) pair to the index of its prior matrix; must be callable from several threads
+struct RaceResolver {
+  virtual ~RaceResolver() {}
+  virtual uint32_t resolve(sv r1, sv r2) = 0;
+};
+
+// per-id phase masks (bin_imputation_in_file, impute.py:2001-2005, 2030-2032): id -> bitmask of positions that keep
+// their side in every phase; an id that is not in the table sends its line to .problem (KeyError in the reference)
+struct MaskTable {
+  std::unordered_map<std::string, uint8_t> fixed;
+};
+
+struct TokParams {
+  const DictSnap *snap;
+  bool planb;
+  RaceResolver *races;
+  const MaskTable *masks;     // or null
+  const ClassRule *classify;  // or null: no class lists
+};
+
+struct TokRange {
+  // per line of the range
+  std::vector<uint8_t> kind;
+  std::vector<LineInfo> line;
+  std::vector<int32_t> dev;  // dense mode: subject number inside the range, or -1
+  // subjects and tokens: dense mode appends to the vectors; slab mode writes subject k at subj_dst[line number] and
+  // tokens into tok_dst[0 .. tok_cap) (tok_off = tok_base + position)
+  bool dense = true;
+  std::vector<grim_subject> subj;
+  std::vector<uint16_t> tok;
+  grim_subject *subj_dst = nullptr;
+  uint16_t *tok_dst = nullptr;
+  uint64_t tok_cap = 0, tok_base = 0;
+  uint64_t n_tok = 0;
+  uint32_t n_subj = 0;
+  std::vector<OvEnt> ov;
+  std::string ov_pool;
+  bool race_overflow = false;  // more than 65534 distinct race pairs
+  // class lists (subject numbers as the device will see them: first_subject + ...), when TokParams.classify is set
+  uint32_t first_subject = 0;
+  std::vector<uint32_t> os, om, og;
+  std::vector<SmallRec> small;
+  void clear() {
+    kind.clear(); line.clear(); dev.clear(); subj.clear(); tok.clear(); ov.clear(); ov_pool.clear(); os.clear(); om.clear(); og.clear();
+    small.clear();
+    n_tok = 0; n_subj = 0; race_overflow = false;
+  }
+};
+
+// text[lo, hi) must consist of whole lines ('\n' terminated, except possibly the last one)
+void tokenize_range(const TokParams &prm, const char *text, uint64_t lo, uint64_t hi, TokRange &out);
+
+// ---- formatter core ---------------------------------------------------------------------------------------------------
+struct OutBuf {
+  char *p = nullptr;
+  size_t n = 0, cap = 0;
+  ~OutBuf() { free(p); }
+  OutBuf() {}
+  OutBuf(const OutBuf &) = delete;
+  OutBuf &operator=(const OutBuf &) = delete;
+  inline char *room(size_t k) {
+    if (n + k > cap) grow(k);
+    return p + n;
+  }
+  void grow(size_t k);
+  inline void put(sv s) {
+    char *q = room(s.size());
+    memcpy(q, s.data(), s.size());
+    n += s.size();
+  }
+  inline void put(char c) {
+    *room(1) = c;
+    ++n;
+  }
+  void clear() { n = 0; }
+};
+
+struct FmtParams {
+  const DictSnap *snap;
+  const grim_params *prm;
+  std::vector<std::string> pops;
+  bool want_log = false;     // also the per-subject stdout lines of impute_file (impute.py:2074-2078, 2108-2112, 2138, 2142)
+  double per_subject_s = 0;  // the number printed after a subject's lines
+};
+
+struct FmtRange {
+  OutBuf t[7];  // umug, umug_pops, pmug, pmug_pops, miss, problem, log
+  std::vector<uint32_t> unsupported;  // line numbers (inside the range) of GRIM_ST_UNSUPPORTED subjects, left out of every text
+};
+
+// lines [0, n) of a tokenized range; res/rows as the device returned them; subject number of line j = dev ? dev[j]
+// : first_subject + j; first_line = global index of line 0 (the i of "i,id" in .miss/.problem); skip: optional per line
+void format_range(const FmtParams &fp, const char *text, const TokRange &tr, const grim_subject_result *res, const grim_row *rows,
+                  uint64_t first_line, const uint8_t *skip, FmtRange &out);
+
+// calc_priority_matrix (impute.py:1844-1924) for one race pair, in the reference's operation order; out[P*P]
+struct PriorSpec {
+  double alpha, eta, beta, gamma, delta;
+  bool unk_mr;                         // UNK_priors == "MR": all-ones base matrix, else identity
+  std::vector<double> count_by_prob;   // [P]
+  std::vector<std::string> pops;
+};
+void prior_matrix(const PriorSpec &ps, sv race1, sv race2, double *out);

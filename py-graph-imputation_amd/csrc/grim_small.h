@@ -16,7 +16,6 @@
 #pragma once
 #include "grim_pair.h"
 
-#define GRIM_SMALL_ROWS_FIXED 3  // umug, umug.pops, pmug.pops; then up to 16 pmug rows
 
 __device__ __forceinline__ double half_shfl_d(double v, int src_in_half) {
   return __shfl(v, (threadIdx.x & 32) | src_in_half);
@@ -43,15 +42,7 @@ __device__ __forceinline__ double row16_max(double v) {
   return v;
 }
 
-// what the library keeps in HBM per fast-path subject (built once in grim_batch_upload)
-struct SmallRec {
-  uint16_t tok[2 * GRIM_MAXL];  // position l: side-1 allele, side-2 allele
-  uint8_t slot[GRIM_MAXL];
-  uint8_t same;                 // positions whose two sides are textually identical
-  uint16_t prior_idx;
-  uint32_t si;                  // subject index in the batch
-};                              // 32 bytes
-
+// SmallRec (grim_layout.h): what the library keeps in HBM per fast-path subject, 32 bytes
 __global__ __launch_bounds__(GRIM_WG) void grim_plan_a_small_kernel(DevArgs A, const SmallRec *recs, uint32_t n,
                                                                    uint32_t row_base, uint32_t row_stride) {
   const DevGraph &g = A.g;

@@ -1,0 +1,847 @@
+// grim_stream.cpp -- the streaming pipeline behind grim_stream_* (include/grim_hip.h): impute_file's loop
+// (impute.py:2019-2144: read a line, parse, impute, write) as a chunked, overlapped pipeline
+//
+//     caller's bytes -> chunks of whole lines -> [worker threads] tokenize ranges of the chunk straight into the
+//     chunk's pinned staging area -> [device thread] H2D, kernels, D2H into the pinned landing area ->
+//     [worker threads] format ranges -> commit in input order (file offsets) -> [worker threads] pwrite
+//
+// `depth` chunks are in flight, each owning one capacity batch of the engine (grim_engine_internal.h), so the
+// tokenizer of chunk k+1, the kernels of chunk k and the formatter of chunk k-1 run at the same time.  Subject number
+// inside a chunk = line number inside the chunk (no compaction pass); tokens of a range go to the range's own slab of
+// the staging area (one H2D copy per range); a chunk whose results overflow its bounded row pool is split and run
+// again in halves.  No GPU code here: the device work goes through the engine.
+#include <errno.h>
+#include <fcntl.h>
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <sys/stat.h>
+#include <sys/types.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/grim_hip.h"
+#include "grim_engine_internal.h"
+#include "grim_host_internal.h"
+
+namespace {
+
+using Clock = std::chrono::steady_clock;
+static inline double secs(Clock::time_point a, Clock::time_point b) { return std::chrono::duration<double>(b - a).count(); }
+
+struct StreamRaces : RaceResolver {  // race pair -> prior matrix, shared by every chunk of the stream
+  std::mutex mu;
+  std::unordered_map<std::string, uint32_t> idx;
+  std::vector<double> mats;  // [n][P*P]
+  PriorSpec ps;
+  uint32_t n = 0;
+  uint32_t resolve(sv r1, sv r2) override {
+    std::string key;
+    key.reserve(r1.size() + r2.size() + 1);
+    key.append(r1);
+    key.push_back('\x01');
+    key.append(r2);
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = idx.find(key);
+    if (it != idx.end()) return it->second;
+    if (n >= 0xFFFEu) return 0xFFFFFFFFu;
+    const size_t PP = ps.pops.size() * ps.pops.size();
+    mats.resize((size_t)(n + 1) * PP);
+    prior_matrix(ps, r1, r2, mats.data() + (size_t)n * PP);
+    idx.emplace(std::move(key), n);
+    return n++;
+  }
+};
+
+enum { CH_FREE = 0, CH_FILLING, CH_TOKENIZING, CH_TOKENIZED, CH_DEVICE_DONE, CH_FORMATTED, CH_COMMITTED, CH_WRITTEN };
+
+struct Chunk {
+  int slot_no = 0;
+  grim_batch *batch = nullptr;
+  uint64_t index = 0, first_line = 0;
+  std::string text;
+  uint32_t n_lines = 0;
+  std::vector<uint64_t> mark_off;  // byte offset of line k * granule
+  // ranges
+  uint32_t n_ranges = 0;
+  std::vector<uint64_t> cut;               // [R + 1] byte boundaries
+  std::vector<uint32_t> range_first_line;  // [R + 1]
+  std::vector<uint64_t> slab_off, slab_cap;
+  std::vector<TokRange> tr;
+  std::vector<std::unique_ptr<FmtRange>> fr;
+  std::vector<std::array<uint64_t, 7>> file_off;
+  std::atomic<int> pending{0};
+  int state = CH_FREE;
+  // master class lists of the chunk (subject numbers = line numbers)
+  std::vector<uint32_t> os, om, og;
+  std::vector<SmallRec> small;
+  std::vector<uint8_t> kinds;       // records mode
+  std::vector<grim_row> extra_rows;  // rows of a chunk that had to be run in parts
+  const grim_row *rows = nullptr;
+  double device_s = 0;
+  uint32_t n_dev_subjects = 0;
+  bool records_out = false, records_released = false;
+};
+
+struct Task {
+  int type;  // 0 tokenize, 1 format, 2 write
+  Chunk *c;
+  uint32_t r;
+};
+
+}  // namespace
+
+struct grim_stream {
+  grim_ctx *ctx = nullptr;
+  const grim_graph *graph = nullptr;
+  grim_params prm;
+  grim_stream_opts opt;
+  DictSnap snap;
+  StreamRaces races;
+  MaskTable masks;
+  bool have_masks = false;
+  ClassRule rule;
+  FmtParams fp;
+  uint32_t n_pops = 0;
+  uint32_t chunk_lines = 0, granule = 1024, n_threads = 1, depth = 0;
+  uint64_t rows_per_chunk = 0;
+
+  std::vector<std::unique_ptr<Chunk>> chunks;  // the `depth` slots
+  Chunk *filling = nullptr;
+  uint64_t next_index = 0, next_line = 0;
+  bool carry_cr = false;
+
+  std::mutex mu;  // guards task queues, chunk states, commit state
+  std::condition_variable cv_work, cv_dev, cv_slot, cv_rec, cv_done;
+  std::deque<Task> q_hi, q_lo;
+  bool stop = false, failed = false, input_closed = false;
+  std::string err;
+  std::vector<std::thread> workers;
+  std::thread dev_thread;
+  uint64_t next_device = 0, next_commit = 0, next_record = 0, n_done = 0;
+
+  int fd[6] = {-1, -1, -1, -1, -1, -1};
+  uint64_t file_pos[7] = {0, 0, 0, 0, 0, 0, 0};
+  std::vector<std::pair<char *, size_t>> mem[7];  // in-memory sinks: buffers in commit order
+  std::string joined[7];
+  bool joined_ok[7] = {false, false, false, false, false, false, false};
+
+  struct Unsup {
+    uint64_t line;
+    uint32_t reason;
+    std::string id;
+  };
+  std::vector<Unsup> unsupported;
+
+  Clock::time_point t_open;
+  grim_stream_stats st;
+  std::atomic<uint64_t> tok_ns{0}, fmt_ns{0}, wr_ns{0};
+
+  void fail(const std::string &m) {  // mu held
+    if (!failed) {
+      failed = true;
+      err = m;
+    }
+    cv_work.notify_all();
+    cv_dev.notify_all();
+    cv_slot.notify_all();
+    cv_rec.notify_all();
+    cv_done.notify_all();
+  }
+  Chunk *by_index(uint64_t idx) {
+    for (auto &c : chunks)
+      if (c->state != CH_FREE && c->index == idx) return c.get();
+    return nullptr;
+  }
+};
+
+static void release_if_done(grim_stream *s, Chunk *c) {  // mu held
+  if (c->state != CH_WRITTEN) return;
+  if (s->opt.want_records && !c->records_released) return;
+  c->state = CH_FREE;
+  ++s->n_done;
+  s->cv_slot.notify_all();
+  s->cv_done.notify_all();
+}
+
+// ---- stage: tokenize one range ---------------------------------------------------------------------------------------
+static void assemble(grim_stream *s, Chunk *c) {
+  c->os.clear();
+  c->om.clear();
+  c->og.clear();
+  c->small.clear();
+  c->n_dev_subjects = 0;
+  bool race_overflow = false;
+  for (uint32_t r = 0; r < c->n_ranges; ++r) {
+    TokRange &T = c->tr[r];
+    c->os.insert(c->os.end(), T.os.begin(), T.os.end());
+    c->small.insert(c->small.end(), T.small.begin(), T.small.end());
+    c->om.insert(c->om.end(), T.om.begin(), T.om.end());
+    c->og.insert(c->og.end(), T.og.begin(), T.og.end());
+    c->n_dev_subjects += T.n_subj;
+    race_overflow = race_overflow || T.race_overflow;
+  }
+  if (s->opt.want_records) {
+    c->kinds.clear();
+    for (uint32_t r = 0; r < c->n_ranges; ++r) c->kinds.insert(c->kinds.end(), c->tr[r].kind.begin(), c->tr[r].kind.end());
+  }
+  std::lock_guard<std::mutex> lk(s->mu);
+  if (race_overflow) s->fail("more than 65534 distinct race pairs in one run");
+  c->state = CH_TOKENIZED;
+  s->cv_dev.notify_all();
+}
+
+static void run_tokenize(grim_stream *s, Chunk *c, uint32_t r) {
+  const auto t0 = Clock::now();
+  const EngineHost *H = engine_batch_host(c->batch);
+  TokRange &T = c->tr[r];
+  T.clear();
+  T.dense = false;
+  T.first_subject = c->range_first_line[r];
+  T.subj_dst = H->subj + c->range_first_line[r];
+  T.tok_dst = H->tok + c->slab_off[r];
+  T.tok_cap = c->slab_cap[r];
+  T.tok_base = c->slab_off[r];
+  TokParams tp{&s->snap, s->prm.planb != 0, &s->races, s->have_masks ? &s->masks : nullptr, &s->rule};
+  tokenize_range(tp, c->text.data(), c->cut[r], c->cut[r + 1], T);
+  const uint32_t expect = c->range_first_line[r + 1] - c->range_first_line[r];
+  if (T.kind.size() != expect) {
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->fail("internal: a range's line count differs from the reader's");
+  }
+  s->tok_ns += (uint64_t)(secs(t0, Clock::now()) * 1e9);
+  if (c->pending.fetch_sub(1) == 1) assemble(s, c);
+}
+
+// ---- stage: device ------------------------------------------------------------------------------------------------------
+// runs the subjects of lines [lo, hi) of the chunk; on a row-pool overflow the range is halved and both halves run
+// again (a single subject always fits: the pool is never smaller than one subject's worst case)
+static int device_part(grim_stream *s, Chunk *c, uint32_t lo, uint32_t hi, bool whole, std::vector<uint32_t> &og_sorted) {
+  grim_batch *b = c->batch;
+  const EngineHost *H = engine_batch_host(b);
+  auto lb = [](const std::vector<uint32_t> &v, uint32_t x) { return (size_t)(std::lower_bound(v.begin(), v.end(), x) - v.begin()); };
+  const size_t s0 = lb(c->os, lo), s1 = lb(c->os, hi), m0 = lb(c->om, lo), m1 = lb(c->om, hi);
+  if (s1 > s0) {
+    memcpy(H->small, c->small.data() + s0, sizeof(SmallRec) * (s1 - s0));
+    memcpy(H->order_s, c->os.data() + s0, 4 * (s1 - s0));
+  }
+  if (m1 > m0) memcpy(H->order_m, c->om.data() + m0, 4 * (m1 - m0));
+  uint32_t ng = 0;
+  for (uint32_t si : og_sorted)
+    if (si >= lo && si < hi) H->order_g[ng++] = si;
+  std::vector<uint64_t> so, sl;
+  for (uint32_t r = 0; r < c->n_ranges; ++r)
+    if (c->tr[r].n_tok && c->range_first_line[r] < hi && c->range_first_line[r + 1] > lo) {
+      so.push_back(c->slab_off[r]);
+      sl.push_back(c->tr[r].n_tok);
+    }
+  uint32_t n_priors;
+  {
+    std::lock_guard<std::mutex> lk(s->races.mu);
+    n_priors = s->races.n;
+    EngineCaps cp = engine_batch_caps(b);
+    if (n_priors > cp.priors) {
+      cp.priors = n_priors * 2;
+      if (engine_batch_reserve(b, &cp) != 0) return -1;
+      H = engine_batch_host(b);
+    }
+    if (n_priors) memcpy(H->priors, s->races.mats.data(), 8 * s->races.mats.size());
+  }
+  EngineLoad ld{c->n_lines, n_priors, (uint32_t)(s1 - s0), (uint32_t)(m1 - m0), ng, (uint32_t)so.size(), so.data(), sl.data()};
+  if (engine_batch_load(b, &ld) != 0) return -1;
+  const int rc = grim_batch_run(b);
+  if (s->opt.timing) {
+    for (int k = 0; k < 6; ++k) s->st.kernel_ms[k] += grim_batch_kernel_ms(b, k);
+    uint64_t ctr[4];
+    if (grim_batch_counters(b, ctr) == 0)
+      for (int k = 0; k < 4; ++k) s->st.counters[k] += ctr[k];
+  }
+  if (rc == -2) {
+    if (hi - lo <= 1) return -1;  // cannot happen: see grim_stream_open
+    ++s->st.reruns;
+    const uint32_t mid = lo + (hi - lo) / 2;
+    int r1 = device_part(s, c, lo, mid, false, og_sorted);
+    if (r1 != 0) return r1;
+    return device_part(s, c, mid, hi, false, og_sorted);
+  }
+  if (rc != 0) return -1;
+  const uint32_t nrows = grim_batch_total_rows(b);
+  if (whole) {
+    if (engine_batch_fetch(b, 0, c->n_lines, nullptr) != 0) return -1;
+    c->rows = engine_batch_host(b)->rows;
+  } else {
+    // a part of a chunk: its rows are appended to the chunk's own array and the row offsets of its subjects re-based
+    const size_t base = c->extra_rows.size();
+    c->extra_rows.resize(base + nrows);
+    if (engine_batch_fetch(b, lo, hi, nrows ? c->extra_rows.data() + base : nullptr) != 0) return -1;
+    grim_subject_result *res = engine_batch_host(b)->res;
+    auto rebase = [&](uint32_t si) {
+      for (int t = 0; t < GRIM_T_COUNT; ++t) res[si].row_off[t] += (uint32_t)base;
+    };
+    for (size_t k = s0; k < s1; ++k) rebase(c->os[k]);
+    for (size_t k = m0; k < m1; ++k) rebase(c->om[k]);
+    for (uint32_t k = 0; k < ng; ++k) rebase(engine_batch_host(b)->order_g[k]);
+  }
+  return 0;
+}
+
+static void enqueue_format(grim_stream *s, Chunk *c);
+
+static void device_loop(grim_stream *s) {
+  for (;;) {
+    Chunk *c = nullptr;
+    {
+      std::unique_lock<std::mutex> lk(s->mu);
+      for (;;) {
+        if (s->stop || s->failed) return;
+        c = s->by_index(s->next_device);
+        if (c && c->state == CH_TOKENIZED) break;
+        c = nullptr;
+        s->cv_dev.wait(lk);
+      }
+    }
+    const auto t0 = Clock::now();
+    int rc = 0;
+    c->extra_rows.clear();
+    c->rows = nullptr;
+    if (c->n_dev_subjects) {
+      // longest-processing-time-first for the general kernel; stable: equal-cost subjects stay in input order
+      std::vector<uint32_t> og = c->og;
+      const grim_subject *subj = engine_batch_host(c->batch)->subj;
+      std::vector<double> cost(og.size());
+      for (size_t k = 0; k < og.size(); ++k) cost[k] = grim_cost(subj[og[k]]);
+      std::vector<uint32_t> perm(og.size());
+      for (size_t k = 0; k < perm.size(); ++k) perm[k] = (uint32_t)k;
+      std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+      std::vector<uint32_t> sorted(og.size());
+      for (size_t k = 0; k < perm.size(); ++k) sorted[k] = og[perm[k]];
+      rc = device_part(s, c, 0, c->n_lines, true, sorted);
+      if (rc == 0 && !c->extra_rows.empty()) c->rows = c->extra_rows.data();
+      if (rc == 0 && !c->rows) c->rows = engine_batch_host(c->batch)->rows;
+    }
+    c->device_s = secs(t0, Clock::now());
+    {
+      std::lock_guard<std::mutex> lk(s->mu);
+      s->st.device_s += c->device_s;
+      s->st.subjects += c->n_dev_subjects;
+      ++s->next_device;
+      if (rc != 0) {
+        const char *e = grim_last_error(s->ctx);
+        s->fail(std::string("device stage failed: ") + (e ? e : ""));
+        return;
+      }
+      c->state = CH_DEVICE_DONE;
+    }
+    enqueue_format(s, c);
+  }
+}
+
+// ---- stage: format, commit, write ------------------------------------------------------------------------------------
+static void commit_ready(grim_stream *s) {  // mu held: commits every chunk that is formatted, in input order
+  for (;;) {
+    Chunk *c = s->by_index(s->next_commit);
+    if (!c || c->state != CH_FORMATTED) return;
+    const grim_subject_result *res = engine_batch_host(c->batch)->res;
+    bool any_file = false;
+    for (uint32_t r = 0; r < c->n_ranges; ++r) {
+      FmtRange &F = *c->fr[r];
+      for (int k = 0; k < 7; ++k) {
+        c->file_off[r][k] = s->file_pos[k];
+        s->file_pos[k] += F.t[k].n;
+        s->st.text_bytes[k] += F.t[k].n;
+        if (k < 6 && s->fd[k] >= 0) {
+          any_file = any_file || F.t[k].n;
+        } else if (F.t[k].n) {  // in-memory sink: the buffer changes hands
+          s->mem[k].emplace_back(F.t[k].p, F.t[k].n);
+          F.t[k].p = nullptr;
+          F.t[k].n = F.t[k].cap = 0;
+        }
+      }
+      for (uint32_t j : F.unsupported) {
+        const TokRange &T = c->tr[r];
+        uint32_t reason = 5;
+        if (T.kind[j] == K_DEV) reason = res[c->range_first_line[r] + j].reason;
+        s->unsupported.push_back({c->first_line + c->range_first_line[r] + j, reason,
+                                  std::string(c->text.data() + T.line[j].off, T.line[j].id_len)});
+      }
+    }
+    ++s->next_commit;
+    c->state = CH_COMMITTED;
+    if (s->opt.want_records) s->cv_rec.notify_all();
+    if (any_file) {
+      c->pending.store((int)c->n_ranges);
+      for (uint32_t r = 0; r < c->n_ranges; ++r) s->q_hi.push_back(Task{2, c, r});
+      s->cv_work.notify_all();
+    } else {
+      c->state = CH_WRITTEN;
+      release_if_done(s, c);
+    }
+  }
+}
+
+static void enqueue_format(grim_stream *s, Chunk *c) {
+  std::lock_guard<std::mutex> lk(s->mu);
+  if (!s->opt.want_text) {
+    for (uint32_t r = 0; r < c->n_ranges; ++r) {
+      c->fr[r]->unsupported.clear();
+      for (int k = 0; k < 7; ++k) c->fr[r]->t[k].clear();
+    }
+    c->state = CH_FORMATTED;
+    commit_ready(s);
+    return;
+  }
+  c->pending.store((int)c->n_ranges);
+  for (uint32_t r = 0; r < c->n_ranges; ++r) s->q_hi.push_back(Task{1, c, r});
+  s->cv_work.notify_all();
+}
+
+static void run_format(grim_stream *s, Chunk *c, uint32_t r) {
+  const auto t0 = Clock::now();
+  FmtRange &F = *c->fr[r];
+  for (int k = 0; k < 7; ++k) F.t[k].clear();
+  F.unsupported.clear();
+  FmtParams fp = s->fp;  // copies a few strings; per range, not per line
+  fp.per_subject_s = c->n_dev_subjects ? c->device_s / c->n_dev_subjects : 0.0;
+  format_range(fp, c->text.data(), c->tr[r], engine_batch_host(c->batch)->res, c->rows, c->first_line + c->range_first_line[r],
+               nullptr, F);
+  s->fmt_ns += (uint64_t)(secs(t0, Clock::now()) * 1e9);
+  if (c->pending.fetch_sub(1) == 1) {
+    std::lock_guard<std::mutex> lk(s->mu);
+    c->state = CH_FORMATTED;
+    commit_ready(s);
+  }
+}
+
+static void run_write(grim_stream *s, Chunk *c, uint32_t r) {
+  const auto t0 = Clock::now();
+  FmtRange &F = *c->fr[r];
+  bool ok = true;
+  for (int k = 0; k < 6 && ok; ++k) {
+    if (s->fd[k] < 0 || !F.t[k].n) continue;
+    size_t done = 0;
+    while (done < F.t[k].n) {
+      const ssize_t w = pwrite(s->fd[k], F.t[k].p + done, F.t[k].n - done, (off_t)(c->file_off[r][k] + done));
+      if (w < 0) {
+        if (errno == EINTR) continue;
+        ok = false;
+        break;
+      }
+      done += (size_t)w;
+    }
+  }
+  s->wr_ns += (uint64_t)(secs(t0, Clock::now()) * 1e9);
+  if (!ok) {
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->fail(std::string("writing an output file failed: ") + strerror(errno));
+  }
+  if (c->pending.fetch_sub(1) == 1) {
+    std::lock_guard<std::mutex> lk(s->mu);
+    c->state = CH_WRITTEN;
+    release_if_done(s, c);
+  }
+}
+
+static void worker_loop(grim_stream *s) {
+  for (;;) {
+    Task t;
+    {
+      std::unique_lock<std::mutex> lk(s->mu);
+      for (;;) {
+        if (s->stop) return;
+        if (!s->q_hi.empty()) {
+          t = s->q_hi.front();
+          s->q_hi.pop_front();
+          break;
+        }
+        if (!s->q_lo.empty()) {
+          t = s->q_lo.front();
+          s->q_lo.pop_front();
+          break;
+        }
+        s->cv_work.wait(lk);
+      }
+    }
+    if (t.type == 0) run_tokenize(s, t.c, t.r);
+    else if (t.type == 1) run_format(s, t.c, t.r);
+    else run_write(s, t.c, t.r);
+  }
+}
+
+// ---- the reader side: bytes -> chunks ----------------------------------------------------------------------------------
+static Chunk *acquire_chunk(grim_stream *s) {
+  std::unique_lock<std::mutex> lk(s->mu);
+  for (;;) {
+    if (s->failed) return nullptr;
+    for (auto &c : s->chunks)
+      if (c->state == CH_FREE) {
+        c->state = CH_FILLING;
+        c->index = s->next_index++;
+        c->first_line = s->next_line;
+        c->text.clear();
+        c->n_lines = 0;
+        c->mark_off.clear();
+        c->mark_off.push_back(0);  // line 0 starts at byte 0; line k * granule: noted when its predecessor ends
+        c->records_out = c->records_released = false;
+        return c.get();
+      }
+    s->cv_slot.wait(lk);
+  }
+}
+
+static int dispatch(grim_stream *s, Chunk *c) {
+  // ranges: whole granules, about one range per thread
+  const uint32_t n = c->n_lines;
+  uint32_t per = (n + s->n_threads - 1) / s->n_threads;
+  per = ((per + s->granule - 1) / s->granule) * s->granule;
+  if (per == 0) per = s->granule;
+  const uint32_t R = (n + per - 1) / per;
+  c->n_ranges = R;
+  c->cut.assign(R + 1, c->text.size());
+  c->range_first_line.assign(R + 1, n);
+  c->slab_off.assign(R, 0);
+  c->slab_cap.assign(R, 0);
+  for (uint32_t r = 0; r < R; ++r) {
+    c->range_first_line[r] = r * per;
+    c->cut[r] = c->mark_off[(size_t)r * per / s->granule];
+  }
+  uint64_t tok_total = 0;
+  for (uint32_t r = 0; r < R; ++r) {
+    c->slab_off[r] = tok_total;
+    c->slab_cap[r] = (c->cut[r + 1] - c->cut[r]) / 2 + 16;
+    tok_total += c->slab_cap[r];
+  }
+  if (c->tr.size() < R) c->tr.resize(R);
+  while (c->fr.size() < R) c->fr.emplace_back(new FmtRange());
+  if (c->file_off.size() < R) c->file_off.resize(R);
+  EngineCaps cp = engine_batch_caps(c->batch);
+  if (n > cp.subj || tok_total > cp.tok) {
+    if (n > cp.subj) cp.subj = n;
+    if (tok_total > cp.tok) cp.tok = tok_total + tok_total / 4;
+    if (engine_batch_reserve(c->batch, &cp) != 0) {
+      std::lock_guard<std::mutex> lk(s->mu);
+      s->fail(std::string("growing a chunk's buffers failed: ") + grim_last_error(s->ctx));
+      return -1;
+    }
+  }
+  s->next_line += n;
+  std::lock_guard<std::mutex> lk(s->mu);
+  s->st.lines += n;
+  ++s->st.chunks;
+  c->state = CH_TOKENIZING;
+  c->pending.store((int)R);
+  for (uint32_t r = 0; r < R; ++r) s->q_lo.push_back(Task{0, c, r});
+  s->cv_work.notify_all();
+  return 0;
+}
+
+extern "C" int grim_stream_write(grim_stream *s, const char *text, uint64_t len) {
+  if (!s || s->input_closed) return -1;
+  uint64_t a = 0;
+  while (a < len) {
+    if (!s->filling) {
+      s->filling = acquire_chunk(s);
+      if (!s->filling) return -1;
+    }
+    Chunk *c = s->filling;
+    // take whole lines until the chunk is full; a partial last line stays open (the next call continues it)
+    const uint32_t want = s->chunk_lines - c->n_lines;
+    uint64_t b = a;
+    uint32_t got = 0;
+    const uint64_t base = c->text.size();
+    while (b < len && got < want) {
+      const char *nl = (const char *)memchr(text + b, '\n', len - b);
+      if (!nl) {
+        b = len;
+        break;
+      }
+      b = (uint64_t)(nl - text) + 1;
+      ++got;
+      const uint32_t ln = c->n_lines + got;
+      if (ln % s->granule == 0 && ln < s->chunk_lines) c->mark_off.push_back(base + (b - a));
+    }
+    c->text.append(text + a, b - a);
+    c->n_lines += got;
+    a = b;
+    if (c->n_lines >= s->chunk_lines) {
+      s->filling = nullptr;
+      if (dispatch(s, c) != 0) return -1;
+    }
+  }
+  return s->failed ? -1 : 0;
+}
+
+extern "C" int grim_stream_write_file(grim_stream *s, const char *path) {
+  if (!s || !path) return -1;
+  const int fd = open(path, O_RDONLY);
+  if (fd < 0) {
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->fail(std::string("cannot open ") + path + ": " + strerror(errno));
+    return -1;
+  }
+  std::vector<char> buf(8u << 20);
+  int rc = 0;
+  for (;;) {
+    ssize_t n = read(fd, buf.data(), buf.size());
+    if (n < 0) {
+      if (errno == EINTR) continue;
+      std::lock_guard<std::mutex> lk(s->mu);
+      s->fail(std::string("reading ") + path + " failed: " + strerror(errno));
+      rc = -1;
+      break;
+    }
+    if (n == 0) break;
+    size_t m = (size_t)n;
+    char *p = buf.data();
+    size_t skip = 0;
+    if (s->carry_cr && p[0] == '\n') skip = 1;  // the "\n" of a "\r\n" split across two blocks
+    s->carry_cr = false;
+    if (memchr(p, '\r', m)) {  // universal newlines, as Python's open(): "\r\n" and "\r" end a line
+      size_t w = 0;
+      for (size_t i = skip; i < m; ++i) {
+        if (p[i] == '\r') {
+          p[w++] = '\n';
+          if (i + 1 < m) {
+            if (p[i + 1] == '\n') ++i;
+          } else {
+            s->carry_cr = true;
+          }
+        } else {
+          p[w++] = p[i];
+        }
+      }
+      m = w;
+      skip = 0;
+    }
+    if (m > skip && grim_stream_write(s, p + skip, m - skip) != 0) {
+      rc = -1;
+      break;
+    }
+  }
+  close(fd);
+  return rc;
+}
+
+extern "C" int grim_stream_finish(grim_stream *s) {
+  if (!s) return -1;
+  if (!s->input_closed) {
+    s->input_closed = true;
+    Chunk *c = s->filling;
+    s->filling = nullptr;
+    if (c) {
+      if (!c->text.empty() && c->text.back() != '\n') {  // a last line without its newline is a line
+        ++c->n_lines;
+      }
+      if (c->n_lines == 0) {
+        std::lock_guard<std::mutex> lk(s->mu);
+        c->state = CH_FREE;
+        --s->next_index;
+      } else if (dispatch(s, c) != 0) {
+        return -1;
+      }
+    }
+  }
+  std::unique_lock<std::mutex> lk(s->mu);
+  for (;;) {
+    if (s->failed) break;
+    if (s->opt.want_records ? s->next_commit >= s->next_index : s->n_done >= s->next_index) break;
+    s->cv_done.wait_for(lk, std::chrono::milliseconds(50));
+  }
+  s->st.wall_s = secs(s->t_open, Clock::now());
+  return s->failed ? -1 : 0;
+}
+
+extern "C" const char *grim_stream_error(const grim_stream *s) { return s ? s->err.c_str() : "no stream"; }
+
+extern "C" const char *grim_stream_text(grim_stream *s, int which, uint64_t *len) {
+  if (!s || which < 0 || which > 6) return nullptr;
+  if (!s->joined_ok[which]) {
+    size_t tot = 0;
+    for (auto &b : s->mem[which]) tot += b.second;
+    s->joined[which].clear();
+    s->joined[which].reserve(tot);
+    for (auto &b : s->mem[which]) {
+      s->joined[which].append(b.first, b.second);
+      free(b.first);
+    }
+    s->mem[which].clear();
+    s->joined_ok[which] = true;
+  }
+  if (len) *len = s->joined[which].size();
+  return s->joined[which].data();
+}
+
+extern "C" int grim_stream_get_stats(const grim_stream *s, grim_stream_stats *out) {
+  if (!s || !out) return -1;
+  *out = s->st;
+  out->tokenize_cpu_s = s->tok_ns.load() * 1e-9;
+  out->format_cpu_s = s->fmt_ns.load() * 1e-9;
+  out->write_cpu_s = s->wr_ns.load() * 1e-9;
+  out->unsupported = s->unsupported.size();
+  out->bytes_h2d = engine_bytes_moved(nullptr, 0);
+  out->bytes_d2h = engine_bytes_moved(nullptr, 1);
+  return 0;
+}
+
+extern "C" uint64_t grim_stream_n_unsupported(const grim_stream *s) { return s ? s->unsupported.size() : 0; }
+
+extern "C" int grim_stream_unsupported(const grim_stream *s, uint64_t k, uint64_t *line, uint32_t *reason, const char **id, uint32_t *id_len) {
+  if (!s || k >= s->unsupported.size()) return -1;
+  const auto &u = s->unsupported[k];
+  if (line) *line = u.line;
+  if (reason) *reason = u.reason;
+  if (id) *id = u.id.data();
+  if (id_len) *id_len = (uint32_t)u.id.size();
+  return 0;
+}
+
+extern "C" int grim_stream_next_records(grim_stream *s, grim_stream_records *out) {
+  if (!s || !out || !s->opt.want_records) return -1;
+  std::unique_lock<std::mutex> lk(s->mu);
+  for (;;) {
+    if (s->failed) return -1;
+    Chunk *c = s->by_index(s->next_record);
+    if (c && c->state >= CH_COMMITTED && !c->records_out) {
+      c->records_out = true;
+      ++s->next_record;
+      out->first_line = c->first_line;
+      out->n_lines = c->n_lines;
+      out->kinds = c->kinds.data();
+      out->res = engine_batch_host(c->batch)->res;
+      out->rows = c->rows;
+      out->chunk = c;
+      return 1;
+    }
+    if (s->input_closed && s->next_record >= s->next_index) return 0;
+    s->cv_rec.wait_for(lk, std::chrono::milliseconds(50));
+  }
+}
+
+extern "C" int grim_stream_release_records(grim_stream *s, grim_stream_records *rec) {
+  if (!s || !rec || !rec->chunk) return -1;
+  Chunk *c = (Chunk *)rec->chunk;
+  std::lock_guard<std::mutex> lk(s->mu);
+  c->records_released = true;
+  rec->chunk = nullptr;
+  release_if_done(s, c);
+  return 0;
+}
+
+extern "C" grim_stream *grim_stream_open(grim_ctx *ctx, const grim_graph *g, const grim_dict *dict, const grim_params *prm,
+                                         const grim_prior_spec *priors, const char *const *pop_names, uint32_t n_pops,
+                                         const grim_stream_opts *opts) {
+  if (!ctx || !g || !dict || !prm || !priors || !pop_names || !opts || n_pops == 0) return nullptr;
+  grim_stream *s = new grim_stream();
+  s->ctx = ctx;
+  s->graph = g;
+  s->prm = *prm;
+  s->opt = *opts;
+  s->n_pops = n_pops;
+  s->next_line = opts->line_offset;
+  memset(&s->st, 0, sizeof(s->st));
+  dict_snapshot(dict, s->snap);
+  s->races.ps.alpha = priors->alpha;
+  s->races.ps.eta = priors->eta;
+  s->races.ps.beta = priors->beta;
+  s->races.ps.gamma = priors->gamma;
+  s->races.ps.delta = priors->delta;
+  s->races.ps.unk_mr = priors->unk_mr != 0;
+  for (uint32_t i = 0; i < n_pops; ++i) {
+    s->races.ps.pops.emplace_back(pop_names[i]);
+    s->races.ps.count_by_prob.push_back(priors->count_by_prob ? priors->count_by_prob[i] : 1.0);
+    s->fp.pops.emplace_back(pop_names[i]);
+  }
+  s->fp.snap = &s->snap;
+  s->fp.prm = &s->prm;
+  s->fp.want_log = opts->want_log != 0;
+  if (opts->mask_ids && opts->n_masks) {
+    const char *p = opts->mask_ids;
+    for (uint32_t i = 0; i < opts->n_masks; ++i) {
+      const size_t n = strlen(p);
+      s->masks.fixed[std::string(p, n)] = opts->mask_fixed ? opts->mask_fixed[i] : 0;
+      p += n + 1;
+    }
+    s->have_masks = true;
+  } else if (opts->mask_ids) {
+    s->have_masks = true;  // an empty table: every id is missing
+  }
+  s->rule.small_ok = (n_pops == 1) && prm->opt_threshold > 1 && !getenv("GRIM_NO_SMALL");
+  s->rule.medium_ok = !getenv("GRIM_NO_MEDIUM");
+  s->rule.graph_loci = s->snap.n_loci;
+  s->rule.opt_threshold = prm->opt_threshold;
+  s->chunk_lines = opts->chunk_lines ? opts->chunk_lines : 131072u;
+  s->granule = 1024;
+  if (s->chunk_lines < s->granule) s->granule = s->chunk_lines;
+  s->depth = opts->depth ? opts->depth : 4u;
+  int nt = opts->n_threads;
+  if (nt <= 0) nt = (int)std::min<unsigned>(32u, std::max(1u, std::thread::hardware_concurrency()));
+  s->n_threads = (uint32_t)nt;
+  // row pool of a chunk: bounded; never less than the fixed-stride region of the half-wave kernel plus one subject's
+  // worst case and the one-wave kernel's per-wave row blocks
+  const uint64_t per = engine_rows_per_subject(prm, n_pops);
+  uint64_t rows = opts->rows_per_chunk ? opts->rows_per_chunk : 32ull * s->chunk_lines;
+  const uint64_t floor_rows = (uint64_t)engine_small_stride(prm) * s->chunk_lines + 2 * per + 64ull * 256 * 32 + 1024;
+  if (rows < floor_rows) rows = floor_rows;
+  if (rows > 0x7FFFFFF0ull) rows = 0x7FFFFFF0ull;
+  s->rows_per_chunk = rows;
+  for (int k = 0; k < 6; ++k)
+    if (opts->out_path[k]) {
+      s->fd[k] = open(opts->out_path[k], O_WRONLY | O_CREAT | O_TRUNC, 0644);
+      if (s->fd[k] < 0) {
+        engine_set_error(ctx, (std::string("grim_stream_open: cannot create ") + opts->out_path[k] + ": " + strerror(errno)).c_str());
+        for (int j = 0; j < k; ++j)
+          if (s->fd[j] >= 0) close(s->fd[j]);
+        delete s;
+        return nullptr;
+      }
+    }
+  EngineCaps caps{s->chunk_lines, (uint64_t)s->chunk_lines * 48, 64, rows};
+  for (uint32_t i = 0; i < s->depth; ++i) {
+    std::unique_ptr<Chunk> c(new Chunk());
+    c->slot_no = (int)i;
+    c->batch = engine_batch_create(ctx, g, prm, &caps);
+    if (!c->batch) {
+      for (auto &o : s->chunks) grim_batch_free(o->batch);
+      for (int k = 0; k < 6; ++k)
+        if (s->fd[k] >= 0) close(s->fd[k]);
+      delete s;
+      return nullptr;
+    }
+    if (opts->timing) grim_batch_set_timing(c->batch, 1);
+    s->chunks.push_back(std::move(c));
+  }
+  s->t_open = Clock::now();
+  for (uint32_t i = 0; i < s->n_threads; ++i) s->workers.emplace_back(worker_loop, s);
+  s->dev_thread = std::thread(device_loop, s);
+  return s;
+}
+
+extern "C" void grim_stream_free(grim_stream *s) {
+  if (!s) return;
+  {
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->stop = true;
+    s->cv_work.notify_all();
+    s->cv_dev.notify_all();
+    s->cv_slot.notify_all();
+  }
+  for (auto &t : s->workers) t.join();
+  if (s->dev_thread.joinable()) s->dev_thread.join();
+  for (auto &c : s->chunks) grim_batch_free(c->batch);
+  for (int k = 0; k < 6; ++k)
+    if (s->fd[k] >= 0) close(s->fd[k]);
+  for (int k = 0; k < 7; ++k)
+    for (auto &b : s->mem[k]) free(b.first);
+  delete s;
+}

@@ -295,7 +295,7 @@ class DeviceBatch:
 # ======================================================================================================
 # host-side helpers of the library (C++: allele dictionary, tokenizer, formatter) -- no GPU needed
 # ======================================================================================================
-K_DEVICE, K_PROBLEM_ID, K_PROBLEM_RAW, K_MISS_NO_DEVICE = 0, 1, 2, 3
+K_DEVICE, K_PROBLEM_ID, K_PROBLEM_RAW, K_MISS_NO_DEVICE, K_UNSUPPORTED = 0, 1, 2, 3, 4
 
 EXPORTS += [
     "grim_dict_create", "grim_dict_free", "grim_dict_set_locus", "grim_dict_intern", "grim_dict_find", "grim_dict_name",
@@ -303,7 +303,35 @@ EXPORTS += [
     "grim_parsed_subject_array", "grim_parsed_tokens", "grim_parsed_kinds", "grim_parsed_dev_index",
     "grim_parsed_n_races", "grim_parsed_race", "grim_parsed_id", "grim_parsed_set_kind", "grim_parsed_set_flags", "grim_format", "grim_text_get", "grim_text_free",
     "grim_format_double", "grim_hostgraph_load_csv", "grim_hostgraph_desc", "grim_hostgraph_free", "grim_graphgen_csv",
+    "grim_parsed_allele", "grim_prior_matrix", "grim_stream_open", "grim_stream_write", "grim_stream_write_file", "grim_stream_finish",
+    "grim_stream_error", "grim_stream_text", "grim_stream_get_stats", "grim_stream_n_unsupported", "grim_stream_unsupported",
+    "grim_stream_next_records", "grim_stream_release_records", "grim_stream_free",
 ]
+
+
+class PriorSpec(C.Structure):
+    _fields_ = [("alpha", C.c_double), ("eta", C.c_double), ("beta", C.c_double), ("gamma", C.c_double), ("delta", C.c_double),
+                ("unk_mr", C.c_uint8), ("count_by_prob", C.POINTER(C.c_double))]
+
+
+class StreamOpts(C.Structure):
+    _fields_ = [("chunk_lines", C.c_uint32), ("depth", C.c_uint32), ("n_threads", C.c_int32), ("line_offset", C.c_uint64),
+                ("rows_per_chunk", C.c_uint64), ("want_text", C.c_uint8), ("want_log", C.c_uint8), ("want_records", C.c_uint8),
+                ("timing", C.c_uint8), ("out_path", C.c_char_p * 6), ("mask_ids", C.c_char_p), ("mask_fixed", C.c_void_p),
+                ("n_masks", C.c_uint32)]
+
+
+class StreamStats(C.Structure):
+    _fields_ = [("lines", C.c_uint64), ("subjects", C.c_uint64), ("chunks", C.c_uint64), ("reruns", C.c_uint64),
+                ("unsupported", C.c_uint64), ("wall_s", C.c_double), ("tokenize_cpu_s", C.c_double), ("format_cpu_s", C.c_double),
+                ("write_cpu_s", C.c_double), ("device_s", C.c_double), ("kernel_ms", C.c_double * 6), ("counters", C.c_uint64 * 4),
+                ("text_bytes", C.c_uint64 * 7), ("bytes_h2d", C.c_uint64), ("bytes_d2h", C.c_uint64)]
+
+
+class StreamRecords(C.Structure):
+    _fields_ = [("first_line", C.c_uint64), ("n_lines", C.c_uint32), ("kinds", C.c_void_p), ("res", C.c_void_p),
+                ("rows", C.c_void_p), ("chunk", C.c_void_p)]
+
 
 _host_ready = False
 
@@ -365,6 +393,35 @@ def host_lib():
     L.grim_graphgen_csv.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.c_uint32, C.POINTER(C.c_char_p),
                                     C.POINTER(C.c_uint32), C.c_uint32, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p,
                                     C.c_char_p, C.c_uint64]
+    L.grim_parsed_allele.restype = C.c_void_p
+    L.grim_parsed_allele.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+    L.grim_prior_matrix.restype = C.c_int
+    L.grim_prior_matrix.argtypes = [C.POINTER(PriorSpec), C.POINTER(C.c_char_p), C.c_uint32, C.c_char_p, C.c_char_p, C.c_void_p]
+    L.grim_stream_open.restype = C.c_void_p
+    L.grim_stream_open.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Params), C.POINTER(PriorSpec), C.POINTER(C.c_char_p),
+                                   C.c_uint32, C.POINTER(StreamOpts)]
+    L.grim_stream_write.restype = C.c_int
+    L.grim_stream_write.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64]
+    L.grim_stream_write_file.restype = C.c_int
+    L.grim_stream_write_file.argtypes = [C.c_void_p, C.c_char_p]
+    L.grim_stream_finish.restype = C.c_int
+    L.grim_stream_finish.argtypes = [C.c_void_p]
+    L.grim_stream_error.restype = C.c_char_p
+    L.grim_stream_error.argtypes = [C.c_void_p]
+    L.grim_stream_text.restype = C.c_void_p
+    L.grim_stream_text.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint64)]
+    L.grim_stream_get_stats.restype = C.c_int
+    L.grim_stream_get_stats.argtypes = [C.c_void_p, C.POINTER(StreamStats)]
+    L.grim_stream_n_unsupported.restype = C.c_uint64
+    L.grim_stream_n_unsupported.argtypes = [C.c_void_p]
+    L.grim_stream_unsupported.restype = C.c_int
+    L.grim_stream_unsupported.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_void_p),
+                                          C.POINTER(C.c_uint32)]
+    L.grim_stream_next_records.restype = C.c_int
+    L.grim_stream_next_records.argtypes = [C.c_void_p, C.POINTER(StreamRecords)]
+    L.grim_stream_release_records.restype = C.c_int
+    L.grim_stream_release_records.argtypes = [C.c_void_p, C.POINTER(StreamRecords)]
+    L.grim_stream_free.argtypes = [C.c_void_p]
     _host_ready = True
     return L
 
@@ -461,6 +518,12 @@ class Parsed:
         ptr = host_lib().grim_parsed_id(self.h, line, C.byref(n))
         return C.string_at(ptr, n.value).decode() if ptr else None
 
+    def allele(self, line, slot, idx):
+        """text of allele `idx` at locus slot `slot` as line `line` uses it (dictionary allele or the line's own)"""
+        n = C.c_uint32(0)
+        ptr = host_lib().grim_parsed_allele(self.h, line, slot, idx, C.byref(n))
+        return C.string_at(ptr, n.value).decode() if ptr else None
+
     def format(self, adict, params, pops, res, rows, line_offset=0, skip=None, as_bytes=False):
         L = host_lib()
         names = (C.c_char_p * len(pops))(*[p.encode() for p in pops])
@@ -553,3 +616,124 @@ def graphgen_csv(hpf_csv, pops, cutoffs, loci_map, nodes_csv, edges_csv, top_lin
                              err, len(err))
     if rc != 0:
         raise ValueError(err.value.decode())
+
+
+def prior_spec(priority, unk_priors, count_by_prob=None):
+    """grim_prior_spec from the conf's "priority" dict, UNK_priors and the population counts (kept alive by the caller)"""
+    ps = PriorSpec()
+    ps.alpha, ps.eta, ps.beta, ps.gamma, ps.delta = (float(priority[k]) for k in ("alpha", "eta", "beta", "gamma", "delta"))
+    ps.unk_mr = 1 if unk_priors == "MR" else 0
+    keep = None
+    if count_by_prob is not None:
+        keep = np.ascontiguousarray(count_by_prob, dtype=np.float64)
+        ps.count_by_prob = keep.ctypes.data_as(C.POINTER(C.c_double))
+    return ps, keep
+
+
+def prior_matrix(ps, pops, race1, race2):
+    """calc_priority_matrix in the library (grim_prior_matrix) -> P x P float64"""
+    names = (C.c_char_p * len(pops))(*[p.encode() for p in pops])
+    out = np.zeros((len(pops), len(pops)), dtype=np.float64)
+    rc = host_lib().grim_prior_matrix(C.byref(ps), names, len(pops), (race1 or "").encode(), (race2 or "").encode(), _ptr(out))
+    if rc != 0:
+        raise NativeError("grim_prior_matrix failed")
+    return out
+
+
+TEXT_KEYS = ("umug", "umug_pops", "pmug", "pmug_pops", "miss", "problem")
+
+
+class Stream:
+    """grim_stream: the chunked tokenizer -> device -> formatter pipeline (impute_file's loop)."""
+
+    def __init__(self, ctx, dgraph, adict, params, ps, pops, out_paths=None, want_text=True, want_log=False, want_records=False,
+                 chunk_lines=0, depth=0, n_threads=0, line_offset=0, rows_per_chunk=0, timing=False, masks=None):
+        L = host_lib()
+        self.ctx = ctx
+        o = StreamOpts()
+        o.chunk_lines = int(chunk_lines or int(os.environ.get("GRIM_CHUNK_LINES", "0")))
+        o.depth = int(depth or int(os.environ.get("GRIM_STREAM_DEPTH", "0")))
+        o.n_threads = int(n_threads or int(os.environ.get("GRIM_HOST_THREADS", "0")))
+        o.line_offset = int(line_offset)
+        o.rows_per_chunk = int(rows_per_chunk or int(os.environ.get("GRIM_ROWS_PER_CHUNK", "0")))
+        o.want_text = 1 if want_text else 0
+        o.want_log = 1 if want_log else 0
+        o.want_records = 1 if want_records else 0
+        o.timing = 1 if timing else 0
+        self._keep = [params, ps]
+        if out_paths:
+            for k, key in enumerate(TEXT_KEYS):
+                if out_paths.get(key):
+                    o.out_path[k] = os.fsencode(out_paths[key])
+        if masks is not None:
+            ids = b"".join(str(k).encode() + b"\0" for k in masks.keys())
+            fixed = np.array([int(v) for v in masks.values()], dtype=np.uint8)
+            self._keep += [ids, fixed]
+            o.mask_ids = ids if len(masks) else b"\0"
+            o.mask_fixed = _ptr(fixed) if len(masks) else None
+            o.n_masks = len(masks)
+        names = (C.c_char_p * len(pops))(*[p.encode() for p in pops])
+        self.line_offset = int(line_offset)
+        self.h = L.grim_stream_open(ctx.h, dgraph.h, adict.h, C.byref(params), C.byref(ps), names, len(pops), C.byref(o))
+        if not self.h:
+            raise NativeError("grim_stream_open failed: " + ctx.error())
+
+    def _check(self, rc):
+        if rc < 0:
+            raise NativeError("grim_stream: " + host_lib().grim_stream_error(self.h).decode())
+
+    def write(self, data):
+        self._check(host_lib().grim_stream_write(self.h, data, len(data)))
+
+    def write_file(self, path):
+        self._check(host_lib().grim_stream_write_file(self.h, os.fsencode(path)))
+
+    def finish(self):
+        self._check(host_lib().grim_stream_finish(self.h))
+
+    def text(self, which, as_bytes=False):
+        n = C.c_uint64(0)
+        ptr = host_lib().grim_stream_text(self.h, which, C.byref(n))
+        data = C.string_at(ptr, n.value) if n.value else b""
+        return data if as_bytes else data.decode()
+
+    def stats(self):
+        st = StreamStats()
+        host_lib().grim_stream_get_stats(self.h, C.byref(st))
+        return st
+
+    def unsupported(self):
+        L = host_lib()
+        out = []
+        for k in range(int(L.grim_stream_n_unsupported(self.h))):
+            line, reason, ptr, n = C.c_uint64(0), C.c_uint32(0), C.c_void_p(0), C.c_uint32(0)
+            L.grim_stream_unsupported(self.h, k, C.byref(line), C.byref(reason), C.byref(ptr), C.byref(n))
+            out.append((int(line.value), C.string_at(ptr.value, n.value).decode() if n.value else "", int(reason.value)))
+        return out
+
+    def next_records(self):
+        """records mode: -> (first_line, kinds, res, rows_base_address, handle) of the next chunk, or None at the end.
+        The arrays are VIEWS of the chunk's pinned buffers: copy what you keep, then release(handle)."""
+        rec = StreamRecords()
+        rc = host_lib().grim_stream_next_records(self.h, C.byref(rec))
+        self._check(rc)
+        if rc == 0:
+            return None
+        n = int(rec.n_lines)
+        kinds = np.frombuffer((C.c_char * n).from_address(rec.kinds), dtype=np.uint8, count=n)
+        res = np.frombuffer((C.c_char * (n * RESULT_DT.itemsize)).from_address(rec.res), dtype=RESULT_DT, count=n)
+        return int(rec.first_line), kinds, res, rec.rows, rec
+
+    def release(self, rec):
+        host_lib().grim_stream_release_records(self.h, C.byref(rec))
+
+    def close(self):
+        if self.h:
+            host_lib().grim_stream_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -422,109 +422,127 @@ class Imputation(object):
         return self.open_phases_for_em(phases, chrom["N_Loc"], cutoff)
 
     def impute_file(self, config, planb=None, em_mr=False, em=False):
-        # the file goes to the library's tokenizer as it is and the six outputs come back as bytes: no per-line
-        # Python strings on the way in or out
-        with open(config["imputation_input_file"], "rb") as fh:
-            raw = fh.read()
-        if b"\r" in raw:  # let Python's universal newlines split the lines exactly as the reference's open() does
-            raw = raw.decode().replace("\r\n", "\n").replace("\r", "\n").encode()
-        if raw and not raw.endswith(b"\n"):
-            raw += b"\n"
-        texts = self.impute_lines(None, config, planb=planb, em_mr=em_mr, em=em, _raw=raw)
-        self.write_outputs(config, texts)
+        """impute.py:1985-2155.  The input file is read, tokenised, imputed, formatted and written by the library's
+        streaming pipeline (grim_stream_*: chunks of lines, tokenizer threads -> device -> formatter threads ->
+        ordered pwrite), so no per-line Python work remains; Python prints the per-subject lines when not quiet."""
+        out_paths = {}
+        for key, path_key, flag in self._OUT_FILES:
+            if flag is None or config[flag]:
+                out_paths[key] = config[path_key]
+        self._stream_run(config, planb, em_mr, em, out_paths=out_paths, in_path=config["imputation_input_file"])
 
-    @staticmethod
-    def write_outputs(config, texts):
-        names = [("umug", "imputation_out_umug_freq_file", "output_MUUG"),
-                 ("umug_pops", "imputation_out_umug_pops_file", "output_MUUG"),
-                 ("pmug", "imputation_out_hap_freq_file", "output_haplotypes"),
-                 ("pmug_pops", "imputation_out_hap_pops_file", "output_haplotypes"),
-                 ("miss", "imputation_out_miss_file", None), ("problem", "imputation_out_problem_file", None)]
-        for key, path_key, flag in names:
+    _OUT_FILES = [("umug", "imputation_out_umug_freq_file", "output_MUUG"),
+                  ("umug_pops", "imputation_out_umug_pops_file", "output_MUUG"),
+                  ("pmug", "imputation_out_hap_freq_file", "output_haplotypes"),
+                  ("pmug_pops", "imputation_out_hap_pops_file", "output_haplotypes"),
+                  ("miss", "imputation_out_miss_file", None), ("problem", "imputation_out_problem_file", None)]
+
+    @classmethod
+    def write_outputs(cls, config, texts):
+        for key, path_key, flag in cls._OUT_FILES:
             if flag is not None and not config[flag]:
                 continue
             data = texts[key]
             with open(config[path_key], "wb" if isinstance(data, bytes) else "w") as fh:
                 fh.write(data)
 
-    def impute_lines(self, lines, config, planb=None, em_mr=False, line_offset=0, em=False, _raw=None):
+    def impute_lines(self, lines, config, planb=None, em_mr=False, line_offset=0, em=False, as_bytes=False):
         """The body of impute_file on a list of input lines.  Returns the six output texts keyed
         'umug','umug_pops','pmug','pmug_pops','miss','problem'.  `line_offset` is the global index
-        of lines[0] (multi-GPU shards keep the reference's line numbers in .miss/.problem).
+        of lines[0] (multi-GPU shards keep the reference's line numbers in .miss/.problem)."""
+        data = "".join(l if l.endswith("\n") else l + "\n" for l in lines).encode()
+        return self._stream_run(config, planb, em_mr, em, data=data, line_offset=line_offset, as_bytes=as_bytes)
 
-        Tokenising and formatting run in the library (C++, all host cores); Python only builds one
-        prior matrix per distinct race pair and prints the reference's per-subject lines."""
-        priority = config["priority"]
-        muug_on = config["output_MUUG"]
-        haps_on = config["output_haplotypes"]
+    def _stream_run(self, config, planb, em_mr, em, out_paths=None, in_path=None, data=None, line_offset=0, as_bytes=False):
         if planb is None:
             planb = config["planb"]
         if not config["epsilon"] > 0:
             raise NotImplementedError("epsilon <= 0: the reference returns its 'NaN' sentinel and fails every subject")
         self.unsupported = []
-        tm = [timeit.default_timer()]
-        text = _raw if _raw is not None else "".join(l if l.endswith("\n") else l + "\n" for l in lines).encode()
-        tm.append(timeit.default_timer())
-        parsed = nat.Parsed(self.netGraph.adict, text, planb)
-        tm.append(timeit.default_timer())
+        masks = None
+        if os.path.isfile(config["bin_imputation_input_file"]):
+            # phase masks (impute.py:2001-2005, 2030-2032, 277-290): position m may switch sides only where the
+            # subject's list holds 1; an id missing from the file is a KeyError in the reference -> raw line to .problem
+            import json
+            with open(config["bin_imputation_input_file"]) as fh:
+                f_bin = json.load(fh)
+            masks = {}
+            for sid, mask in f_bin.items():
+                fixed = 0
+                for m in range(nat.MAXL):
+                    if not (m < len(mask) and mask[m] == 1):
+                        fixed |= 1 << m
+                masks[sid] = fixed
+        params = self._params(config, planb, em_mr, em)
+        ps, keep = nat.prior_spec(config["priority"], self.unk_priors, self.count_by_prob)
+        ctx = nat.default_context(self.device)
+        dgraph = self.netGraph.device(ctx)
+        t0 = timeit.default_timer()
+        st = nat.Stream(ctx, dgraph, self.netGraph.adict, params, ps, self.populations, out_paths=out_paths,
+                        want_log=not self.quiet, line_offset=line_offset, masks=masks, timing=bool(int(os.environ.get("GRIM_TIMING", "0"))))
         try:
-            if os.path.isfile(config["bin_imputation_input_file"]):
-                # phase masks (impute.py:2001-2005, 2030-2032, 277-290): position m may switch sides only
-                # where the subject's list holds 1; an id missing from the file is a KeyError in the
-                # reference -> raw line to .problem
-                import json
-                with open(config["bin_imputation_input_file"]) as fh:
-                    f_bin = json.load(fh)
-                kinds0 = parsed.kinds()
-                for j in range(parsed.n_lines):
-                    if kinds0[j] == nat.K_PROBLEM_RAW:
-                        continue
-                    mask = f_bin.get(parsed.subject_id(j))
-                    if mask is None:
-                        parsed.set_kind(j, nat.K_PROBLEM_RAW)
-                    elif kinds0[j] == nat.K_DEVICE:
-                        fixed = 0
-                        for m in range(nat.MAXL):
-                            if not (m < len(mask) and mask[m] == 1):
-                                fixed |= 1 << m
-                        parsed.set_flags(j, fixed)
+            if in_path is not None:
+                st.write_file(in_path)
+            elif data:
+                st.write(data)
+            st.finish()
+            stats = st.stats()
+            self.last_stats = {
+                "n": int(stats.subjects), "lines": int(stats.lines), "chunks": int(stats.chunks), "reruns": int(stats.reruns),
+                "wall_s": stats.wall_s, "total_s": timeit.default_timer() - t0, "device_s": stats.device_s,
+                "kernel_ms": stats.kernel_ms[0], "kernel_a_ms": stats.kernel_ms[1], "kernel_b_ms": stats.kernel_ms[2],
+                "counters": [int(x) for x in stats.counters],
+                "host_s": {"tokenize_cpu": stats.tokenize_cpu_s, "format_cpu": stats.format_cpu_s, "write_cpu": stats.write_cpu_s},
+                "text_bytes": [int(x) for x in stats.text_bytes],
+            }
+            self.unsupported = st.unsupported()
+            if not self.quiet:
+                import sys
+                sys.stdout.write(st.text(6))
+            texts = None
+            if out_paths is None:
+                texts = {key: st.text(k, as_bytes=as_bytes) for k, key in enumerate(nat.TEXT_KEYS)}
+        finally:
+            st.close()
+        if self.unsupported and self.on_unsupported == "raise":
+            raise UnsupportedSubjects(self.unsupported)
+        return texts
+
+    def impute_lines_block(self, lines, config, planb=None, em_mr=False, line_offset=0, em=False):
+        """The same through the block entry points of the C-ABI (grim_tokenize -> grim_batch_upload/run/results ->
+        grim_format: the whole input as ONE device batch, every step on the calling thread).  The streaming
+        pipeline is the product path; this one is what a caller with its own scheduling would use, and the tests
+        hold the two against each other."""
+        priority = config["priority"]
+        if planb is None:
+            planb = config["planb"]
+        if not config["epsilon"] > 0:
+            raise NotImplementedError("epsilon <= 0: the reference returns its 'NaN' sentinel and fails every subject")
+        self.unsupported = []
+        text = "".join(l if l.endswith("\n") else l + "\n" for l in lines).encode()
+        parsed = nat.Parsed(self.netGraph.adict, text, planb)
+        try:
             races = parsed.races()
-            if len(races) >= 65535:
-                raise OverflowError("more than 65535 distinct race pairs in one batch")
             P = len(self.populations)
+            ps, keep = nat.prior_spec(priority, self.unk_priors, self.count_by_prob)
             priors = np.ones((max(1, len(races)), P, P))
             for k, (r1, r2) in enumerate(races):
-                priors[k] = self._prior_matrix(r1, r2, priority)
+                priors[k] = nat.prior_matrix(ps, self.populations, r1, r2)
             subj = parsed.subjects()
             kinds = parsed.kinds()
             dev = parsed.dev_index()
             params = self._params(config, planb, em_mr, em)
-            start = timeit.default_timer()
             if len(subj):
                 res, rows = self._run_arrays(subj, parsed.tokens(), priors, params)
             else:
                 res, rows = np.zeros(0, dtype=nat.RESULT_DT), np.zeros(0, dtype=nat.ROW_DT)
-            per_subject = (timeit.default_timer() - start) / max(1, len(subj))
-
-            skip = None
-            bad_lines = np.nonzero((kinds == nat.K_DEVICE) & (res["status"][np.maximum(dev, 0)] == nat.ST_UNSUPPORTED))[0] \
-                if len(subj) else []
-            if len(bad_lines):
-                bad = [(line_offset + int(j), parsed.subject_id(int(j)), int(res[dev[j]]["reason"])) for j in bad_lines]
-                self.unsupported = bad
-                if self.on_unsupported == "raise":
-                    raise UnsupportedSubjects(bad)
-                skip = np.zeros(len(kinds), dtype=np.uint8)
-                skip[bad_lines] = 1
-            tm.append(timeit.default_timer())
-            texts = parsed.format(self.netGraph.adict, params, self.populations, res, rows, line_offset, skip,
-                                  as_bytes=_raw is not None)
-            tm.append(timeit.default_timer())
-            self.last_stats["host_s"] = {"join": tm[1] - tm[0], "tokenize": tm[2] - tm[1], "device_total": tm[3] - tm[2],
-                                         "format": tm[4] - tm[3]}
-            if not self.quiet:
-                self._print_log(parsed, kinds, dev, res, skip, line_offset, muug_on, haps_on, per_subject)
-            return texts
+            bad_lines = [int(j) for j in range(len(kinds)) if kinds[j] == nat.K_UNSUPPORTED or
+                         (kinds[j] == nat.K_DEVICE and res["status"][dev[j]] == nat.ST_UNSUPPORTED)]
+            self.unsupported = [(line_offset + j, parsed.subject_id(j), 5 if kinds[j] == nat.K_UNSUPPORTED else int(res[dev[j]]["reason"]))
+                                for j in bad_lines]
+            if self.unsupported and self.on_unsupported == "raise":
+                raise UnsupportedSubjects(self.unsupported)
+            return parsed.format(self.netGraph.adict, params, self.populations, res, rows, line_offset, None)
         finally:
             parsed.close()
 
@@ -545,35 +563,6 @@ class Imputation(object):
         }
         batch.close()
         return res, rows
-
-    def _print_log(self, parsed, kinds, dev, res, skip, line_offset, muug_on, haps_on, per_subject):
-        """stdout of impute_file (impute.py:2074-2078, 2108-2112, 2138, 2142)."""
-        for j in range(len(kinds)):
-            if skip is not None and skip[j]:
-                continue
-            i = line_offset + j
-            k = kinds[j]
-            if k == nat.K_PROBLEM_ID:
-                continue
-            sid = parsed.subject_id(j)
-            if k == nat.K_PROBLEM_RAW:
-                print(f"{i} Subject: {sid} - Exception")
-                continue
-            r = res[dev[j]] if k == nat.K_DEVICE else None
-            if r is not None and r["status"] == nat.ST_NOPHASE:
-                if haps_on:
-                    print("{index} Subject: {id} 3 haplotypes".format(index=i, id=sid))  # len("Nan")
-                    print(f"{i} Subject: {sid} - Exception")
-                else:
-                    print("{index} Subject: {id} 0 haplotypes".format(index=i, id=sid))
-                continue
-            if haps_on:
-                print("{index} Subject: {id} {hap_length} haplotypes".format(
-                    index=i, id=sid, hap_length=int(r["n_pairs"]) if r is not None else 0))
-            if muug_on:
-                print("{index} Subject: {id} {hap_length} haplotypes".format(
-                    index=i, id=sid, hap_length=int(r["n_genotypes"]) if r is not None else 0))
-            print(per_subject)
 
     def impute_lines_python(self, lines, config, planb=None, em_mr=False, line_offset=0, em=False):
         """The same in pure Python host code (tokeniser `_tokenise`, formatter `_write_rows`): kept as

@@ -25,17 +25,18 @@ def test_float_text_equals_cpython_repr():
             assert nat.format_double(-v) == repr(float(-v)), v
 
 
-def _decode(g, subj, toks):
-    """subject record -> structure of allele NAMES (ids of unknown alleles depend on interning order)"""
+def _decode(g, subj, toks, parsed=None, lines_of=None):
+    """subject record -> structure of allele NAMES (alleles outside the dictionary have per-subject ids: their text
+    comes from the parsed block)"""
     out = []
-    for s in subj:
+    for si, s in enumerate(subj):
         off = int(s["tok_off"])
         pos = []
         for k in range(int(s["n_loci"])):
             sides = []
             for side in range(2):
                 n = int(s["cnt"][k][side])
-                sides.append(([g.adict.name(int(s["slot"][k]), int(t)) for t in toks[off: off + n]], int(s["wid"][k][side])))
+                sides.append(([parsed.allele(lines_of[si], int(s["slot"][k]), int(t)) for t in toks[off: off + n]], int(s["wid"][k][side])))
                 off += n
             pos.append((int(s["slot"][k]), sides))
         out.append((int(s["n_loci"]), int(s["pad"][0]), pos))
@@ -93,10 +94,44 @@ def test_cpp_tokenizer_equals_python_tokenizer(scenario):
             py_ids.append(sid)
         assert list(kinds) == py_kinds
         assert [parsed.subject_id(i) for i in range(len(all_lines)) if py_ids[i] is not None] == [x for x in py_ids if x is not None]
-        got = _decode(g, subj, toks)
+        lines_of = [j for j in range(len(all_lines)) if dev[j] >= 0]
+        got = _decode(g, subj, toks, parsed, lines_of)
         assert len(got) == len(py_recs)
         for a, (n, slots, same, pos) in zip(got, py_recs):
             exp_pos = [(slots[k], [([g.adict.name(slots[k], t) for t in pos[k][s][0]], pos[k][s][1]) for s in range(2)]) for k in range(n)]
             assert a == (n, same, exp_pos)
         assert [races[int(s["prior_idx"])] for s in subj] == py_races
         parsed.close()
+
+
+def test_cpp_prior_matrix_bit_identical_to_python():
+    """grim_prior_matrix (C++ restatement of calc_priority_matrix, impute.py:1844-1924) against the Python/numpy
+    version the oracle pins (tests/test_host_logic.py): every entry bit for bit."""
+    from grim import _native as nat
+    from grim.imputation.impute import Imputation
+
+    rng = np.random.default_rng(11)
+    pops = ["CAU", "AFA", "HIS", "API", "NAM"]
+    for trial in range(40):
+        P = int(rng.integers(1, 6))
+        pp = pops[:P]
+        imp = Imputation.__new__(Imputation)
+        imp.populations = pp
+        imp.unk_priors = "MR" if trial % 2 else "SR"
+        imp.count_by_prob = np.ones(P) if trial % 3 else rng.uniform(0.5, 3.0, P)
+        pri = {k: float(v) for k, v in zip(("alpha", "eta", "beta", "gamma", "delta"), rng.uniform(0, 1, 5))}
+        if trial % 4 == 0:
+            pri = {"alpha": 0.4999999, "eta": 0, "beta": 1e-7, "gamma": 1e-7, "delta": 0.4999999}
+        ps, keep = nat.prior_spec(pri, imp.unk_priors, imp.count_by_prob)
+        names = pp + ["UNK", "", "XXX"]
+        for _ in range(30):
+            def race():
+                k = int(rng.integers(1, 4))
+                return ";".join(names[int(rng.integers(0, len(names)))] for _ in range(k))
+            r1, r2 = race(), race()
+            if rng.random() < 0.1:
+                r1 = r2 = ""
+            with np.errstate(all="ignore"):
+                a = imp._prior_matrix(r1, r2, pri)
+            b = nat.prior_matrix(ps, pp, r1, r2)
+            assert np.array_equal(np.asarray(a, dtype=np.float64).view(np.uint64), b.view(np.uint64)), (pp, r1, r2)
