@@ -285,6 +285,7 @@ typedef struct {
   uint8_t want_log;         /* also text 6: the lines impute_file prints per subject */
   uint8_t want_records;     /* hand every chunk's records to grim_stream_next_records (the caller must drain them) */
   uint8_t timing;           /* per-kernel HIP events (grim_batch_set_timing) */
+  uint8_t rows_exact;       /* take rows_per_chunk as it is (no floor): the caller knows that one subject's rows fit */
   const char *out_path[6];  /* per text: file to create and fill, or NULL = keep in memory (grim_stream_text) */
   /* bin_imputation_in_file phase masks (impute.py:2001-2005, 2030-2032): n_masks ids (NUL-terminated, back to back
    * in mask_ids) and per id the bitmask of positions that keep their side; an id missing from the table sends its

@@ -162,6 +162,9 @@ struct grim_ctx {
   // per batch cost more than the kernels)
   void *scratch;
   uint64_t scratch_bytes;
+  // capacity batches a finished stream handed back: the next stream on this context takes them instead of
+  // allocating (and pinning) a few hundred MB per slot again
+  std::vector<grim_batch *> spare;
 };
 
 struct grim_graph {
@@ -179,6 +182,8 @@ struct grim_batch {
   // capacities of the device buffers (a batch made by grim_batch_upload is sized exactly; a stream slot is sized for
   // the biggest chunk and reloaded chunk after chunk)
   EngineCaps cap;
+  uint32_t g_pops;  // population count of the graph the prior buffers were sized for
+  uint64_t row_limit;  // rows a run may use (<= cap.rows: a recycled batch may own more than its new user asked for)
   grim_subject *d_subj;
   uint16_t *d_tok;
   double *d_priors;
@@ -251,9 +256,13 @@ extern "C" grim_ctx *grim_create(int device_id) {
   return c;
 }
 
+static void batch_destroy(grim_batch *b);
+
 extern "C" void grim_destroy(grim_ctx *c) {
   if (!c) return;
   hipSetDevice(c->device);
+  for (grim_batch *b : c->spare) batch_destroy(b);
+  c->spare.clear();
   if (c->scratch) hipFree(c->scratch);
   hipStreamDestroy(c->stream);
   delete c;
@@ -471,7 +480,7 @@ static void batch_bind(grim_batch *b) {
   A.next_list = b->d_next;
   A.res = b->d_res;
   A.rows = b->d_rows;
-  A.row_cap = (uint32_t)b->cap.rows;
+  A.row_cap = (uint32_t)(b->row_limit && b->row_limit < b->cap.rows ? b->row_limit : b->cap.rows);
   A.small_ctr = b->d_small_ctr;
   A.counters = b->d_state;
   A.queue = (uint32_t *)(A.counters + GRIM_NCTR);
@@ -479,26 +488,14 @@ static void batch_bind(grim_batch *b) {
   A.next_count = A.queue + 2;
 }
 
-grim_batch *engine_batch_create(grim_ctx *c, const grim_graph *g, const grim_params *p, const EngineCaps *caps) {
-  if (!c || !g || !p || !caps) return nullptr;
-  use_device(c->device);
-  if (p->top_n == 0 || p->top_n > GRIM_TOPCAP) { c->err = "grim_batch_upload: max_haplotypes_number_in_phase must be 1..128"; return nullptr; }
-  if (p->n_ladder < 0 || p->n_ladder > GRIM_MAXLADDER) { c->err = "grim_batch_upload: epsilon ladder too long"; return nullptr; }
-  grim_batch *b = new grim_batch();
-  memset((void *)b, 0, sizeof(*b));
-  b->ctx = c;
+// parameters, graph and the per-workgroup scratch layout of a batch (everything that is not a buffer)
+static void batch_init_params(grim_batch *b, const grim_graph *g, const grim_params *p) {
   b->g = g;
   DevArgs &A = b->a;
   A.g = g->d;
   A.prm = *p;
   const uint32_t P = g->d.P;
   b->small_stride = engine_small_stride(p);
-  bool ok = dev_realloc(b->d_state, GRIM_NCTR + 4);
-  if (hipHostMalloc((void **)&b->hstate, 8 * (GRIM_NCTR + 4)) != hipSuccess) {
-    b->hstate = nullptr;
-    ok = false;
-  }
-  ok = ok && batch_reserve(b, *caps);
   // per-workgroup scratch layout (bytes per slot); the block itself belongs to the context and is bound at run time
   A.pair_cap = GRIM_MAXPH * p->top_n * p->top_n;
   uint32_t tab = 64;
@@ -539,20 +536,77 @@ grim_batch *engine_batch_create(grim_ctx *c, const grim_graph *g, const grim_par
   L.proj_p = take(4ull * GRIM_NWAVE * A.proj_cap);
   L.rtok = take(2ull * GRIM_RTOK_CAP);
   L.stride = align256(o);
-  for (int i = 0; i < 8 && ok; ++i) ok = hipEventCreate(&b->ev[i]) == hipSuccess;
   b->timing = env_int("GRIM_TIMING", 0) != 0;
+  memset(b->acc_ms, 0, sizeof(b->acc_ms));
+  b->n_timed = 0;
+  b->n_subj = b->n_small = b->n_medium = b->n_general = 0;
+  b->rows_used = 0;
+}
+
+grim_batch *engine_batch_create(grim_ctx *c, const grim_graph *g, const grim_params *p, const EngineCaps *caps) {
+  if (!c || !g || !p || !caps) return nullptr;
+  use_device(c->device);
+  if (p->top_n == 0 || p->top_n > GRIM_TOPCAP) { c->err = "grim_batch_upload: max_haplotypes_number_in_phase must be 1..128"; return nullptr; }
+  if (p->n_ladder < 0 || p->n_ladder > GRIM_MAXLADDER) { c->err = "grim_batch_upload: epsilon ladder too long"; return nullptr; }
+  // a batch some earlier stream handed back (same population count: the prior buffers are sized in P x P units)
+  for (size_t k = 0; k < c->spare.size(); ++k) {
+    grim_batch *b = c->spare[k];
+    if (b->g_pops != g->d.P) continue;
+    c->spare.erase(c->spare.begin() + (long)k);
+    batch_init_params(b, g, p);
+    b->row_limit = caps->rows;
+    if (!batch_reserve(b, *caps)) {
+      c->err = "grim_batch: device or pinned-host allocation failed";
+      batch_destroy(b);
+      return nullptr;
+    }
+    batch_bind(b);
+    return b;
+  }
+  grim_batch *b = new grim_batch();
+  memset((void *)b, 0, sizeof(*b));
+  b->ctx = c;
+  b->g_pops = g->d.P;
+  b->row_limit = caps->rows;
+  batch_init_params(b, g, p);
+  bool ok = dev_realloc(b->d_state, GRIM_NCTR + 4);
+  if (hipHostMalloc((void **)&b->hstate, 8 * (GRIM_NCTR + 4)) != hipSuccess) {
+    b->hstate = nullptr;
+    ok = false;
+  }
+  ok = ok && batch_reserve(b, *caps);
+  for (int i = 0; i < 8 && ok; ++i) ok = hipEventCreate(&b->ev[i]) == hipSuccess;
   if (!ok) {
     c->err = "grim_batch: device or pinned-host allocation failed";
-    grim_batch_free(b);
+    batch_destroy(b);
     return nullptr;
   }
   batch_bind(b);
   return b;
 }
 
+// hand a capacity batch back to its context for the next stream (at most 8 are kept)
+void engine_batch_recycle(grim_batch *b) {
+  if (!b) return;
+  grim_ctx *c = b->ctx;
+  use_device(c->device);
+  hipStreamSynchronize(c->stream);
+  if (b->gexec) {
+    hipGraphExecDestroy(b->gexec);
+    b->gexec = nullptr;
+  }
+  b->graph_state = 0;
+  if (c->spare.size() >= 8) {
+    batch_destroy(b);
+    return;
+  }
+  c->spare.push_back(b);
+}
+
 int engine_batch_reserve(grim_batch *b, const EngineCaps *caps) {
   if (!b || !caps) return -1;
   use_device(b->ctx->device);
+  if (caps->rows > b->row_limit) b->row_limit = caps->rows;
   if (!batch_reserve(b, *caps)) {
     b->ctx->err = "grim_batch: device or pinned-host allocation failed while growing a batch";
     return -1;
@@ -754,6 +808,12 @@ extern "C" int grim_batch_run(grim_batch *b) {
   use_device(c->device);
   DevArgs &A = b->a;
   if (bind_scratch(b) != 0) return -1;
+  if ((uint64_t)b->n_small * b->small_stride > A.row_cap) {
+    // the half-wave kernel's rows have fixed places at the bottom of the pool: they must all exist
+    b->rows_used = 0;
+    c->err = "grim_batch_run: output row pool smaller than the half-wave kernel's fixed region";
+    return -2;
+  }
   b->ms_s = b->ms_a = b->ms_g = b->ms_m = 0;
   if (b->timing) {
     if (enqueue_stage1(b, true) != 0) {
@@ -918,7 +978,9 @@ extern "C" int grim_batch_results(grim_batch *b, grim_subject_result *res, grim_
   return 0;
 }
 
-extern "C" void grim_batch_free(grim_batch *b) {
+extern "C" void grim_batch_free(grim_batch *b) { batch_destroy(b); }
+
+static void batch_destroy(grim_batch *b) {
   if (!b) return;
   use_device(b->ctx->device);
   hipStreamSynchronize(b->ctx->stream);

@@ -45,3 +45,5 @@ int engine_batch_load(grim_batch *b, const EngineLoad *ld);
 int engine_batch_fetch(grim_batch *b, uint32_t res_lo, uint32_t res_hi, grim_row *rows_dst);
 uint64_t engine_bytes_moved(const grim_batch *b, int dir);  // 0 = H2D, 1 = D2H since creation
 void engine_set_error(grim_ctx *ctx, const char *msg);
+// hand a batch back to its context: the next engine_batch_create on that context reuses its buffers
+void engine_batch_recycle(grim_batch *b);

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
 #include <sys/types.h>
@@ -254,6 +255,7 @@ static int device_part(grim_stream *s, Chunk *c, uint32_t lo, uint32_t hi, bool 
     EngineCaps cp = engine_batch_caps(b);
     if (n_priors > cp.priors) {
       cp.priors = n_priors * 2;
+      cp.rows = 0;
       if (engine_batch_reserve(b, &cp) != 0) return -1;
       H = engine_batch_host(b);
     }
@@ -262,6 +264,9 @@ static int device_part(grim_stream *s, Chunk *c, uint32_t lo, uint32_t hi, bool 
   EngineLoad ld{c->n_lines, n_priors, (uint32_t)(s1 - s0), (uint32_t)(m1 - m0), ng, (uint32_t)so.size(), so.data(), sl.data()};
   if (engine_batch_load(b, &ld) != 0) return -1;
   const int rc = grim_batch_run(b);
+  if (getenv("GRIM_DEBUG_STREAM"))
+    fprintf(stderr, "grim stream: chunk %llu lines [%u,%u) small %zu medium %zu general %u -> rc %d, rows %u (pool %llu)\n",
+            (unsigned long long)c->index, lo, hi, s1 - s0, m1 - m0, ng, rc, grim_batch_total_rows(b), (unsigned long long)s->rows_per_chunk);
   if (s->opt.timing) {
     for (int k = 0; k < 6; ++k) s->st.kernel_ms[k] += grim_batch_kernel_ms(b, k);
     uint64_t ctr[4];
@@ -529,6 +534,7 @@ static int dispatch(grim_stream *s, Chunk *c) {
   if (n > cp.subj || tok_total > cp.tok) {
     if (n > cp.subj) cp.subj = n;
     if (tok_total > cp.tok) cp.tok = tok_total + tok_total / 4;
+    cp.rows = 0;  // the row pool stays as it is (a recycled batch may own more rows than this stream may use)
     if (engine_batch_reserve(c->batch, &cp) != 0) {
       std::lock_guard<std::mutex> lk(s->mu);
       s->fail(std::string("growing a chunk's buffers failed: ") + grim_last_error(s->ctx));
@@ -791,8 +797,10 @@ extern "C" grim_stream *grim_stream_open(grim_ctx *ctx, const grim_graph *g, con
   // worst case and the one-wave kernel's per-wave row blocks
   const uint64_t per = engine_rows_per_subject(prm, n_pops);
   uint64_t rows = opts->rows_per_chunk ? opts->rows_per_chunk : 32ull * s->chunk_lines;
-  const uint64_t floor_rows = (uint64_t)engine_small_stride(prm) * s->chunk_lines + 2 * per + 64ull * 256 * 32 + 1024;
-  if (rows < floor_rows) rows = floor_rows;
+  // (one subject: at most four block grabs of the one-wave kernel, each max(rows needed, 64); more subjects than the pool
+  //  holds are what the split-and-rerun is for)
+  const uint64_t floor_rows = (uint64_t)engine_small_stride(prm) * s->chunk_lines + 2 * per + 4 * 64 + 1024;
+  if (rows < floor_rows && !(opts->rows_exact && opts->rows_per_chunk)) rows = floor_rows;
   if (rows > 0x7FFFFFF0ull) rows = 0x7FFFFFF0ull;
   s->rows_per_chunk = rows;
   for (int k = 0; k < 6; ++k)
@@ -838,7 +846,7 @@ extern "C" void grim_stream_free(grim_stream *s) {
   }
   for (auto &t : s->workers) t.join();
   if (s->dev_thread.joinable()) s->dev_thread.join();
-  for (auto &c : s->chunks) grim_batch_free(c->batch);
+  for (auto &c : s->chunks) engine_batch_recycle(c->batch);
   for (int k = 0; k < 6; ++k)
     if (s->fd[k] >= 0) close(s->fd[k]);
   for (int k = 0; k < 7; ++k)

@@ -317,7 +317,7 @@ class PriorSpec(C.Structure):
 class StreamOpts(C.Structure):
     _fields_ = [("chunk_lines", C.c_uint32), ("depth", C.c_uint32), ("n_threads", C.c_int32), ("line_offset", C.c_uint64),
                 ("rows_per_chunk", C.c_uint64), ("want_text", C.c_uint8), ("want_log", C.c_uint8), ("want_records", C.c_uint8),
-                ("timing", C.c_uint8), ("out_path", C.c_char_p * 6), ("mask_ids", C.c_char_p), ("mask_fixed", C.c_void_p),
+                ("timing", C.c_uint8), ("rows_exact", C.c_uint8), ("out_path", C.c_char_p * 6), ("mask_ids", C.c_char_p), ("mask_fixed", C.c_void_p),
                 ("n_masks", C.c_uint32)]
 
 
@@ -647,7 +647,7 @@ class Stream:
     """grim_stream: the chunked tokenizer -> device -> formatter pipeline (impute_file's loop)."""
 
     def __init__(self, ctx, dgraph, adict, params, ps, pops, out_paths=None, want_text=True, want_log=False, want_records=False,
-                 chunk_lines=0, depth=0, n_threads=0, line_offset=0, rows_per_chunk=0, timing=False, masks=None):
+                 chunk_lines=0, depth=0, n_threads=0, line_offset=0, rows_per_chunk=0, timing=False, masks=None, rows_exact=False):
         L = host_lib()
         self.ctx = ctx
         o = StreamOpts()
@@ -660,6 +660,7 @@ class Stream:
         o.want_log = 1 if want_log else 0
         o.want_records = 1 if want_records else 0
         o.timing = 1 if timing else 0
+        o.rows_exact = 1 if rows_exact else 0
         self._keep = [params, ps]
         if out_paths:
             for k, key in enumerate(TEXT_KEYS):

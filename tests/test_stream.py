@@ -1,0 +1,211 @@
+"""The streaming pipeline of the library (grim_stream_*, csrc/grim_stream.cpp) on the GPU: chunking, ranges, the bounded
+row pool with split-and-rerun, records mode, and BASELINE config 3 (1 M subjects) through properties + an oracle slice.
+Everything goes through the C-ABI (ctypes)."""
+import os
+
+import numpy as np
+import pytest
+
+import harness
+import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _imp(gname, conf):
+    from grim.imputation.impute import Imputation
+    from grim.imputation.networkx_graph import Graph
+    from grim.run_impute_def import load_config
+
+    work = harness.ensure_graph(gname)
+    conf2, cpath = harness._write_inputs(work, conf, [], "stream_cfg")
+    cwd = os.getcwd()
+    os.chdir(work)
+    try:
+        cfg, _ = load_config(cpath)
+        g = harness._graph_cache.get(gname)
+        if g is None:
+            g = Graph(cfg).build_graph(cfg["node_file"], cfg["top_links_file"], cfg["edges_file"])
+            harness._graph_cache[gname] = g
+        imp = Imputation(g, cfg)  # (reads pops_count_file, a path relative to the work directory)
+    finally:
+        os.chdir(cwd)
+    imp.quiet = True
+    return imp, cfg
+
+
+def _stream_texts(imp, cfg, lines, em_mr=False, **kw):
+    """the six texts of `lines` through a stream opened with explicit options (chunk size, row pool, threads)"""
+    from grim import _native as nat
+
+    params = imp._params(cfg, cfg["planb"], em_mr, False)
+    ps, keep = nat.prior_spec(cfg["priority"], imp.unk_priors, imp.count_by_prob)
+    ctx = nat.default_context(None)
+    st = nat.Stream(ctx, imp.netGraph.device(ctx), imp.netGraph.adict, params, ps, imp.populations, **kw)
+    try:
+        data = ("\n".join(lines) + "\n").encode() if lines else b""
+        # feed in awkward pieces: lines straddle the calls
+        step = 777
+        for a in range(0, len(data), step):
+            st.write(data[a:a + step])
+        st.finish()
+        texts = {key: st.text(k) for k, key in enumerate(nat.TEXT_KEYS)}
+        stats = st.stats()
+        return texts, stats, st.unsupported()
+    finally:
+        st.close()
+
+
+@pytest.mark.parametrize("scenario", ["cau_mixed", "pop4_mixed", "cau_edge", "pop4_planc_rerun", "cau_scan30", "cau_mr_res1000"])
+def test_small_chunks_and_ranges_equal_golden(scenario):
+    """64-line chunks (several chunks in flight, several ranges per chunk on 4 threads): same bytes as the reference"""
+    gname, conf, lines, exp, elog, em = harness.golden(scenario)
+    imp, cfg = _imp(gname, conf)
+    texts, stats, unsup = _stream_texts(imp, cfg, lines, em_mr=em, chunk_lines=64, n_threads=4, depth=3)
+    assert not unsup
+    assert stats.chunks == (len(lines) + 63) // 64
+    for k in exp:
+        if (k in ("umug", "umug_pops") and not cfg["output_MUUG"]) or (k in ("pmug", "pmug_pops") and not cfg["output_haplotypes"]):
+            continue
+        assert texts[k] == exp[k], "%s: %s differs from the reference output" % (scenario, k)
+
+
+@pytest.mark.parametrize("scenario", ["cau_mixed", "pop4_mixed", "cau_mr_res1000"])
+def test_row_pool_overflow_splits_and_reruns(scenario):
+    """a row pool far too small for the chunk: the chunk is halved and run again until the parts fit; same bytes"""
+    gname, conf, lines, exp, elog, em = harness.golden(scenario)
+    imp, cfg = _imp(gname, conf)
+    pool = 2600 if scenario == "cau_mr_res1000" else 700  # one subject fits (2 002 / 52 rows at most, plus block slack), the chunk does not
+    texts, stats, unsup = _stream_texts(imp, cfg, lines, em_mr=em, chunk_lines=256, rows_per_chunk=pool, rows_exact=True, n_threads=2)
+    assert stats.reruns > 0, "the pool was meant to overflow"
+    for k in exp:
+        assert texts[k] == exp[k], "%s: %s differs after split-and-rerun" % (scenario, k)
+
+
+def test_block_entry_points_equal_stream():
+    """grim_tokenize -> grim_batch_upload/run/results -> grim_format (one batch, caller's thread) against the stream"""
+    rows = synth.read_freqs(synth.CAU_FREQS)
+    conf = harness.base_conf(harness.POPS["pop4"])
+    conf["UNK_priors"] = "MR"
+    lines = synth.SubjectGen(rows, 41, pops=harness.POPS["pop4"]).mixed(400) + synth.edge_cases("AFA") + synth.plan_c_cases("HIS")
+    imp, cfg = _imp("pop4", conf)
+    a = imp.impute_lines_block(lines, cfg)
+    b = imp.impute_lines(lines, cfg)
+    for k in b:
+        assert a[k] == b[k], k
+
+
+def test_records_mode_matches_texts():
+    """want_records: the raw result records of every chunk, in input order, while the texts are built as well"""
+    import threading
+
+    from grim import _native as nat
+
+    rows = synth.read_freqs(synth.CAU_FREQS)
+    lines = synth.SubjectGen(rows, 42).full(3000) + synth.SubjectGen(rows, 43).mixed(500)
+    conf = harness.base_conf(["CAU"])
+    imp, cfg = _imp("cau", conf)
+    params = imp._params(cfg, cfg["planb"], False, False)
+    ps, keep = nat.prior_spec(cfg["priority"], imp.unk_priors, imp.count_by_prob)
+    ctx = nat.default_context(None)
+    st = nat.Stream(ctx, imp.netGraph.device(ctx), imp.netGraph.adict, params, ps, imp.populations, want_records=True,
+                    chunk_lines=512, depth=2, n_threads=3)
+    data = ("\n".join(lines) + "\n").encode()
+    err = []
+
+    def feed():
+        try:
+            st.write(data)
+            st.finish()
+        except Exception as e:  # pragma: no cover
+            err.append(e)
+
+    th = threading.Thread(target=feed)
+    th.start()
+    n_lines = n_rows = n_pairs = 0
+    first = []
+    while True:
+        rec = st.next_records()
+        if rec is None:
+            break
+        first_line, kinds, res, rows_addr, handle = rec
+        first.append(first_line)
+        dev = kinds == nat.K_DEVICE
+        n_lines += len(kinds)
+        n_rows += int(res["n_rows"][dev][:, nat.T_PMUG].sum())
+        n_pairs += int((res["status"][dev] == nat.ST_OK).sum())
+        st.release(handle)
+    th.join()
+    assert not err
+    assert first == list(range(0, len(lines), 512))
+    assert n_lines == len(lines)
+    pmug = st.text(2)
+    assert n_rows == len(pmug.splitlines())
+    assert n_pairs == len({l.split(",")[0] for l in st.text(0).splitlines()})
+    st.close()
+
+
+def test_input_file_with_crlf_and_no_final_newline(tmp_path):
+    """grim_stream_write_file: universal newlines as Python's open(), last line without '\\n'"""
+    rows = synth.read_freqs(synth.CAU_FREQS)
+    lines = synth.SubjectGen(rows, 44).mixed(300)
+    conf = harness.base_conf(["CAU"])
+    imp, cfg = _imp("cau", conf)
+    ref = imp.impute_lines(lines, cfg)
+    p = tmp_path / "in.csv"
+    p.write_bytes("\r\n".join(lines[:150]).encode() + b"\r" + "\r".join(lines[150:]).encode())
+    cfg2 = dict(cfg)
+    cfg2["imputation_input_file"] = str(p)
+    out = {}
+    for key, path_key, flag in imp._OUT_FILES:
+        cfg2[path_key] = str(tmp_path / (key + ".txt"))
+    imp.impute_file(cfg2)
+    for key, path_key, flag in imp._OUT_FILES:
+        assert open(cfg2[path_key]).read() == ref[key], key
+
+
+def test_config3_one_million_subjects_properties_and_oracle_slice():
+    """BASELINE configs[2]: CAU 5-locus, 1 M fully typed subjects, seed 1 (one GPU's worth here: the graph is replicated
+    and subjects are independent, so a shard is the same computation).  File -> file through impute_file."""
+    rows = synth.read_freqs(synth.CAU_FREQS)
+    n = 1_000_000
+    lines = synth.SubjectGen(rows, 1).full_fast(n)
+    conf = harness.base_conf(["CAU"])
+    got, glog, imp = harness.run_product("cau", conf, lines, tag="c3", quiet=True)
+    assert imp.last_stats["lines"] == n and imp.last_stats["chunks"] >= 7
+    assert got["miss"] == "" and got["problem"] == ""
+    umug = got["umug"].splitlines()
+    assert len(umug) == n
+    # one MUUG per subject in input order, rank 0
+    k = 0
+    for i in range(0, n, 9973):
+        f = umug[i].split(",")
+        assert f[0] == "S%d" % i and f[3] == "0"
+        k += 1
+    # checksum of checksums over permutation: a permuted slice gives the same rows for the same ids
+    perm = np.random.default_rng(7).permutation(50_000)
+    sub = [lines[i] for i in perm]
+    got2, _, _ = harness.run_product("cau", conf, sub, tag="c3p", quiet=True)
+    want = {l.split(",")[0]: l for l in umug[:50_000]}
+    for l in got2["umug"].splitlines():
+        assert want[l.split(",")[0]] == l
+    # phased rows: ranked, and they add up to the MUUG when all are listed
+    by = {}
+    for l in got["pmug"].splitlines()[:400_000]:
+        f = l.split(",")
+        by.setdefault(f[0], []).append(float(f[2]))
+    for i in range(0, 60_000, 7):
+        ps = by.get("S%d" % i)
+        if ps is None:
+            continue
+        assert ps == sorted(ps, reverse=True)
+        u = float(umug[i].split(",")[2])
+        if len(ps) < 10:
+            assert abs(sum(ps) - u) <= 1e-12 * u
+    # an oracle slice from the middle of the file (all six files)
+    lo, hi = 500_000, 501_500
+    exp, _ = harness.run_oracle("cau", conf, lines[lo:hi], tag="c3_orc")
+    ids = {l.split(",")[0] for l in lines[lo:hi]}
+    for key in ("umug", "umug_pops", "pmug", "pmug_pops"):
+        mine = [l for l in got[key].splitlines() if l.split(",", 1)[0] in ids]
+        assert mine == exp[key].splitlines(), key

@@ -102,7 +102,7 @@ def read_outputs(work, tag):
 _graph_cache = {}
 
 
-def run_product(graph_name, conf, lines, tag="prod", em_mr=False, on_unsupported="raise"):
+def run_product(graph_name, conf, lines, tag="prod", em_mr=False, on_unsupported="raise", quiet=False):
     """Run the HIP path through the reference-shaped API.  -> (texts, log lines, Imputation)."""
     from grim.imputation.impute import Imputation
     from grim.imputation.networkx_graph import Graph
@@ -121,7 +121,7 @@ def run_product(graph_name, conf, lines, tag="prod", em_mr=False, on_unsupported
             _graph_cache[graph_name] = g
         imp = Imputation(g, cfg)
         imp.on_unsupported = on_unsupported
-        imp.quiet = False
+        imp.quiet = quiet
         os.makedirs(out_dir, exist_ok=True)
         buf = io.StringIO()
         with contextlib.redirect_stdout(buf):

@@ -127,6 +127,20 @@ class SubjectGen:
             out.append("%s%d,%s,%s,%s" % (prefix, i, self.gl(h1, h2), self.pops[0], self.pops[0]))
         return out
 
+    def full_fast(self, n, prefix="S"):
+        """the same lines as full(n) (same generator state afterwards), drawn in one vectorised call: Generator.choice
+        with p= takes one uniform double per draw, whether it is asked for one value or for 2n"""
+        idx = self.rng.choice(len(self.haps), size=2 * n, p=self.p)
+        pop = self.pops[0]
+        out = []
+        haps = self.haps
+        for i in range(n):
+            h1, h2 = haps[int(idx[2 * i])], haps[int(idx[2 * i + 1])]
+            out.append("%s%d,%s+%s^%s+%s^%s+%s^%s+%s^%s+%s,%s,%s" % (
+                prefix, i, h1["A"], h2["A"], h1["B"], h2["B"], h1["C"], h2["C"], h1["DQB1"], h2["DQB1"], h1["DRB1"], h2["DRB1"],
+                pop, pop))
+        return out
+
     def mixed(self, n, amb=0.3, miss=0.15, recomb=0.3, prefix="M"):
         """config 4 style: ambiguity, missing loci, recombinants, mixed race columns."""
         out = []
