@@ -2,11 +2,23 @@
 """
 bench.py -- imputed subjects/sec on the CAU 5-locus graph (BASELINE.json metric).
 
-A step = one pass of the grim.impute hot path (plan A kernel, plan B/C kernel when subjects need
-it) over one batch of synthetic subjects that is already resident in HBM.  N=1 workload:
-BASELINE.json configs[1] -- 10k fully typed synthetic subjects, seed 0.  N>1: weak scaling, every
-rank owns its own 10k-subject batch (seed = rank), graph replicated per GPU, no data-path
-collective; the timed region is bracketed by barrier + device sync and the max over ranks counts.
+A step = one pass of the grim.impute hot path over one batch of synthetic subjects.  N=1 workload (default):
+BASELINE.json configs[1] -- 10k fully typed synthetic subjects, seed 0.
+
+What is timed (SURVEY 8d protocol), all in one run:
+  value / ms_per_step   HEADLINE: host GL strings in memory -> result records in host memory.  Every step hands the batch's
+                        text to the library's streaming pipeline (grim_stream, records mode): tokenizer threads -> pinned
+                        staging -> H2D -> kernels -> D2H -> records in pinned host memory, consumed by this process.
+                        Steps are pipelined (depth 4) the way a file's chunks are; the graph is resident in HBM.
+  kernel_only/roofline  the same batch resident in HBM, kernels only (per-kernel HIP events on the launch stream):
+                        the input of the roofline fraction (algorithmic bytes / kernel time / 8 TB/s).
+  file_to_file          Imputation.impute_file: subject file on disk -> the six output files on disk (adds the formatter
+                        threads and the ordered pwrites).
+  cpu_baseline          the oracle (Python restatement of the reference) on the box's host cores, strings in memory ->
+                        result texts in memory, graph load excluded -- the same scope as the headline.
+N>1: one process per GPU, weak scaling (every rank owns its own batch, seed = rank), graph replicated, no data-path
+collective; barrier + device sync around the timed region, max over ranks.  `--workload config3` is the strong-scaling
+variant (1 M subjects in total, split over the ranks).
 
 Prints ONE JSON line on rank 0.
 """
@@ -14,6 +26,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -21,6 +34,34 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MAX_CHUNK = 131072
+
+WORKLOADS = {
+    # name: (graph, description, default subjects per step on ONE GPU, scaling)
+    "config2": ("cau", "BASELINE configs[1]: CAU 5-locus graph, 10k synthetic fully-typed subjects", 10000, "weak"),
+    "config3": ("cau", "BASELINE configs[2]: CAU 5-locus graph, 1M synthetic fully-typed subjects (seed 1) split over the GPUs", 1000000, "strong"),
+    "config4": ("pop4", "BASELINE configs[3]: 4-population 5-locus graph, 100k subjects with missing loci / ambiguity / recombinants (seed 3), MR priors", 100000, "strong"),
+    "config5": ("wmda", "BASELINE configs[4] (synthetic stand-in): WMDA-scale multi-population graph, high-ambiguity subjects, options threshold 1e6, 100 haplotypes in phase", 256, "strong"),
+    "mixed": ("cau", "CAU 5-locus graph, mixed subjects (ambiguity, missing loci, recombinants); not a BASELINE config", 10000, "weak"),
+}
+
+
+def make_lines(workload, n, rank, world, rows):
+    import harness
+    import synth
+
+    if workload == "config2":
+        return synth.SubjectGen(rows, rank).full_fast(n)  # seed 0 on rank 0 = config 2
+    if workload == "config3":
+        total = n * world
+        return synth.SubjectGen(rows, 1).full_fast(total)[rank * n:(rank + 1) * n]
+    if workload == "config4":
+        total = n * world
+        return synth.SubjectGen(rows, 3, pops=harness.POPS["pop4"]).mixed(total)[rank * n:(rank + 1) * n]
+    if workload == "config5":
+        import wmda_scale
+        return wmda_scale.subjects(n * world)[rank * n:(rank + 1) * n]
+    return synth.SubjectGen(rows, rank).mixed(n)
 
 
 def main():
@@ -28,11 +69,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--subjects", type=int, default=10000, help="subjects per GPU (config 2: 10000)")
-    ap.add_argument("--workload", default="full", choices=["full", "mixed"])
+    ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS) + ["full"])
+    ap.add_argument("--subjects", type=int, default=0, help="subjects per step and GPU (default: the workload's size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-file", action="store_true", help="skip the file -> file leg")
+    ap.add_argument("--file-subjects", type=int, default=1000000, help="lines of the file -> file leg (config 2/3: 1M = config 3's file)")
     ap.add_argument("--cpu-workers", type=int, default=8, help="processes of the CPU baseline (cpu_baseline.cores)")
+    ap.add_argument("--kernel-steps", type=int, default=50, help="runs of the resident-batch kernel loop (roofline)")
     args = ap.parse_args()
+    if args.workload == "full":
+        args.workload = "config2"
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -55,6 +101,8 @@ def main():
             ge.build()  # one rank (re)builds the library if it is stale; the others wait
         dist.barrier()
     ge.build()
+    import numpy as np
+
     import harness
     import synth
     from grim import _native as nat
@@ -62,147 +110,272 @@ def main():
     from grim.imputation.networkx_graph import Graph
     from grim.run_impute_def import load_config
 
-    # ---- graph + subjects (host work, outside the timed region) -----------------------------------
-    if rank == 0:
-        work = harness.ensure_graph("cau")
-    if dist is not None:
-        dist.barrier()
-    work = harness.ensure_graph("cau")
-    conf = harness.base_conf(["CAU"])
+    gname, desc, dflt_n, scaling = WORKLOADS[args.workload]
+    n_step = args.subjects or (dflt_n if scaling == "weak" else max(1, dflt_n // world))
+    # chunk size of the stream: a divisor of the step so that every step is a whole number of device batches
+    m = (n_step + MAX_CHUNK - 1) // MAX_CHUNK
+    while n_step % m:
+        m += 1
+    chunk_lines = n_step // m
+
+    # ---- graph + subjects (host work, outside every timed region) ------------------------------------
+    if gname == "wmda":
+        import wmda_scale
+        if rank == 0:
+            wmda_scale.ensure()
+        if dist is not None:
+            dist.barrier()
+        work = wmda_scale.ensure()
+        conf = wmda_scale.conf()
+    else:
+        if rank == 0:
+            harness.ensure_graph(gname)
+        if dist is not None:
+            dist.barrier()
+        work = harness.ensure_graph(gname)
+        conf = harness.base_conf(harness.POPS[gname])
+        if gname == "pop4":
+            conf["UNK_priors"] = "MR"
     cpath = os.path.join(work, "conf_bench_%d.json" % rank)
     json.dump(conf, open(cpath, "w"))
     os.chdir(work)
     cfg, _ = load_config(cpath)
     graph = Graph(cfg).build_graph(cfg["node_file"], cfg["top_links_file"], cfg["edges_file"])
     rows = synth.read_freqs(synth.CAU_FREQS)
-    gen = synth.SubjectGen(rows, rank)  # seed 0 on rank 0 = config 2
-    lines = gen.full(args.subjects) if args.workload == "full" else gen.mixed(args.subjects)
+    lines = make_lines(args.workload, n_step, rank, world, rows)
+    text = ("\n".join(lines) + "\n").encode()
     n_dev_all = max(1, nat.lib().grim_device_count())
     imp = Imputation(graph, cfg, device=local_rank % n_dev_all)
-    import numpy as np
-    parsed = nat.Parsed(graph.adict, ("\n".join(lines) + "\n").encode(), cfg["planb"])  # C++ tokenizer of the library
-    subj, toks = parsed.subjects(), parsed.tokens()
-    assert len(subj) == len(lines)
-    records = subj
-    n_tok = int(subj["cnt"].sum())
-    priors = np.stack([imp._prior_matrix(r1, r2, cfg["priority"]) for r1, r2 in parsed.races()])
+    imp.quiet = True
+    P = len(cfg["pops"])
     params = imp._params(cfg, cfg["planb"], False)
+    ps, keep = nat.prior_spec(cfg["priority"], imp.unk_priors, imp.count_by_prob)
     ctx = nat.default_context(local_rank % n_dev_all)
-    batch = nat.DeviceBatch(ctx, graph.device(ctx), params, subj, toks, priors)  # upload: subjects now resident in HBM
-    batch.run()
-    res, rows_out = batch.results()
-    n_ok = int((res["status"] == nat.ST_OK).sum())
+    dgraph = graph.device(ctx)
 
     def sync_barrier():
         if dist is not None:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        batch.run()
-    # every timed step: each kernel bracketed by its own start/stop HIP events on the launch stream
-    # (hipExtLaunchKernelGGL); the library keeps the per-kernel sums, read once after the loop
-    batch.set_timing(True)
+    # ---- A. headline: host strings -> host records, K steps through one stream ------------------------
+    st = nat.Stream(ctx, dgraph, graph.adict, params, ps, cfg["pops"], want_text=False, want_records=True,
+                    chunk_lines=chunk_lines, depth=4)
+    chunks_per_step = n_step // chunk_lines
+    go = threading.Event()
+    feed_err = []
+
+    def feed():
+        try:
+            for _ in range(args.warmup):
+                st.write(text)
+            go.wait()
+            for _ in range(args.steps):
+                st.write(text)
+            st.finish()
+        except Exception as e:  # pragma: no cover
+            feed_err.append(e)
+            go.set()
+
+    th = threading.Thread(target=feed)
+    th.start()
+    seen = {"lines": 0, "ok": 0, "rows": 0}
+
+    def drain(n_chunks):
+        for _ in range(n_chunks):
+            rec = st.next_records()
+            if rec is None:
+                raise RuntimeError("stream ended early: %r" % feed_err)
+            first_line, kinds, res, rows_addr, handle = rec
+            seen["lines"] += len(kinds)
+            seen["ok"] += int((res["status"][kinds == nat.K_DEVICE] == nat.ST_OK).sum())
+            seen["rows"] += int(res["n_rows"].sum()) if len(res) else 0
+            st.release(handle)
+
+    drain(args.warmup * chunks_per_step)
     sync_barrier()
+    seen.update(lines=0, ok=0, rows=0)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        batch.run()  # one complete synchronous run: kernels, stream synchronise, state check
+    go.set()
+    drain(args.steps * chunks_per_step)
     sync_barrier()
     elapsed = time.perf_counter() - t0
+    th.join()
+    if feed_err:
+        raise feed_err[0]
+    assert st.next_records() is None
+    sstats = st.stats()
+    st.close()
+    n_ok_per_step = seen["ok"] // max(1, args.steps)
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- B. kernels only: the same batch resident in HBM (roofline input) ----------------------------------
+    parsed = nat.Parsed(graph.adict, text, cfg["planb"])
+    subj, toks = parsed.subjects(), parsed.tokens()
+    n_tok = int(subj["cnt"].sum())
+    priors = np.stack([nat.prior_matrix(ps, cfg["pops"], r1, r2) for r1, r2 in parsed.races()])
+    batch = nat.DeviceBatch(ctx, dgraph, params, subj, toks, priors)
+    batch.run()
+    res, rows_out = batch.results()
+    for _ in range(3):
+        batch.run()
+    batch.set_timing(True)  # every kernel bracketed by its own start/stop HIP events on the launch stream
+    tk0 = time.perf_counter()
+    for _ in range(args.kernel_steps):
+        batch.run()
+    kernel_loop_s = time.perf_counter() - tk0
     ctr = batch.counters()  # probes, CSR neighbour ids, frequency vectors gathered, (row pool use)
     ctr[3] = int(res["n_rows"].sum())  # rows actually produced
-    P = len(cfg["pops"])
     # B_subj = B_in + sum_sides(16 q + 4 nbr + 8 P c) + 24 B_rows ; B_in = 4 + 2/token + 4
-    algo_bytes = (8 * len(records) + 2 * n_tok) + 16 * ctr[0] + 4 * ctr[1] + 8 * P * ctr[2] + 24 * ctr[3]
-    # HIP-event time of each kernel, averaged over the timed steps; the roofline is quoted for the
-    # dominant one (config 2: every subject takes the half-wave kernel)
+    algo_bytes = (8 * len(subj) + 2 * n_tok) + 16 * ctr[0] + 4 * ctr[1] + 8 * P * ctr[2] + 24 * ctr[3]
     names = ("grim_plan_a_small_kernel", "grim_plan_a_kernel", "grim_plan_b_kernel", "grim_plan_a_medium_kernel")
-    per_kernel = [batch.kernel_ms(0x10 | w) for w in (3, 4, 2, 5)]  # means over the timed steps
-    dom = max(range(3), key=lambda i: per_kernel[i])
+    per_kernel = [batch.kernel_ms(0x10 | w) for w in (3, 4, 2, 5)]  # means over the timed runs
+    dom = max(range(len(per_kernel)), key=lambda i: per_kernel[i])
     avg_ms = per_kernel[dom]
-    achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
+    all_ms = sum(per_kernel)
+    # the roofline is quoted for the dominant kernel against the bytes of the whole pass when that kernel is (nearly)
+    # the whole pass (config 2/3: the half-wave kernel), else for the sum of the kernels
+    whole = avg_ms >= 0.95 * all_ms
+    roof_ms = avg_ms if whole else all_ms
+    achieved = algo_bytes / (roof_ms * 1e-3) / 1e9 if roof_ms > 0 else 0.0
+    batch.close()
+    parsed.close()
 
-    # HBM traffic per launch of the dominant kernel: PMC numbers cannot be collected from inside this
-    # process; they come from the committed rocprofv3 --pmc passes over this same command
+    # HBM traffic per launch of the dominant kernel: PMC numbers cannot be collected from inside this process; they
+    # come from the committed rocprofv3 --pmc passes over this same command (tools/profile_round.sh)
     traffic, traffic_src = None, None
-    pmc_file = "r1g_pmc_traffic.json"  # newest committed PMC passes (tools/profile_round.sh)
-    pmc_path = os.path.join(ROOT, "profiles", pmc_file)
-    if os.path.exists(pmc_path) and args.workload == "full" and args.subjects == 10000:
-        pmc = json.load(open(pmc_path)).get(names[dom])
-        if pmc and "hbm_bytes_raw" in pmc:
+    pmc_path = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
+    if os.path.exists(pmc_path):
+        pmc = json.load(open(pmc_path)).get(args.workload, {}).get(names[dom])
+        if pmc and "hbm_bytes_raw" in pmc and n_step == dflt_n:
             traffic = pmc["hbm_bytes_raw"]
-            traffic_src = "profiles/" + pmc_file + ": (FETCH_SIZE + WRITE_SIZE) KB x 1024 per launch, separate --pmc passes; " \
+            traffic_src = "profiles/r2_pmc_traffic.json: (FETCH_SIZE + WRITE_SIZE) KB x 1024 per launch, separate --pmc passes; " \
                           "with FETCH_SIZE doubled (gfx950 wide-read correction): %d" % pmc["hbm_bytes_fetch_doubled"]
 
     out = None
     if rank == 0:
+        total_subjects = world * n_step * args.steps
         out = {
             "metric": "imputed subjects/sec (whole node), 5-locus CAU graph",
-            "value": world * len(records) * args.steps / elapsed,
+            "value": total_subjects / elapsed,
             "unit": "subjects/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "CAU 5-locus graph, %d synthetic %s subjects per GPU, seed=rank (BASELINE configs[1])"
-                            % (args.subjects, "fully-typed" if args.workload == "full" else "mixed"),
-                "subjects_per_gpu": len(records), "subjects_with_results": n_ok,
+                "workload": desc + ("; %d subjects per step and GPU, seed=rank" % n_step if scaling == "weak" else
+                                    "; %d subjects per step and GPU" % n_step),
+                "subjects_per_step_per_gpu": n_step, "subjects_with_results_per_step": n_ok_per_step,
                 "graph_nodes": int(graph.arrays["n_nodes"]), "populations": P,
-                "inputs": "tokenised subjects resident in HBM; results left in HBM",
+                "timed_region": "host GL strings in memory -> grim_stream (tokenizer threads, pinned staging, H2D, kernels, D2H) -> "
+                                "result records in pinned host memory, read by the caller; %d device batch(es) of %d lines per step, "
+                                "4 in flight" % (chunks_per_step, chunk_lines),
+                "host_threads": int(os.environ.get("GRIM_HOST_THREADS", "0")) or min(32, os.cpu_count() or 1),
+                "stream_cpu_s": {"tokenize": sstats.tokenize_cpu_s, "device_thread_busy": sstats.device_s},
+            },
+            "kernel_only": {
+                "subjects_per_s": len(subj) / (all_ms * 1e-3) if all_ms > 0 else None,
+                "kernel_ms_per_step": all_ms,
+                "synchronous_run_ms": 1e3 * kernel_loop_s / args.kernel_steps,
+                "inputs": "tokenised subjects resident in HBM; results left in HBM (round 1's headline)",
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": names[dom], "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": algo_bytes,
+                "kernel": names[dom] if whole else "+".join(n for n, v in zip(names, per_kernel) if v > 0),
+                "avg_launch_ms": roof_ms, "algorithmic_bytes_per_launch": algo_bytes,
                 "kernel_ms": dict(zip(names, per_kernel)),
             },
         }
+        if world == 1 and not args.no_file:
+            out["file_to_file"] = file_leg(args, work, conf, cfg, imp, lines, rows, n_step)
         if world == 1 and not args.no_cpu_baseline:
-            # bounded sample, about 15 s of wall time: the batch itself plus more of the same generator, split over
-            # worker processes the way the reference's scripts/runfile_mp.py splits a file (one oracle per chunk,
-            # each loading the graph itself); the workers never touch the GPU
-            import subprocess
-
-            workers = max(1, min(args.cpu_workers, os.cpu_count() or 1))
-            if args.workload == "full":
-                sample = lines[:10000] + synth.SubjectGen(rows, 1000).full(50000 * workers)
-            else:
-                sample = lines[: min(len(lines), 8000 * workers)]
-            spath = os.path.join(work, "data", "subjects", "bench_cpu.csv")
-            with open(spath, "w") as fh:
-                fh.write("\n".join(sample) + "\n")
-            cjson = os.path.join(work, "conf_bench_cpu.json")
-            json.dump(conf, open(cjson, "w"))
-            t1 = time.perf_counter()
-            procs = []
-            for k in range(workers):
-                lo, hi = len(sample) * k // workers, len(sample) * (k + 1) // workers
-                procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "cpu_baseline_worker.py"), "cau", cjson, spath,
-                                               str(lo), str(hi)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL))
-            done = [json.loads(p.communicate()[0].decode().strip().splitlines()[-1]) for p in procs]
-            dt = time.perf_counter() - t1
-            out["cpu_baseline"] = {
-                "value": len(sample) / dt, "unit": "subjects/s", "cores": workers, "kind": "port",
-                "sample": "%d subjects of the same generator through oracle/grim_oracle.py (Python restatement of the reference), "
-                          "%d worker processes with a contiguous chunk each as in scripts/runfile_mp.py, %.1f s wall including each "
-                          "worker's graph load; slowest worker %.1f s of imputation" % (len(sample), workers, dt, max(d["s"] for d in done)),
-            }
+            out["cpu_baseline"] = cpu_leg(args, work, conf, lines, rows, gname)
         print(json.dumps(out))
-    batch.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def file_leg(args, work, conf, cfg, imp, lines, rows, n_step):
+    """Imputation.impute_file, subject file on disk -> six output files on disk; best of 3 after one warm run."""
+    import synth
+
+    n_file = n_step
+    flines = lines
+    if args.workload in ("config2", "config3") and args.file_subjects > n_step:
+        n_file = args.file_subjects  # config 3's file: 1M subjects, seed 1
+        flines = synth.SubjectGen(rows, 1).full_fast(n_file)
+    path = os.path.join(work, "data", "subjects", "bench_file.csv")
+    with open(path, "w") as fh:
+        fh.write("\n".join(flines) + "\n")
+    c2 = dict(cfg)
+    c2["imputation_input_file"] = path
+    out_dir = os.path.join(work, "output_bench_file")
+    os.makedirs(out_dir, exist_ok=True)
+    for key, path_key, flag in imp._OUT_FILES:
+        c2[path_key] = os.path.join(out_dir, key + ".txt")
+    imp.impute_file(c2)
+    best, stats = None, None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        imp.impute_file(c2)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best:
+            best, stats = dt, dict(imp.last_stats)
+    return {
+        "subjects": n_file, "seconds": best, "subjects_per_s": n_file / best,
+        "what": "Imputation.impute_file: subject file on disk -> .umug/.umug.pops/.pmug/.pmug.pops/.miss/.problem on disk (best of 3)",
+        "pipeline_wall_s": stats.get("wall_s"), "device_thread_busy_s": stats.get("device_s"),
+        "cpu_s": stats.get("host_s"), "output_bytes": sum(stats.get("text_bytes", [])[:6]), "chunks": stats.get("chunks"),
+    }
+
+
+def cpu_leg(args, work, conf, lines, rows, gname):
+    """bounded sample, about 15 s of wall time: more subjects of the same generator, split over worker processes the way
+    the reference's scripts/runfile_mp.py splits a file (one oracle per chunk, each loading the graph itself; the graph
+    load is NOT counted: the GPU side's graph is resident too); the workers never touch the GPU"""
+    import subprocess
+
+    import synth
+
+    workers = max(1, min(args.cpu_workers, os.cpu_count() or 1))
+    if args.workload in ("config2", "config3"):
+        sample = synth.SubjectGen(rows, 1000).full_fast(20000 * workers)
+    elif args.workload == "config5":
+        sample = lines[: 2 * workers]
+    else:
+        sample = lines[: min(len(lines), 2500 * workers)]
+    spath = os.path.join(work, "data", "subjects", "bench_cpu.csv")
+    with open(spath, "w") as fh:
+        fh.write("\n".join(sample) + "\n")
+    cjson = os.path.join(work, "conf_bench_cpu.json")
+    json.dump(conf, open(cjson, "w"))
+    t1 = time.perf_counter()
+    procs = []
+    for k in range(workers):
+        lo, hi = len(sample) * k // workers, len(sample) * (k + 1) // workers
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "cpu_baseline_worker.py"), gname, cjson, spath,
+                                       str(lo), str(hi)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL))
+    done = [json.loads(p.communicate()[0].decode().strip().splitlines()[-1]) for p in procs]
+    dt = time.perf_counter() - t1
+    slowest = max(d["s"] for d in done)
+    return {
+        "value": len(sample) / slowest, "unit": "subjects/s", "cores": workers, "kind": "port",
+        "sample": "%d subjects of the same generator through oracle/grim_oracle.py (Python restatement of the reference), %d worker "
+                  "processes with a contiguous chunk each as in scripts/runfile_mp.py; input lines in memory -> output texts in memory, "
+                  "slowest worker %.1f s (graph load excluded, as on the GPU side; %.1f s wall with it)" % (len(sample), workers, slowest, dt),
+        "with_graph_load_subjects_per_s": len(sample) / dt,
+    }
 
 
 if __name__ == "__main__":

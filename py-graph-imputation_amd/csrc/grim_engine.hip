@@ -179,25 +179,25 @@ struct grim_batch {
   grim_ctx *ctx;
   const grim_graph *g;
   DevArgs a;
-  // capacities of the device buffers (a batch made by grim_batch_upload is sized exactly; a stream slot is sized for
-  // the biggest chunk and reloaded chunk after chunk)
-  EngineCaps cap;
-  uint32_t g_pops;  // population count of the graph the prior buffers were sized for
-  uint64_t row_limit;  // rows a run may use (<= cap.rows: a recycled batch may own more than its new user asked for)
-  grim_subject *d_subj;
-  uint16_t *d_tok;
-  double *d_priors;
-  SmallRec *d_small;
-  uint32_t *d_os, *d_om, *d_og, *d_bail, *d_next, *d_small_ctr;
-  grim_subject_result *d_res;
-  grim_row *d_rows;
-  unsigned long long *d_state;
-  EngineHost h;        // pinned staging (inputs) and landing area (results)
-  uint64_t h_rows_cap; // rows the pinned landing area holds
+  // Three arenas, laid out per load (engine_batch_plan): what the next batch holds decides the offsets, so ONE copy
+  // moves a batch's whole input to the device and ONE copy brings its results back.
+  //   in   (device + pinned mirror): run state | subjects | half-wave records | three class lists | tokens
+  //   work (device only)           : hand-over lists, per-wave counters
+  //   out  (device + pinned mirror): result headers | row pool
+  uint8_t *d_in, *h_in, *d_work, *d_out, *h_out;
+  uint64_t in_cap, work_cap, out_cap, h_out_cap;
+  double *d_priors, *h_priors;  // prior matrices: their own small buffers, uploaded only when the set changes
+  uint32_t priors_cap, priors_up;
+  uint64_t row_limit;   // rows a run may use
+  EnginePlan plan;      // what the arenas are laid out for
+  uint64_t off_tok, off_rows;  // byte offsets inside in / out
+  EngineHost h;         // pointers into the pinned arenas (valid until the next plan)
   uint32_t n_subj, n_slots;
   uint32_t n_small_waves;
   bool small_ctr_pending;  // the half-wave kernel's per-wave counts have not been added to `counters` yet
   unsigned long long *hstate;  // pinned: counters + work/row heads of the last run
+  SmallRec *d_small;
+  uint32_t *d_os, *d_om;
   uint32_t n_medium;
   uint32_t n_small, n_general, small_stride;
   uint64_t scratch_need;  // bytes of per-workgroup scratch this batch's runs need (bound at run time)
@@ -420,72 +420,87 @@ uint64_t engine_rows_per_subject(const grim_params *p, uint32_t P) {
   return 2ull * p->n_results + 2ull * (p->n_pop_results < (uint64_t)P * P ? p->n_pop_results : (uint64_t)P * P);
 }
 
-template <typename T>
-static bool dev_realloc(T *&ptr, uint64_t n) {
+static bool dev_realloc(uint8_t *&ptr, uint64_t bytes) {
   if (ptr) hipFree(ptr);
   ptr = nullptr;
-  return hipMalloc((void **)&ptr, (n ? n : 1) * sizeof(T)) == hipSuccess;
+  return hipMalloc((void **)&ptr, bytes ? bytes : 256) == hipSuccess;
 }
-template <typename T>
-static bool pin_realloc(T *&ptr, uint64_t n) {
+static bool pin_realloc(uint8_t *&ptr, uint64_t bytes) {
   if (ptr) hipHostFree(ptr);
   ptr = nullptr;
-  return hipHostMalloc((void **)&ptr, (n ? n : 1) * sizeof(T), hipHostMallocDefault) == hipSuccess;
+  return hipHostMalloc((void **)&ptr, bytes ? bytes : 256, hipHostMallocDefault) == hipSuccess;
 }
 
 static uint64_t g_moved[2];
 
-// (re)allocate whatever is smaller than `want`; contents are not kept
-static bool batch_reserve(grim_batch *b, const EngineCaps &want) {
-  grim_ctx *c = b->ctx;
+// lay the arenas out for a batch of at most pl.n_subj subjects and pl.tok_cap tokens; grows them when needed (what
+// they held is lost then) and points the device arguments and the host-side pointers at the new places
+static bool batch_plan(grim_batch *b, const EnginePlan &pl) {
+  const uint64_t n = pl.n_subj ? pl.n_subj : 1;
+  uint64_t o = 0;
+  auto take = [&](uint64_t bytes) { uint64_t r = o; o = align256(o + bytes); return r; };
+  const uint64_t o_state = take(8ull * (GRIM_NCTR + 4));
+  const uint64_t o_subj = take(sizeof(grim_subject) * n);
+  const uint64_t o_small = take(sizeof(SmallRec) * n);
+  const uint64_t o_os = take(4 * n), o_om = take(4 * n), o_og = take(4 * n);
+  const uint64_t o_tok = take(2 * (pl.tok_cap ? pl.tok_cap : 1));
+  const uint64_t in_bytes = o;
+  o = 0;
+  const uint64_t small_waves = ((n + GRIM_WG / 32 - 1) / (GRIM_WG / 32)) * (GRIM_WG / 64);
+  const uint64_t w_bail = take(4 * n), w_next = take(4 * n), w_ctr = take(4 * (2 * small_waves + 2));
+  const uint64_t work_bytes = o;
+  o = 0;
+  const uint64_t o_res = take(sizeof(grim_subject_result) * n);
+  const uint64_t o_rows = take(sizeof(grim_row) * b->row_limit);
+  const uint64_t out_bytes = o;
   bool ok = true;
-  if (want.subj > b->cap.subj || !b->d_subj) {
-    const uint32_t n = want.subj > b->cap.subj ? want.subj : b->cap.subj;
-    const uint64_t small_waves = (((uint64_t)n + GRIM_WG / 32 - 1) / (GRIM_WG / 32)) * (GRIM_WG / 64);
-    ok = ok && dev_realloc(b->d_subj, n) && dev_realloc(b->d_small, n) && dev_realloc(b->d_os, n) && dev_realloc(b->d_om, n) &&
-         dev_realloc(b->d_og, n) && dev_realloc(b->d_bail, n) && dev_realloc(b->d_next, n) && dev_realloc(b->d_res, n) &&
-         dev_realloc(b->d_small_ctr, 2 * small_waves + 2);
-    ok = ok && pin_realloc(b->h.subj, n) && pin_realloc(b->h.small, n) && pin_realloc(b->h.order_s, n) &&
-         pin_realloc(b->h.order_m, n) && pin_realloc(b->h.order_g, n) && pin_realloc(b->h.res, n);
-    b->cap.subj = n;
+  if (in_bytes > b->in_cap || !b->d_in) {
+    const uint64_t want = in_bytes > b->in_cap ? in_bytes : b->in_cap;
+    ok = ok && dev_realloc(b->d_in, want) && pin_realloc(b->h_in, want);
+    b->in_cap = ok ? want : 0;
   }
-  if (want.tok > b->cap.tok || !b->d_tok) {
-    const uint64_t n = want.tok > b->cap.tok ? want.tok : b->cap.tok;
-    ok = ok && dev_realloc(b->d_tok, n) && pin_realloc(b->h.tok, n);
-    b->cap.tok = n;
+  if (work_bytes > b->work_cap || !b->d_work) {
+    const uint64_t want = work_bytes > b->work_cap ? work_bytes : b->work_cap;
+    ok = ok && dev_realloc(b->d_work, want);
+    b->work_cap = ok ? want : 0;
   }
-  if (want.priors > b->cap.priors || !b->d_priors) {
-    const uint32_t n = want.priors > b->cap.priors ? want.priors : b->cap.priors;
-    const uint64_t PP = (uint64_t)b->g->d.P * b->g->d.P;
-    ok = ok && dev_realloc(b->d_priors, ((uint64_t)n + 1) * PP) && pin_realloc(b->h.priors, ((uint64_t)n + 1) * PP);
-    b->cap.priors = n;
+  if (out_bytes > b->out_cap || !b->d_out) {
+    const uint64_t want = out_bytes > b->out_cap ? out_bytes : b->out_cap;
+    ok = ok && dev_realloc(b->d_out, want);
+    b->out_cap = ok ? want : 0;
   }
-  if (want.rows > b->cap.rows || !b->d_rows) {
-    uint64_t n = want.rows > b->cap.rows ? want.rows : b->cap.rows;
-    if (n > 0x7FFFFFF0ull) n = 0x7FFFFFF0ull;
-    ok = ok && dev_realloc(b->d_rows, n);
-    b->cap.rows = n;
-  }
-  (void)c;
-  return ok;
-}
-
-static void batch_bind(grim_batch *b) {
+  if (!ok) return false;
+  b->plan = pl;
+  b->off_tok = o_tok;
+  b->off_rows = o_rows;
   DevArgs &A = b->a;
-  A.subj = b->d_subj;
-  A.tok = b->d_tok;
-  A.priors = b->d_priors;
-  A.order = b->d_og;
-  A.bail_list = b->d_bail;
-  A.next_list = b->d_next;
-  A.res = b->d_res;
-  A.rows = b->d_rows;
-  A.row_cap = (uint32_t)(b->row_limit && b->row_limit < b->cap.rows ? b->row_limit : b->cap.rows);
-  A.small_ctr = b->d_small_ctr;
-  A.counters = b->d_state;
+  A.counters = (unsigned long long *)(b->d_in + o_state);
   A.queue = (uint32_t *)(A.counters + GRIM_NCTR);
   A.row_head = A.queue + 1;
   A.next_count = A.queue + 2;
+  A.subj = (const grim_subject *)(b->d_in + o_subj);
+  b->d_small = (SmallRec *)(b->d_in + o_small);
+  b->d_os = (uint32_t *)(b->d_in + o_os);
+  b->d_om = (uint32_t *)(b->d_in + o_om);
+  A.order = (const uint32_t *)(b->d_in + o_og);
+  A.tok = (const uint16_t *)(b->d_in + o_tok);
+  A.bail_list = (uint32_t *)(b->d_work + w_bail);
+  A.next_list = (uint32_t *)(b->d_work + w_next);
+  A.small_ctr = (uint32_t *)(b->d_work + w_ctr);
+  A.res = (grim_subject_result *)(b->d_out + o_res);
+  A.rows = (grim_row *)(b->d_out + o_rows);
+  A.row_cap = (uint32_t)b->row_limit;
+  A.priors = b->d_priors;
+  A.next_cap = (uint32_t)n;
+  b->h.subj = (grim_subject *)(b->h_in + o_subj);
+  b->h.small = (SmallRec *)(b->h_in + o_small);
+  b->h.order_s = (uint32_t *)(b->h_in + o_os);
+  b->h.order_m = (uint32_t *)(b->h_in + o_om);
+  b->h.order_g = (uint32_t *)(b->h_in + o_og);
+  b->h.tok = (uint16_t *)(b->h_in + o_tok);
+  b->h.res = (grim_subject_result *)b->h_out;            // set for real by the first fetch (the landing area grows on demand)
+  b->h.rows = (grim_row *)(b->h_out ? b->h_out + o_rows : nullptr);
+  return true;
 }
 
 // parameters, graph and the per-workgroup scratch layout of a batch (everything that is not a buffer)
@@ -543,45 +558,44 @@ static void batch_init_params(grim_batch *b, const grim_graph *g, const grim_par
   b->rows_used = 0;
 }
 
-grim_batch *engine_batch_create(grim_ctx *c, const grim_graph *g, const grim_params *p, const EngineCaps *caps) {
-  if (!c || !g || !p || !caps) return nullptr;
+grim_batch *engine_batch_create(grim_ctx *c, const grim_graph *g, const grim_params *p, uint64_t row_limit, const EnginePlan *plan) {
+  if (!c || !g || !p || !plan) return nullptr;
   use_device(c->device);
   if (p->top_n == 0 || p->top_n > GRIM_TOPCAP) { c->err = "grim_batch_upload: max_haplotypes_number_in_phase must be 1..128"; return nullptr; }
   if (p->n_ladder < 0 || p->n_ladder > GRIM_MAXLADDER) { c->err = "grim_batch_upload: epsilon ladder too long"; return nullptr; }
-  // a batch some earlier stream handed back (same population count: the prior buffers are sized in P x P units)
-  for (size_t k = 0; k < c->spare.size(); ++k) {
-    grim_batch *b = c->spare[k];
-    if (b->g_pops != g->d.P) continue;
-    c->spare.erase(c->spare.begin() + (long)k);
-    batch_init_params(b, g, p);
-    b->row_limit = caps->rows;
-    if (!batch_reserve(b, *caps)) {
+  if (row_limit > 0x7FFFFFF0ull) row_limit = 0x7FFFFFF0ull;
+  if (row_limit < 64) row_limit = 64;
+  grim_batch *b = nullptr;
+  if (!c->spare.empty()) {  // a batch some earlier stream handed back: its arenas and events are reused
+    b = c->spare.back();
+    c->spare.pop_back();
+    if (b->d_priors) hipFree(b->d_priors);  // sized in P x P units of the graph it served
+    if (b->h_priors) hipHostFree(b->h_priors);
+    b->d_priors = b->h_priors = nullptr;
+    b->priors_cap = b->priors_up = 0;
+  } else {
+    b = new grim_batch();
+    memset((void *)b, 0, sizeof(*b));
+    b->ctx = c;
+    bool ok = true;
+    if (hipHostMalloc((void **)&b->hstate, 8 * (GRIM_NCTR + 4)) != hipSuccess) {
+      b->hstate = nullptr;
+      ok = false;
+    }
+    for (int i = 0; i < 8 && ok; ++i) ok = hipEventCreate(&b->ev[i]) == hipSuccess;
+    if (!ok) {
       c->err = "grim_batch: device or pinned-host allocation failed";
       batch_destroy(b);
       return nullptr;
     }
-    batch_bind(b);
-    return b;
   }
-  grim_batch *b = new grim_batch();
-  memset((void *)b, 0, sizeof(*b));
-  b->ctx = c;
-  b->g_pops = g->d.P;
-  b->row_limit = caps->rows;
+  b->row_limit = row_limit;
   batch_init_params(b, g, p);
-  bool ok = dev_realloc(b->d_state, GRIM_NCTR + 4);
-  if (hipHostMalloc((void **)&b->hstate, 8 * (GRIM_NCTR + 4)) != hipSuccess) {
-    b->hstate = nullptr;
-    ok = false;
-  }
-  ok = ok && batch_reserve(b, *caps);
-  for (int i = 0; i < 8 && ok; ++i) ok = hipEventCreate(&b->ev[i]) == hipSuccess;
-  if (!ok) {
+  if (!batch_plan(b, *plan)) {
     c->err = "grim_batch: device or pinned-host allocation failed";
     batch_destroy(b);
     return nullptr;
   }
-  batch_bind(b);
   return b;
 }
 
@@ -603,15 +617,13 @@ void engine_batch_recycle(grim_batch *b) {
   c->spare.push_back(b);
 }
 
-int engine_batch_reserve(grim_batch *b, const EngineCaps *caps) {
-  if (!b || !caps) return -1;
+int engine_batch_plan(grim_batch *b, const EnginePlan *plan) {
+  if (!b || !plan) return -1;
   use_device(b->ctx->device);
-  if (caps->rows > b->row_limit) b->row_limit = caps->rows;
-  if (!batch_reserve(b, *caps)) {
+  if (!batch_plan(b, *plan)) {
     b->ctx->err = "grim_batch: device or pinned-host allocation failed while growing a batch";
     return -1;
   }
-  batch_bind(b);
   return 0;
 }
 
@@ -620,7 +632,6 @@ void engine_set_error(grim_ctx *c, const char *msg) {
   g_err = msg;
 }
 const EngineHost *engine_batch_host(grim_batch *b) { return b ? &b->h : nullptr; }
-EngineCaps engine_batch_caps(const grim_batch *b) { return b->cap; }
 uint64_t engine_bytes_moved(const grim_batch *, int dir) { return g_moved[dir ? 1 : 0]; }
 
 int engine_batch_load(grim_batch *b, const EngineLoad *ld) {
@@ -628,46 +639,54 @@ int engine_batch_load(grim_batch *b, const EngineLoad *ld) {
   grim_ctx *c = b->ctx;
   use_device(c->device);
   DevArgs &A = b->a;
-  if (ld->n_subj > b->cap.subj || ld->n_priors > b->cap.priors) {
-    c->err = "engine_batch_load: beyond the batch's capacity";
+  if (ld->n_subj > b->plan.n_subj || ld->tok_used > b->plan.tok_cap) {
+    c->err = "engine_batch_load: beyond what the batch was planned for";
     return -1;
   }
+  hipStream_t st = c->stream;
   const uint32_t P = b->g->d.P;
   const uint64_t PP = (uint64_t)P * P;
-  for (uint64_t k = 0; k < PP; ++k) b->h.priors[(uint64_t)ld->n_priors * PP + k] = 1.0;  // Plan B's second level (impute.py:1696-1700)
-  A.ones_prior = ld->n_priors;
-  hipStream_t st = c->stream;
-  auto up = [&](void *dst, const void *src, uint64_t bytes) {
-    if (!bytes) return true;
-    g_moved[0] += bytes;
-    return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st) == hipSuccess;
-  };
-  bool ok = up(b->d_subj, b->h.subj, sizeof(grim_subject) * (uint64_t)ld->n_subj) &&
-            up(b->d_priors, b->h.priors, 8ull * ((uint64_t)ld->n_priors + 1) * PP) &&
-            up(b->d_small, b->h.small, sizeof(SmallRec) * (uint64_t)ld->n_small) && up(b->d_os, b->h.order_s, 4ull * ld->n_small) &&
-            up(b->d_om, b->h.order_m, 4ull * ld->n_medium) && up(b->d_og, b->h.order_g, 4ull * ld->n_general);
-  for (uint32_t k = 0; k < ld->n_tok_spans && ok; ++k) {
-    if (ld->tok_span_off[k] + ld->tok_span_len[k] > b->cap.tok) ok = false;
-    else ok = up(b->d_tok + ld->tok_span_off[k], b->h.tok + ld->tok_span_off[k], 2ull * ld->tok_span_len[k]);
+  // prior matrices + one all-ones matrix for Plan B's second level (impute.py:1696-1700): only when the set changed
+  if (ld->priors && (ld->n_priors != b->priors_up || !b->d_priors)) {
+    if (ld->n_priors + 1 > b->priors_cap || !b->d_priors) {
+      const uint32_t want = ld->n_priors + 1 > 2 * b->priors_cap ? ld->n_priors + 1 : 2 * b->priors_cap;
+      if (b->d_priors) hipFree(b->d_priors);
+      if (b->h_priors) hipHostFree(b->h_priors);
+      b->d_priors = b->h_priors = nullptr;
+      if (hipMalloc((void **)&b->d_priors, 8 * (uint64_t)want * PP) != hipSuccess ||
+          hipHostMalloc((void **)&b->h_priors, 8 * (uint64_t)want * PP, hipHostMallocDefault) != hipSuccess) {
+        c->err = "engine_batch_load: allocation of the prior matrices failed";
+        return -1;
+      }
+      b->priors_cap = want;
+    }
+    if (ld->n_priors) memcpy(b->h_priors, ld->priors, 8 * (uint64_t)ld->n_priors * PP);
+    for (uint64_t k = 0; k < PP; ++k) b->h_priors[(uint64_t)ld->n_priors * PP + k] = 1.0;
+    HIPCHK(hipMemcpyAsync(b->d_priors, b->h_priors, 8 * ((uint64_t)ld->n_priors + 1) * PP, hipMemcpyHostToDevice, st), c, -1);
+    g_moved[0] += 8 * ((uint64_t)ld->n_priors + 1) * PP;
+    b->priors_up = ld->n_priors;
   }
-  if (!ok) {
-    c->err = "engine_batch_load: host-to-device copy failed";
-    return -1;
-  }
+  A.priors = b->d_priors;
+  A.ones_prior = b->priors_up;
   b->n_subj = ld->n_subj;
   b->n_small = ld->n_small;
   b->n_medium = ld->n_medium;
   b->n_general = ld->n_general;
   A.n_medium = ld->n_medium;
   A.n_work = ld->n_general;
-  A.next_cap = b->cap.subj;
+  // the run state travels with the input: clean counters and work heads, rows of the half-wave kernel's fixed region taken
+  unsigned long long *hs = (unsigned long long *)b->h_in;
+  memset(hs, 0, 8 * (GRIM_NCTR + 4));
+  ((uint32_t *)(hs + GRIM_NCTR))[1] = b->n_small * b->small_stride;
+  const uint64_t bytes = b->off_tok + 2 * ld->tok_used;
+  HIPCHK(hipMemcpyAsync(b->d_in, b->h_in, bytes, hipMemcpyHostToDevice, st), c, -1);
+  g_moved[0] += bytes;
   const uint32_t per_block = GRIM_WG / 32;
   b->n_small_waves = ((b->n_small + per_block - 1) / per_block) * (GRIM_WG / 64);
   uint32_t slots = (uint32_t)c->n_cu * 2;
   static const int env_slots = env_int("GRIM_SLOTS", 0);
   if (env_slots > 0) slots = (uint32_t)env_slots;
-  const uint32_t heavy = ld->n_subj;
-  if (slots > heavy) slots = heavy;
+  if (slots > ld->n_subj) slots = ld->n_subj;
   if (slots == 0) slots = 1;
   b->n_slots = slots;
   b->scratch_need = (uint64_t)A.lay.stride * slots;
@@ -678,9 +697,6 @@ int engine_batch_load(grim_batch *b, const EngineLoad *ld) {
   b->graph_state = 0;
   b->rows_used = 0;
   b->small_ctr_pending = false;
-  // heads and counters start clean; after that every run leaves them clean for the next one (grim_finish_kernel)
-  hipLaunchKernelGGL(grim_reset_kernel, dim3(1), dim3(GRIM_WG), 0, st, A.counters, A.queue, b->n_small * b->small_stride);
-  HIPCHK(hipGetLastError(), c, -1);
   return 0;
 }
 
@@ -712,12 +728,11 @@ extern "C" grim_batch *grim_batch_upload(grim_ctx *c, const grim_graph *g, const
   const char *env_rows = getenv("GRIM_ROW_CAP");
   if (env_rows) want = strtoull(env_rows, nullptr, 10);
   if (want > 0x7FFFFFF0ull) want = 0x7FFFFFF0ull;
-  EngineCaps caps{d->n_subjects ? d->n_subjects : 1u, d->n_tokens ? d->n_tokens : 1ull, d->n_priors ? d->n_priors : 1u, want};
-  grim_batch *b = engine_batch_create(c, g, p, &caps);
+  EnginePlan plan{d->n_subjects ? d->n_subjects : 1u, d->n_tokens ? d->n_tokens : 1ull};
+  grim_batch *b = engine_batch_create(c, g, p, want, &plan);
   if (!b) return nullptr;
   if (d->n_subjects) memcpy(b->h.subj, d->subjects, sizeof(grim_subject) * (size_t)d->n_subjects);
   if (d->n_tokens) memcpy(b->h.tok, d->tokens, 2 * (size_t)d->n_tokens);
-  if (d->n_priors) memcpy(b->h.priors, d->priors, 8 * (size_t)d->n_priors * P * P);
   for (size_t k = 0; k < os.size(); ++k) {
     const grim_subject &sj = d->subjects[os[k]];
     grim_small_rec(sj, d->tokens + sj.tok_off, os[k], b->h.small[k]);
@@ -725,8 +740,14 @@ extern "C" grim_batch *grim_batch_upload(grim_ctx *c, const grim_graph *g, const
   }
   if (!om.empty()) memcpy(b->h.order_m, om.data(), 4 * om.size());
   if (!og.empty()) memcpy(b->h.order_g, og.data(), 4 * og.size());
-  const uint64_t span_off = 0, span_len = d->n_tokens;
-  EngineLoad ld{d->n_subjects, d->n_priors, (uint32_t)os.size(), (uint32_t)om.size(), (uint32_t)og.size(), 1, &span_off, &span_len};
+  std::vector<double> one_prior;
+  const double *pri = d->priors;
+  if (!d->n_priors) {  // no matrix given: subjects index matrix 0
+    one_prior.assign((size_t)P * P, 1.0);
+    pri = one_prior.data();
+  }
+  EngineLoad ld{d->n_subjects, (uint32_t)os.size(), (uint32_t)om.size(), (uint32_t)og.size(), d->n_tokens,
+                d->n_priors ? d->n_priors : 1u, pri};
   if (engine_batch_load(b, &ld) != 0 || hipStreamSynchronize(c->stream) != hipSuccess) {
     if (c->err.empty()) c->err = "grim_batch_upload: copy failed";
     grim_batch_free(b);
@@ -942,28 +963,39 @@ int engine_batch_fetch(grim_batch *b, uint32_t res_lo, uint32_t res_hi, grim_row
   grim_ctx *c = b->ctx;
   use_device(c->device);
   if (res_hi > b->n_subj) res_hi = b->n_subj;
-  if (res_hi > res_lo) {
-    HIPCHK(hipMemcpyAsync(b->h.res + res_lo, b->d_res + res_lo, sizeof(grim_subject_result) * (uint64_t)(res_hi - res_lo),
-                          hipMemcpyDeviceToHost, c->stream), c, -1);
-    g_moved[1] += sizeof(grim_subject_result) * (uint64_t)(res_hi - res_lo);
-  }
-  if (b->rows_used) {
-    if (!rows_dst) {
-      if (b->rows_used > b->h_rows_cap) {
-        uint64_t n = b->h_rows_cap ? b->h_rows_cap : 1024;
-        while (n < b->rows_used) n *= 2;
-        if (n > b->cap.rows) n = b->cap.rows;
-        if (!pin_realloc(b->h.rows, n)) {
-          b->h_rows_cap = 0;
-          c->err = "engine_batch_fetch: pinned allocation failed";
-          return -1;
-        }
-        b->h_rows_cap = n;
-      }
-      rows_dst = b->h.rows;
+  // the pinned landing area mirrors the out arena as far as it is used; it grows on demand
+  const uint64_t need = b->off_rows + sizeof(grim_row) * (uint64_t)(rows_dst ? 0 : b->rows_used);
+  if (need > b->h_out_cap || !b->h_out) {
+    uint64_t n = b->h_out_cap ? b->h_out_cap : (1u << 20);
+    while (n < need) n *= 2;
+    if (n > b->out_cap) n = b->out_cap;
+    if (n < need) n = need;
+    if (!pin_realloc(b->h_out, n)) {
+      b->h_out_cap = 0;
+      c->err = "engine_batch_fetch: pinned allocation failed";
+      return -1;
     }
-    HIPCHK(hipMemcpyAsync(rows_dst, b->d_rows, sizeof(grim_row) * (uint64_t)b->rows_used, hipMemcpyDeviceToHost, c->stream), c, -1);
-    g_moved[1] += sizeof(grim_row) * (uint64_t)b->rows_used;
+    b->h_out_cap = n;
+  }
+  b->h.res = (grim_subject_result *)b->h_out;
+  b->h.rows = (grim_row *)(b->h_out + b->off_rows);
+  const bool whole = res_lo == 0 && res_hi == b->n_subj && !rows_dst;
+  if (whole && b->off_rows - sizeof(grim_subject_result) * (uint64_t)b->n_subj < 4096) {
+    // headers and rows are (nearly) back to back: one copy
+    const uint64_t bytes = b->rows_used ? b->off_rows + sizeof(grim_row) * (uint64_t)b->rows_used : sizeof(grim_subject_result) * (uint64_t)b->n_subj;
+    if (bytes) HIPCHK(hipMemcpyAsync(b->h_out, b->d_out, bytes, hipMemcpyDeviceToHost, c->stream), c, -1);
+    g_moved[1] += bytes;
+  } else {
+    if (res_hi > res_lo) {
+      const uint64_t o = sizeof(grim_subject_result) * (uint64_t)res_lo, n = sizeof(grim_subject_result) * (uint64_t)(res_hi - res_lo);
+      HIPCHK(hipMemcpyAsync(b->h_out + o, b->d_out + o, n, hipMemcpyDeviceToHost, c->stream), c, -1);
+      g_moved[1] += n;
+    }
+    if (b->rows_used) {
+      void *dst = rows_dst ? (void *)rows_dst : (void *)(b->h_out + b->off_rows);
+      HIPCHK(hipMemcpyAsync(dst, b->d_out + b->off_rows, sizeof(grim_row) * (uint64_t)b->rows_used, hipMemcpyDeviceToHost, c->stream), c, -1);
+      g_moved[1] += sizeof(grim_row) * (uint64_t)b->rows_used;
+    }
   }
   HIPCHK(hipStreamSynchronize(c->stream), c, -1);
   return 0;
@@ -973,8 +1005,8 @@ extern "C" int grim_batch_results(grim_batch *b, grim_subject_result *res, grim_
   if (!b) return -1;
   grim_ctx *c = b->ctx;
   use_device(c->device);
-  if (b->n_subj) HIPCHK(hipMemcpy(res, b->d_res, sizeof(grim_subject_result) * (size_t)b->n_subj, hipMemcpyDeviceToHost), c, -1);
-  if (b->rows_used) HIPCHK(hipMemcpy(rows, b->d_rows, sizeof(grim_row) * (size_t)b->rows_used, hipMemcpyDeviceToHost), c, -1);
+  if (b->n_subj) HIPCHK(hipMemcpy(res, b->a.res, sizeof(grim_subject_result) * (size_t)b->n_subj, hipMemcpyDeviceToHost), c, -1);
+  if (b->rows_used) HIPCHK(hipMemcpy(rows, b->a.rows, sizeof(grim_row) * (size_t)b->rows_used, hipMemcpyDeviceToHost), c, -1);
   return 0;
 }
 
@@ -987,11 +1019,10 @@ static void batch_destroy(grim_batch *b) {
   for (int i = 0; i < 8; ++i)
     if (b->ev[i]) hipEventDestroy(b->ev[i]);
   if (b->gexec) hipGraphExecDestroy(b->gexec);
-  void *dev[] = {b->d_subj, b->d_tok, b->d_priors, b->d_small, b->d_os, b->d_om, b->d_og, b->d_bail, b->d_next, b->d_small_ctr,
-                 b->d_res, b->d_rows, b->d_state};
+  void *dev[] = {b->d_in, b->d_work, b->d_out, b->d_priors};
   for (void *p : dev)
     if (p) hipFree(p);
-  void *pin[] = {b->h.subj, b->h.tok, b->h.priors, b->h.small, b->h.order_s, b->h.order_m, b->h.order_g, b->h.res, b->h.rows, b->hstate};
+  void *pin[] = {b->h_in, b->h_out, b->h_priors, b->hstate};
   for (void *p : pin)
     if (p) hipHostFree(p);
   delete b;

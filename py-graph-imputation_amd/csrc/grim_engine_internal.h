@@ -1,49 +1,48 @@
 // grim_engine_internal.h -- what the streaming pipeline (grim_stream.cpp) uses of the engine (grim_engine.hip) below
-// the C-ABI: batches with CAPACITY (device buffers + pinned staging allocated once, reloaded chunk after chunk).
+// the C-ABI: batches whose device and pinned-host arenas are allocated once and laid out again for every chunk, so that a
+// chunk's whole input goes up in ONE copy and its results come back in ONE copy.
 #pragma once
 #include <stdint.h>
 
 #include "../../include/grim_hip.h"
 #include "grim_layout.h"
 
-struct EngineCaps {
-  uint32_t subj;    // subject records (and result headers)
-  uint64_t tok;     // u16 tokens
-  uint32_t priors;  // prior matrices (the engine adds the all-ones matrix itself)
-  uint64_t rows;    // output row pool
+struct EnginePlan {   // what the next load holds at most
+  uint32_t n_subj;    // subject records (= result headers)
+  uint64_t tok_cap;   // u16 tokens
 };
 
 struct EngineHost {  // pinned host memory of a batch: inputs are written here, results land here
   grim_subject *subj;
   uint16_t *tok;
-  double *priors;
   SmallRec *small;
   uint32_t *order_s, *order_m, *order_g;
-  grim_subject_result *res;
+  grim_subject_result *res;  // valid after engine_batch_fetch
   grim_row *rows;
 };
 
 struct EngineLoad {
-  uint32_t n_subj;     // subject records [0, n_subj) are copied (records outside every list are never read)
-  uint32_t n_priors;
+  uint32_t n_subj;                        // subject records [0, n_subj) (records outside every list are never read)
   uint32_t n_small, n_medium, n_general;  // entries of order_s (+ small), order_m, order_g
-  uint32_t n_tok_spans;                   // token ranges in use: [off, off+len) in u16 units
-  const uint64_t *tok_span_off, *tok_span_len;
+  uint64_t tok_used;                      // tokens [0, tok_used) are copied
+  uint32_t n_priors;                      // prior matrices [n_priors][P*P] at `priors` (host memory, copied when the
+  const double *priors;                   // count differs from what the batch holds; the set only ever grows)
 };
 
-grim_batch *engine_batch_create(grim_ctx *ctx, const grim_graph *g, const grim_params *p, const EngineCaps *caps);
-int engine_batch_reserve(grim_batch *b, const EngineCaps *caps);  // grow (contents are lost)
+// row_limit: rows one run may produce (the row pool); plan: first layout
+grim_batch *engine_batch_create(grim_ctx *ctx, const grim_graph *g, const grim_params *p, uint64_t row_limit, const EnginePlan *plan);
+// lay the arenas out for the next load (grows them when needed); engine_batch_host pointers change
+int engine_batch_plan(grim_batch *b, const EnginePlan *plan);
 const EngineHost *engine_batch_host(grim_batch *b);
-EngineCaps engine_batch_caps(const grim_batch *b);
 uint32_t engine_small_stride(const grim_params *p);
 // one subject's worst case in output rows (all four tables full)
 uint64_t engine_rows_per_subject(const grim_params *p, uint32_t n_pops);
-// H2D of the used parts of the staging area (asynchronous, on the context's stream) and a clean run state
+// one H2D copy of the input arena as far as it is used (asynchronous, on the context's stream), clean run state included
 int engine_batch_load(grim_batch *b, const EngineLoad *ld);
-// D2H of result headers [res_lo, res_hi) and rows [0, rows_used) into the pinned landing area (rows) or `rows_dst`
-// when given; waits for the copies
+// D2H of result headers [res_lo, res_hi) and rows [0, rows_used) into the pinned landing area (rows: or `rows_dst`
+// when given); waits for the copies
 int engine_batch_fetch(grim_batch *b, uint32_t res_lo, uint32_t res_hi, grim_row *rows_dst);
-uint64_t engine_bytes_moved(const grim_batch *b, int dir);  // 0 = H2D, 1 = D2H since creation
+uint64_t engine_bytes_moved(const grim_batch *b, int dir);  // 0 = H2D, 1 = D2H since the library was loaded
 void engine_set_error(grim_ctx *ctx, const char *msg);
-// hand a batch back to its context: the next engine_batch_create on that context reuses its buffers
+// hand a batch back to its context: the next engine_batch_create on that context reuses its arenas
 void engine_batch_recycle(grim_batch *b);

@@ -242,27 +242,22 @@ static int device_part(grim_stream *s, Chunk *c, uint32_t lo, uint32_t hi, bool 
   uint32_t ng = 0;
   for (uint32_t si : og_sorted)
     if (si >= lo && si < hi) H->order_g[ng++] = si;
-  std::vector<uint64_t> so, sl;
+  uint64_t tok_used = 0;
   for (uint32_t r = 0; r < c->n_ranges; ++r)
-    if (c->tr[r].n_tok && c->range_first_line[r] < hi && c->range_first_line[r + 1] > lo) {
-      so.push_back(c->slab_off[r]);
-      sl.push_back(c->tr[r].n_tok);
-    }
-  uint32_t n_priors;
+    if (c->tr[r].n_tok && c->range_first_line[r] < hi && c->range_first_line[r + 1] > lo) tok_used = c->slab_off[r] + c->tr[r].n_tok;
+  int lrc;
   {
+    // the race table only grows: a batch that holds fewer matrices than the table has gets all of them again
     std::lock_guard<std::mutex> lk(s->races.mu);
-    n_priors = s->races.n;
-    EngineCaps cp = engine_batch_caps(b);
-    if (n_priors > cp.priors) {
-      cp.priors = n_priors * 2;
-      cp.rows = 0;
-      if (engine_batch_reserve(b, &cp) != 0) return -1;
-      H = engine_batch_host(b);
+    EngineLoad ld{c->n_lines, (uint32_t)(s1 - s0), (uint32_t)(m1 - m0), ng, tok_used, s->races.n, s->races.mats.data()};
+    static const double one = 1.0;
+    if (!s->races.n) {  // no line had two parsable fields: nothing indexes a matrix, the engine still wants one
+      ld.n_priors = 0;
+      ld.priors = &one;
     }
-    if (n_priors) memcpy(H->priors, s->races.mats.data(), 8 * s->races.mats.size());
+    lrc = engine_batch_load(b, &ld);
   }
-  EngineLoad ld{c->n_lines, n_priors, (uint32_t)(s1 - s0), (uint32_t)(m1 - m0), ng, (uint32_t)so.size(), so.data(), sl.data()};
-  if (engine_batch_load(b, &ld) != 0) return -1;
+  if (lrc != 0) return -1;
   const int rc = grim_batch_run(b);
   if (getenv("GRIM_DEBUG_STREAM"))
     fprintf(stderr, "grim stream: chunk %llu lines [%u,%u) small %zu medium %zu general %u -> rc %d, rows %u (pool %llu)\n",
@@ -530,16 +525,11 @@ static int dispatch(grim_stream *s, Chunk *c) {
   if (c->tr.size() < R) c->tr.resize(R);
   while (c->fr.size() < R) c->fr.emplace_back(new FmtRange());
   if (c->file_off.size() < R) c->file_off.resize(R);
-  EngineCaps cp = engine_batch_caps(c->batch);
-  if (n > cp.subj || tok_total > cp.tok) {
-    if (n > cp.subj) cp.subj = n;
-    if (tok_total > cp.tok) cp.tok = tok_total + tok_total / 4;
-    cp.rows = 0;  // the row pool stays as it is (a recycled batch may own more rows than this stream may use)
-    if (engine_batch_reserve(c->batch, &cp) != 0) {
-      std::lock_guard<std::mutex> lk(s->mu);
-      s->fail(std::string("growing a chunk's buffers failed: ") + grim_last_error(s->ctx));
-      return -1;
-    }
+  EnginePlan pl{n, tok_total};
+  if (engine_batch_plan(c->batch, &pl) != 0) {
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->fail(std::string("laying out a chunk's buffers failed: ") + grim_last_error(s->ctx));
+    return -1;
   }
   s->next_line += n;
   std::lock_guard<std::mutex> lk(s->mu);
@@ -814,11 +804,11 @@ extern "C" grim_stream *grim_stream_open(grim_ctx *ctx, const grim_graph *g, con
         return nullptr;
       }
     }
-  EngineCaps caps{s->chunk_lines, (uint64_t)s->chunk_lines * 48, 64, rows};
+  EnginePlan plan0{s->chunk_lines, (uint64_t)s->chunk_lines * 48};
   for (uint32_t i = 0; i < s->depth; ++i) {
     std::unique_ptr<Chunk> c(new Chunk());
     c->slot_no = (int)i;
-    c->batch = engine_batch_create(ctx, g, prm, &caps);
+    c->batch = engine_batch_create(ctx, g, prm, rows, &plan0);
     if (!c->batch) {
       for (auto &o : s->chunks) grim_batch_free(o->batch);
       for (int k = 0; k < 6; ++k)
