@@ -231,8 +231,9 @@ def main():
     ctr[3] = int(res["n_rows"].sum())  # rows actually produced
     # B_subj = B_in + sum_sides(16 q + 4 nbr + 8 P c) + 24 B_rows ; B_in = 4 + 2/token + 4
     algo_bytes = (8 * len(subj) + 2 * n_tok) + 16 * ctr[0] + 4 * ctr[1] + 8 * P * ctr[2] + 24 * ctr[3]
-    names = ("grim_plan_a_small_kernel", "grim_plan_a_kernel", "grim_plan_b_kernel", "grim_plan_a_medium_kernel")
-    per_kernel = [batch.kernel_ms(0x10 | w) for w in (3, 4, 2, 5)]  # means over the timed runs
+    names = ("grim_plan_a_small_kernel", "grim_plan_a_kernel", "grim_plan_b_kernel", "grim_plan_a_medium_kernel",
+             "grim_tables_wave_kernel+grim_tables_wg_kernel")
+    per_kernel = [batch.kernel_ms(0x10 | w) for w in (3, 4, 2, 5, 6)]  # means over the timed runs
     dom = max(range(len(per_kernel)), key=lambda i: per_kernel[i])
     avg_ms = per_kernel[dom]
     all_ms = sum(per_kernel)

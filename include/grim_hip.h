@@ -185,8 +185,8 @@ int grim_batch_run_repeat(grim_batch *b, uint32_t n);
  * 22 us without, 29 us with the events. */
 int grim_batch_set_timing(grim_batch *b, int on);
 /* device time of the last grim_batch_run in timing mode (0 otherwise):
- * which = 0 all kernels, 1 the three stage-1 kernels, 2 plan-B/C kernel, 3 half-wave kernel, 4 general plan-A
- *         kernel, 5 one-wave kernel (each from the kernel's own start/stop events);
+ * which = 0 all kernels, 1 half-wave + one-wave + general kernel, 2 plan-B/C kernel, 3 half-wave kernel, 4 general plan-A
+ *         kernel, 5 one-wave kernel, 6 the table kernels (each from the kernels' own start/stop events);
  * which | 0x10 = the mean of that figure over all runs since timing was switched on */
 double grim_batch_kernel_ms(const grim_batch *b, int which);
 /* algorithmic byte counters of the last run: [0] probes, [1] CSR neighbour ids,
@@ -301,7 +301,7 @@ typedef struct {
   double wall_s;                                     /* open -> finish */
   double tokenize_cpu_s, format_cpu_s, write_cpu_s;  /* summed over the worker threads */
   double device_s;                                   /* device thread busy: copies + kernels + waits */
-  double kernel_ms[6];                               /* sums of grim_batch_kernel_ms(which) over the chunks (timing mode) */
+  double kernel_ms[7];                               /* sums of grim_batch_kernel_ms(which) over the chunks (timing mode) */
   uint64_t counters[4];                              /* sums of grim_batch_counters */
   uint64_t text_bytes[7];
   uint64_t bytes_h2d, bytes_d2h;

@@ -10,6 +10,12 @@
 #include "grim_layout.h"
 
 #define GRIM_WG 256
+#ifndef GRIM_WG_PER_CU
+#define GRIM_WG_PER_CU 3  // resident workgroups per CU of the general kernel (LDS: 51 KB each)
+#endif
+#ifndef GRIM_PLANB_WG_PER_CU
+#define GRIM_PLANB_WG_PER_CU 2  // the Plan-B kernel needs its 256 VGPRs (measured: 3 per CU spill and run 8 % slower)
+#endif
 #define GRIM_NWAVE 4
 #define GRIM_NONE 0xFFFFFFFFu
 #define GRIM_VALID 0x8000000000000000ull
@@ -72,7 +78,8 @@ struct DevArgs {
   uint32_t n_work;
   uint32_t *queue;        // [0] general work counter [1] row head [2] plan-B list length [3] plan-B work counter
                           // [4] one-wave kernel work counter [5] its hand-over count [6] heavy plan-B subjects
-                          // [7] its heavier hand-overs
+                          // [7] its heavier hand-overs [8] pair pool head [9] / [10] work items of the one-wave /
+                          // workgroup table kernel [11] / [12] their work counters  (GRIM_NQ words)
   grim_subject_result *res;
   grim_row *rows;
   uint32_t *row_head;
@@ -88,7 +95,27 @@ struct DevArgs {
   uint32_t *next_list;           // subjects handed to the next kernel (plan B): light ones from the front
   uint32_t *next_count;          // (count queue[2]), heavy ones from the back (count queue[6]) -- heavy first
   uint32_t next_cap;             // entries in next_list
+  uint32_t flags;                // diagnostic switches (environment, read when the batch is created): GRIM_F_*
+  PairRec *ppool;                // accepted pairs of subjects whose tables the table kernels build (grim_tables.h)
+  uint32_t ppool_cap;            // records
+  TabWork *t1_list, *t2_list;    // their work items
+  // the three-kernel path of the bigger items: per-item state, bucket / cell starts, work units, pairs dealt into
+  // buckets (psort: [3][ppool_cap], genotype / haplotype pair / population-cell order), groups found ([2][ppool_cap]),
+  // probabilities in cell order, cell sums
+  TabAux *taux;
+  uint32_t *tboff;
+  CellRec *tcell;
+  uint32_t tboff_cap;
+  TabUnit *tunits;
+  uint32_t tunits_cap;
+  uint32_t tstride;              // records per plane of psort / pgrp (the pool's allocated size)
+  uint32_t *psort;
+  GrpRec *pgrp;
+  double *pprob;
 };
+#define GRIM_NQ 24               // u32 words of `queue` (the run state block is counters + queue):
+                                 // [13] bucket-start slots used [14] work units [15] their work counter
+                                 // [16] / [17] work counters of the split / merge kernel
 
 #ifndef GRIM_HEAVY_LOCI
 #define GRIM_HEAVY_LOCI 3
@@ -103,8 +130,13 @@ __device__ __forceinline__ void push_next(const DevArgs &A, uint32_t si, bool he
 }
 
 // ---- optional stage timers (diagnostic build only: hipcc -DGRIM_STAMPS; never in the shipped .so) ----
-#define GRIM_NCTR (8 + 4 * 64 + 16)
 #define GRIM_STAMP_BASE (8 + 4 * 64)
+#ifdef GRIM_STAMPS
+#define GRIM_HIST_BASE (GRIM_STAMP_BASE + 16)  // diagnostic build: log2 histograms, 4 x 24 buckets
+#define GRIM_NCTR (8 + 4 * 64 + 16 + 96)
+#else
+#define GRIM_NCTR (8 + 4 * 64 + 16)
+#endif
 #ifdef GRIM_STAMPS
 #define STAMP_BEGIN() unsigned long long _t0 = wall_clock64()
 #define STAMP(k)                                                           \
@@ -116,9 +148,20 @@ __device__ __forceinline__ void push_next(const DevArgs &A, uint32_t si, bool he
       _t0 = _t1;                                                           \
     }                                                                      \
   } while (0)
+// HIST(h, v, w): bucket floor(log2(v+1)) of histogram h (0..3) += w
+#define HIST(h, v, w)                                                                                  \
+  do {                                                                                                 \
+    if (threadIdx.x == 0) {                                                                            \
+      unsigned int _b = 31u - __clz((unsigned int)(v) + 1u);                                           \
+      atomicAdd(&A.counters[GRIM_HIST_BASE + 24 * (h) + (_b < 23u ? _b : 23u)], (unsigned long long)(w)); \
+    }                                                                                                  \
+  } while (0)
+#define STAMP_NOW() wall_clock64()
 #else
 #define STAMP_BEGIN()
 #define STAMP(k)
+#define HIST(h, v, w)
+#define STAMP_NOW() 0ull
 #endif
 
 // ---- small helpers ------------------------------------------------------------------------------

@@ -16,6 +16,7 @@
 #include "grim_plan_b.h"
 #include "grim_small.h"
 #include "grim_medium.h"
+#include "grim_tables.h"
 #include "grim_engine_internal.h"
 
 // =================================================================================================
@@ -23,7 +24,7 @@
 // sides (one wave per side, wave64 ballots/prefix scans, LDS-staged running top-K); the whole
 // workgroup then scores haplotype pairs, dedups, sums and ranks.
 // =================================================================================================
-__global__ __launch_bounds__(GRIM_WG, 2) void grim_plan_a_kernel(DevArgs A) {
+__global__ __launch_bounds__(GRIM_WG, GRIM_WG_PER_CU) void grim_plan_a_kernel(DevArgs A) {
   __shared__ WgShared sh;
   __shared__ WaveTop wt[GRIM_NWAVE];
   const int tid = threadIdx.x;
@@ -33,6 +34,7 @@ __global__ __launch_bounds__(GRIM_WG, 2) void grim_plan_a_kernel(DevArgs A) {
   // taken first, then this kernel's own subjects (heaviest first), then the light hand-overs
   const uint32_t n_bail = A.bail_list ? A.queue[5] : 0, n_bail_heavy = A.bail_list ? A.queue[7] : 0;
   if (tid < GRIM_NWAVE * 4) ((unsigned long long *)sh.wctr)[tid] = 0;
+  wg_arena(sh, wt);
   __syncthreads();
   for (;;) {
     if (tid == 0) sh.bc[3] = atomicAdd(A.queue, 1u);
@@ -54,6 +56,8 @@ __global__ __launch_bounds__(GRIM_WG, 2) void grim_plan_a_kernel(DevArgs A) {
     if (tid < (int)(sizeof(grim_subject_result) / 4)) ((uint32_t *)&sh.out)[tid] = 0;
     __syncthreads();
     STAMP_BEGIN();
+    const unsigned long long t_subject = STAMP_NOW();
+    (void)t_subject;
     enumerate_phases(sh);
     const double *prior = A.priors + (uint64_t)sh.subj.prior_idx * P * P;
     const int nph = sh.nph;
@@ -71,6 +75,8 @@ __global__ __launch_bounds__(GRIM_WG, 2) void grim_plan_a_kernel(DevArgs A) {
       apply_stage(A, sh, stage + 1);
     }
     STAMP(8);
+    const unsigned long long t_sides = STAMP_NOW();
+    (void)t_sides;
     uint8_t status = GRIM_ST_MISS, reason = 0, plan = 'a';
     if (!fits) {
       status = GRIM_ST_UNSUPPORTED;  // more than GRIM_RTOK_CAP/3 alleles in one GL string
@@ -96,8 +102,10 @@ __global__ __launch_bounds__(GRIM_WG, 2) void grim_plan_a_kernel(DevArgs A) {
         nU = pair_pass(A, sh, S, prior, np, eps, true, &mx);
         STAMP(11);
       }
+      const unsigned long long t_pairs = STAMP_NOW();
+      (void)t_pairs;
       if (nU > 0) {
-        emit_tables(A, sh, S, nU, sh.out);
+        emit_tables(A, sh, S, nU, sh.out, si);
         STAMP(12);
         status = GRIM_ST_OK;
         if (tid == 0) sh.out.max_prob = mx;
@@ -133,7 +141,7 @@ __global__ __launch_bounds__(GRIM_WG, 2) void grim_plan_a_kernel(DevArgs A) {
 // zero the counters and work heads of a batch (one launch instead of several memsets)
 __global__ void grim_reset_kernel(unsigned long long *counters, uint32_t *queue, uint32_t row_head0) {
   for (int i = threadIdx.x; i < GRIM_NCTR; i += blockDim.x) counters[i] = 0;
-  if (threadIdx.x < 8) queue[threadIdx.x] = threadIdx.x == 1 ? row_head0 : 0u;
+  if (threadIdx.x < GRIM_NQ) queue[threadIdx.x] = threadIdx.x == 1 ? row_head0 : 0u;
 }
 
 // End of a stage: the state block (counters, then the eight queue words) goes straight to the batch's pinned
@@ -143,11 +151,15 @@ __global__ void grim_finish_kernel(unsigned long long *state, unsigned long long
   __shared__ uint32_t pending;
   const uint32_t *queue = (const uint32_t *)(state + GRIM_NCTR);
   if (threadIdx.x == 0) pending = after_plan_b ? 0u : queue[2] + queue[6];
-  for (int i = threadIdx.x; i < GRIM_NCTR + 4; i += blockDim.x) host_state[i] = state[i];
+  for (int i = threadIdx.x; i < GRIM_NCTR + GRIM_NQ / 2; i += blockDim.x) host_state[i] = state[i];
   __syncthreads();
-  if (pending) return;
+  if (pending) {
+    // Plan B follows: its table kernels continue behind the work units of this stage
+    if (threadIdx.x == 0) ((uint32_t *)(state + GRIM_NCTR))[15] = ((uint32_t *)(state + GRIM_NCTR))[14];
+    return;
+  }
   for (int i = threadIdx.x; i < GRIM_NCTR; i += blockDim.x) state[i] = 0;
-  if (threadIdx.x < 8) ((uint32_t *)(state + GRIM_NCTR))[threadIdx.x] = threadIdx.x == 1 ? row_head0 : 0u;
+  if (threadIdx.x < GRIM_NQ) ((uint32_t *)(state + GRIM_NCTR))[threadIdx.x] = threadIdx.x == 1 ? row_head0 : 0u;
 }
 
 // =================================================================================================
@@ -187,6 +199,8 @@ struct grim_batch {
   uint8_t *d_in, *h_in, *d_work, *d_out, *h_out;
   uint64_t in_cap, work_cap, out_cap, h_out_cap;
   double *d_priors, *h_priors;  // prior matrices: their own small buffers, uploaded only when the set changes
+  uint8_t *d_pool;              // the table kernels' arena (device only; grows at load time): pair records, per-item state,
+  uint64_t pool_cap, pool_bytes; // bucket starts, cells, work units, bucket order, groups, probabilities in cell order
   uint32_t priors_cap, priors_up;
   uint64_t row_limit;   // rows a run may use
   EnginePlan plan;      // what the arenas are laid out for
@@ -201,12 +215,13 @@ struct grim_batch {
   uint32_t n_medium;
   uint32_t n_small, n_general, small_stride;
   uint64_t scratch_need;  // bytes of per-workgroup scratch this batch's runs need (bound at run time)
-  hipEvent_t ev[8];  // timing mode, kernel start/stop: [3]/[5] half-wave, [0]/[1] one-wave, [6]/[7] general, [4]/[2] Plan B
+  hipEvent_t ev[12];  // timing mode, kernel start/stop: [3]/[5] half-wave, [0]/[1] one-wave, [6]/[7] general, [4]/[2] Plan B,
+                      // [8]/[9] table kernels of stage 1, [10]/[11] table kernels after Plan B
   bool timing;       // GRIM_TIMING=1 or grim_batch_set_timing: direct launches with per-kernel events instead of the graph replay
   hipGraphExec_t gexec;
   int graph_state;  // 0 not tried, 1 captured, -1 direct launches
-  float ms_a, ms_b, ms_s, ms_g, ms_m;
-  double acc_ms[6];   // sums over the timed runs since timing was switched on (index = `which`)
+  float ms_a, ms_b, ms_s, ms_g, ms_m, ms_t;
+  double acc_ms[7];   // sums over the timed runs since timing was switched on (index = `which`)
   uint32_t n_timed;
   uint32_t rows_used;
   unsigned long long counters[8];
@@ -439,7 +454,7 @@ static bool batch_plan(grim_batch *b, const EnginePlan &pl) {
   const uint64_t n = pl.n_subj ? pl.n_subj : 1;
   uint64_t o = 0;
   auto take = [&](uint64_t bytes) { uint64_t r = o; o = align256(o + bytes); return r; };
-  const uint64_t o_state = take(8ull * (GRIM_NCTR + 4));
+  const uint64_t o_state = take(8ull * (GRIM_NCTR + GRIM_NQ / 2));
   const uint64_t o_subj = take(sizeof(grim_subject) * n);
   const uint64_t o_small = take(sizeof(SmallRec) * n);
   const uint64_t o_os = take(4 * n), o_om = take(4 * n), o_og = take(4 * n);
@@ -448,6 +463,7 @@ static bool batch_plan(grim_batch *b, const EnginePlan &pl) {
   o = 0;
   const uint64_t small_waves = ((n + GRIM_WG / 32 - 1) / (GRIM_WG / 32)) * (GRIM_WG / 64);
   const uint64_t w_bail = take(4 * n), w_next = take(4 * n), w_ctr = take(4 * (2 * small_waves + 2));
+  const uint64_t w_t1 = take(sizeof(TabWork) * 2 * n), w_t2 = take(sizeof(TabWork) * 2 * n);  // a subject queues at most two items
   const uint64_t work_bytes = o;
   o = 0;
   const uint64_t o_res = take(sizeof(grim_subject_result) * n);
@@ -487,6 +503,8 @@ static bool batch_plan(grim_batch *b, const EnginePlan &pl) {
   A.bail_list = (uint32_t *)(b->d_work + w_bail);
   A.next_list = (uint32_t *)(b->d_work + w_next);
   A.small_ctr = (uint32_t *)(b->d_work + w_ctr);
+  A.t1_list = (TabWork *)(b->d_work + w_t1);
+  A.t2_list = (TabWork *)(b->d_work + w_t2);
   A.res = (grim_subject_result *)(b->d_out + o_res);
   A.rows = (grim_row *)(b->d_out + o_rows);
   A.row_cap = (uint32_t)b->row_limit;
@@ -552,6 +570,7 @@ static void batch_init_params(grim_batch *b, const grim_graph *g, const grim_par
   L.rtok = take(2ull * GRIM_RTOK_CAP);
   L.stride = align256(o);
   b->timing = env_int("GRIM_TIMING", 0) != 0;
+  A.flags = env_int("GRIM_TABLES_HBM", 0) ? GRIM_F_TABLES_HBM : 0u;
   memset(b->acc_ms, 0, sizeof(b->acc_ms));
   b->n_timed = 0;
   b->n_subj = b->n_small = b->n_medium = b->n_general = 0;
@@ -578,11 +597,11 @@ grim_batch *engine_batch_create(grim_ctx *c, const grim_graph *g, const grim_par
     memset((void *)b, 0, sizeof(*b));
     b->ctx = c;
     bool ok = true;
-    if (hipHostMalloc((void **)&b->hstate, 8 * (GRIM_NCTR + 4)) != hipSuccess) {
+    if (hipHostMalloc((void **)&b->hstate, 8 * (GRIM_NCTR + GRIM_NQ / 2)) != hipSuccess) {
       b->hstate = nullptr;
       ok = false;
     }
-    for (int i = 0; i < 8 && ok; ++i) ok = hipEventCreate(&b->ev[i]) == hipSuccess;
+    for (int i = 0; i < 12 && ok; ++i) ok = hipEventCreate(&b->ev[i]) == hipSuccess;
     if (!ok) {
       c->err = "grim_batch: device or pinned-host allocation failed";
       batch_destroy(b);
@@ -676,14 +695,55 @@ int engine_batch_load(grim_batch *b, const EngineLoad *ld) {
   A.n_work = ld->n_general;
   // the run state travels with the input: clean counters and work heads, rows of the half-wave kernel's fixed region taken
   unsigned long long *hs = (unsigned long long *)b->h_in;
-  memset(hs, 0, 8 * (GRIM_NCTR + 4));
+  memset(hs, 0, 8 * (GRIM_NCTR + GRIM_NQ / 2));
   ((uint32_t *)(hs + GRIM_NCTR))[1] = b->n_small * b->small_stride;
   const uint64_t bytes = b->off_tok + 2 * ld->tok_used;
   HIPCHK(hipMemcpyAsync(b->d_in, b->h_in, bytes, hipMemcpyHostToDevice, st), c, -1);
   g_moved[0] += bytes;
+  {
+    // arena of the table kernels: a pair pool of 512 records per subject that can reach them directly, a few for the
+    // half-wave kernel's subjects (they get there through Plan B only), and the arrays of the three-kernel path sized by
+    // it; running out of any of them is reported like a row-pool overflow
+    uint64_t R = (1ull << 20) + 512ull * ((uint64_t)ld->n_medium + ld->n_general) + 16ull * ld->n_small;
+    static const long env_pool = getenv("GRIM_PAIR_POOL") ? atol(getenv("GRIM_PAIR_POOL")) : 0;
+    if (R > 0x7FFFFFF0ull) R = 0x7FFFFFF0ull;
+    const uint64_t items = 2ull * ld->n_subj < R / 256 + 1 ? 2ull * ld->n_subj : R / 256 + 1;  // bigger work items at most
+    uint64_t cap_b = R / 8 + (items + 1) * ((uint64_t)P * P + 4), cap_u = R / 8 + items * 64 + 1024;  // buckets hold >= 24 pairs on average, two tables
+    if (cap_b > R + 4096) cap_b = R + 4096;
+    uint64_t o = 0;
+    auto take = [&](uint64_t bytes) { uint64_t r = o; o = align256(o + bytes); return r; };
+    const uint64_t o_pool = take(sizeof(PairRec) * R), o_aux = take(sizeof(TabAux) * 2 * (uint64_t)(ld->n_subj ? ld->n_subj : 1)),
+                   o_boff = take(4 * cap_b), o_cell = take(sizeof(CellRec) * cap_b), o_units = take(sizeof(TabUnit) * cap_u),
+                   o_sort = take(4 * 3 * R), o_grp = take(sizeof(GrpRec) * 2 * R), o_prob = take(8 * R);
+    if (o > b->pool_bytes || !b->d_pool) {
+      HIPCHK(hipStreamSynchronize(st), c, -1);
+      if (b->d_pool) hipFree(b->d_pool);
+      b->d_pool = nullptr;
+      b->pool_bytes = 0;
+      if (hipMalloc((void **)&b->d_pool, o) != hipSuccess) {
+        (void)hipGetLastError();
+        c->err = "engine_batch_load: cannot allocate " + std::to_string((unsigned long long)(o >> 20)) + " MiB for the table kernels";
+        return -1;
+      }
+      b->pool_bytes = o;
+    }
+    b->pool_cap = R;
+    A.ppool = (PairRec *)(b->d_pool + o_pool);
+    A.ppool_cap = (uint32_t)(env_pool > 0 && (uint64_t)env_pool < R ? (uint64_t)env_pool : R);
+    A.taux = (TabAux *)(b->d_pool + o_aux);
+    A.tboff = (uint32_t *)(b->d_pool + o_boff);
+    A.tcell = (CellRec *)(b->d_pool + o_cell);
+    A.tboff_cap = (uint32_t)cap_b;
+    A.tunits = (TabUnit *)(b->d_pool + o_units);
+    A.tunits_cap = (uint32_t)cap_u;
+    A.tstride = (uint32_t)R;
+    A.psort = (uint32_t *)(b->d_pool + o_sort);
+    A.pgrp = (GrpRec *)(b->d_pool + o_grp);
+    A.pprob = (double *)(b->d_pool + o_prob);
+  }
   const uint32_t per_block = GRIM_WG / 32;
   b->n_small_waves = ((b->n_small + per_block - 1) / per_block) * (GRIM_WG / 64);
-  uint32_t slots = (uint32_t)c->n_cu * 2;
+  uint32_t slots = (uint32_t)c->n_cu * GRIM_WG_PER_CU;
   static const int env_slots = env_int("GRIM_SLOTS", 0);
   if (env_slots > 0) slots = (uint32_t)env_slots;
   if (slots > ld->n_subj) slots = ld->n_subj;
@@ -775,6 +835,32 @@ static int bind_scratch(grim_batch *b) {
   return 0;
 }
 
+// The table kernels: the one-wave kernel for work items of up to GRIM_TAB_T1_MAX pairs; split, bucket and merge kernel
+// for the rest.  All read their list lengths on the device (the kernels before them in the stream wrote them) and come
+// back at once when there is nothing to do.  start/stop: timing mode, one interval around the four.
+static void enqueue_tables(grim_batch *b, hipEvent_t start, hipEvent_t stop) {
+  grim_ctx *c = b->ctx;
+  DevArgs &A = b->a;
+  const uint32_t cand = b->n_subj;
+  uint32_t g1 = (uint32_t)c->n_cu * 14u, g2 = (uint32_t)c->n_cu * GRIM_TAB_WG_PER_CU;
+  if (g1 > cand) g1 = cand;
+  if (g2 > b->n_slots) g2 = b->n_slots;  // one scratch slot per workgroup
+  if (g1 == 0) g1 = 1;
+  if (g2 == 0) g2 = 1;
+  const uint32_t g3 = (uint32_t)c->n_cu * (160u * 1024u / (uint32_t)sizeof(WaveTab<TAB_NB>) > 32u ? 32u : 160u * 1024u / (uint32_t)sizeof(WaveTab<TAB_NB>));  // resident waves of the bucket kernel
+  if (start && stop) {
+    hipExtLaunchKernelGGL(grim_tables_wave_kernel, dim3(g1), dim3(64), 0, c->stream, start, nullptr, 0, A);
+    hipLaunchKernelGGL(grim_tables_split_kernel, dim3(g2), dim3(GRIM_WG), 0, c->stream, A);
+    hipLaunchKernelGGL(grim_tables_bucket_kernel, dim3(g3), dim3(64), 0, c->stream, A);
+    hipExtLaunchKernelGGL(grim_tables_merge_kernel, dim3(g2), dim3(GRIM_WG), 0, c->stream, nullptr, stop, 0, A);
+  } else {
+    hipLaunchKernelGGL(grim_tables_wave_kernel, dim3(g1), dim3(64), 0, c->stream, A);
+    hipLaunchKernelGGL(grim_tables_split_kernel, dim3(g2), dim3(GRIM_WG), 0, c->stream, A);
+    hipLaunchKernelGGL(grim_tables_bucket_kernel, dim3(g3), dim3(64), 0, c->stream, A);
+    hipLaunchKernelGGL(grim_tables_merge_kernel, dim3(g2), dim3(GRIM_WG), 0, c->stream, A);
+  }
+}
+
 // Stage 1 of a run: half-wave kernel, one-wave kernel, general plan-A kernel, finish kernel (state to the pinned
 // host copy, device copy reset for the next run).  Default: launched directly.  GRIM_GRAPH=1: captured once per batch and
 // replayed as ONE hipGraph launch (no event nodes: they carry no timestamps when replayed on this runtime).
@@ -811,6 +897,7 @@ static int enqueue_stage1(grim_batch *b, bool timing) {
     else
       hipLaunchKernelGGL(grim_plan_a_kernel, grid, block, 0, c->stream, A);
   }
+  if (b->n_general + b->n_medium) enqueue_tables(b, timing ? b->ev[8] : nullptr, timing ? b->ev[9] : nullptr);
   hipLaunchKernelGGL(grim_finish_kernel, dim3(1), dim3(GRIM_WG), 0, c->stream, A.counters, b->hstate, b->n_small * b->small_stride, 0);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -835,7 +922,7 @@ extern "C" int grim_batch_run(grim_batch *b) {
     c->err = "grim_batch_run: output row pool smaller than the half-wave kernel's fixed region";
     return -2;
   }
-  b->ms_s = b->ms_a = b->ms_g = b->ms_m = 0;
+  b->ms_s = b->ms_a = b->ms_g = b->ms_m = b->ms_t = 0;
   if (b->timing) {
     if (enqueue_stage1(b, true) != 0) {
       c->err = "grim_batch_run: kernel launch failed";
@@ -845,6 +932,7 @@ extern "C" int grim_batch_run(grim_batch *b) {
     if (b->n_small) HIPCHK(hipEventElapsedTime(&b->ms_s, b->ev[3], b->ev[5]), c, -1);
     if (b->n_medium) HIPCHK(hipEventElapsedTime(&b->ms_m, b->ev[0], b->ev[1]), c, -1);
     if (b->n_general + b->n_medium) HIPCHK(hipEventElapsedTime(&b->ms_g, b->ev[6], b->ev[7]), c, -1);
+    if (b->n_general + b->n_medium) HIPCHK(hipEventElapsedTime(&b->ms_t, b->ev[8], b->ev[9]), c, -1);
     b->ms_a = b->ms_s + b->ms_m + b->ms_g;
   } else {
     if (b->graph_state == 0) {
@@ -871,8 +959,8 @@ extern "C" int grim_batch_run(grim_batch *b) {
     HIPCHK(hipStreamSynchronize(c->stream), c, -1);
   }
   b->ms_b = 0;
-  uint32_t head[8];
-  memcpy(head, b->hstate + GRIM_NCTR, 32);
+  uint32_t head[GRIM_NQ];
+  memcpy(head, b->hstate + GRIM_NCTR, 4 * GRIM_NQ);
   // ---- stage 2: Plan B / C only when the first stage left subjects for it ------------------------
   if (A.prm.planb && head[2] + head[6] > 0) {
     uint32_t grid = b->n_slots < head[2] + head[6] ? b->n_slots : head[2] + head[6];
@@ -880,21 +968,27 @@ extern "C" int grim_batch_run(grim_batch *b) {
       c->err = "grim_batch_run: plan-B launch failed";
       return -1;
     }
+    enqueue_tables(b, b->timing ? b->ev[10] : nullptr, b->timing ? b->ev[11] : nullptr);
     hipLaunchKernelGGL(grim_finish_kernel, dim3(1), dim3(GRIM_WG), 0, c->stream, A.counters, b->hstate, b->n_small * b->small_stride, 1);
     HIPCHK(hipGetLastError(), c, -1);
     HIPCHK(hipStreamSynchronize(c->stream), c, -1);
-    if (b->timing) HIPCHK(hipEventElapsedTime(&b->ms_b, b->ev[4], b->ev[2]), c, -1);
-    memcpy(head, b->hstate + GRIM_NCTR, 32);
+    if (b->timing) {
+      float t2 = 0;
+      HIPCHK(hipEventElapsedTime(&b->ms_b, b->ev[4], b->ev[2]), c, -1);
+      HIPCHK(hipEventElapsedTime(&t2, b->ev[10], b->ev[11]), c, -1);
+      b->ms_t += t2;
+    }
+    memcpy(head, b->hstate + GRIM_NCTR, 4 * GRIM_NQ);
   }
   if (b->timing) {
-    const double v[6] = {(double)b->ms_a + b->ms_b, b->ms_a, b->ms_b, b->ms_s, b->ms_g, b->ms_m};
-    for (int k = 0; k < 6; ++k) b->acc_ms[k] += v[k];
+    const double v[7] = {(double)b->ms_a + b->ms_b + b->ms_t, b->ms_a, b->ms_b, b->ms_s, b->ms_g, b->ms_m, b->ms_t};
+    for (int k = 0; k < 7; ++k) b->acc_ms[k] += v[k];
     b->n_timed++;
   }
   static const int dbg_classes = env_int("GRIM_DEBUG_CLASSES", 0);
   if (dbg_classes)
-    fprintf(stderr, "grim classes: small %u medium %u general %u | medium->general %u (+%u heavier), to plan B %u (+%u heavy) | stage 1 %s\n",
-            b->n_small, b->n_medium, b->n_general, head[5], head[7], head[2], head[6], b->graph_state == 1 ? "replayed as a hipGraph" : "launched directly");
+    fprintf(stderr, "grim classes: small %u medium %u general %u | medium->general %u (+%u heavier), to plan B %u (+%u heavy) | table items %u one-wave, %u bigger (%u work units), %u pair records | stage 1 %s\n",
+            b->n_small, b->n_medium, b->n_general, head[5], head[7], head[2], head[6], head[9], head[10], head[14], head[8], b->graph_state == 1 ? "replayed as a hipGraph" : "launched directly");
   memcpy(b->counters, b->hstate, 64);
   b->small_ctr_pending = b->n_small > 0;
   for (int sh = 0; sh < 64; ++sh)
@@ -904,6 +998,12 @@ extern "C" int grim_batch_run(grim_batch *b) {
   fprintf(stderr, "grim stamps (us):");
   for (int k = 0; k < 16; ++k) fprintf(stderr, " [%d]%.0f", k, b->hstate[GRIM_STAMP_BASE + k] / 100.0);
   fprintf(stderr, "\n");
+  static const char *hname[4] = {"hist 0", "hist 1", "hist 2", "hist 3"};
+  for (int h = 0; h < 4; ++h) {
+    fprintf(stderr, "grim hist %s:", hname[h]);
+    for (int k = 0; k < 24; ++k) fprintf(stderr, " %llu", b->hstate[GRIM_HIST_BASE + 24 * h + k]);
+    fprintf(stderr, "\n");
+  }
 #endif
   if (b->counters[4] != 0 || head[1] > A.row_cap) {
     if (b->rows_used > A.row_cap) b->rows_used = A.row_cap;
@@ -925,14 +1025,15 @@ extern "C" double grim_batch_kernel_ms(const grim_batch *b, int which) {
   if (!b) return 0.0;
   if (which & 0x10) {  // mean over the timed runs since grim_batch_set_timing(b, 1)
     const int k = which & 0xF;
-    return (k < 6 && b->n_timed) ? b->acc_ms[k] / b->n_timed : 0.0;
+    return (k < 7 && b->n_timed) ? b->acc_ms[k] / b->n_timed : 0.0;
   }
   if (which == 1) return b->ms_a;
   if (which == 2) return b->ms_b;
   if (which == 3) return b->ms_s;
   if (which == 4) return b->ms_g;
   if (which == 5) return b->ms_m;
-  return (double)b->ms_a + (double)b->ms_b;
+  if (which == 6) return b->ms_t;
+  return (double)b->ms_a + (double)b->ms_b + (double)b->ms_t;
 }
 
 extern "C" int grim_batch_counters(const grim_batch *cb, uint64_t out[4]) {
@@ -1016,10 +1117,10 @@ static void batch_destroy(grim_batch *b) {
   if (!b) return;
   use_device(b->ctx->device);
   hipStreamSynchronize(b->ctx->stream);
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < 12; ++i)
     if (b->ev[i]) hipEventDestroy(b->ev[i]);
   if (b->gexec) hipGraphExecDestroy(b->gexec);
-  void *dev[] = {b->d_in, b->d_work, b->d_out, b->d_priors};
+  void *dev[] = {b->d_in, b->d_work, b->d_out, b->d_priors, b->d_pool};
   for (void *p : dev)
     if (p) hipFree(p);
   void *pin[] = {b->h_in, b->h_out, b->h_priors, b->hstate};

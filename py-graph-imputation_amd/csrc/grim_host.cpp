@@ -137,6 +137,9 @@ struct Scratch {  // per thread, reused line after line
   std::string last_r1s, last_r2s;
   uint32_t last_race = 0;
   bool have_last = false;
+  // race pairs this range has seen: the shared table (a mutex) is asked once per distinct pair and range
+  std::unordered_map<std::string, uint32_t> race_cache;
+  std::string race_key;
 };
 
 }  // namespace
@@ -360,7 +363,16 @@ void tokenize_range(const TokParams &prm, const char *text, uint64_t lo, uint64_
       if (sc.have_last && r1 == sv(sc.last_r1s) && r2 == sv(sc.last_r2s)) {
         race = sc.last_race;
       } else {
-        race = prm.races->resolve(r1, r2);
+        sc.race_key.assign(r1);
+        sc.race_key.push_back('\x01');
+        sc.race_key.append(r2);
+        auto rc = sc.race_cache.find(sc.race_key);
+        if (rc != sc.race_cache.end()) {
+          race = rc->second;
+        } else {
+          race = prm.races->resolve(r1, r2);
+          sc.race_cache.emplace(sc.race_key, race);
+        }
         if (race >= 0xFFFFu) {
           R.race_overflow = true;
           race = 0;

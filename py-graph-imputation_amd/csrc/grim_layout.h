@@ -15,6 +15,40 @@ struct SmallRec {
   uint32_t si;                  // subject index in the batch
 };                              // 32 bytes
 
+// one accepted haplotype pair of a subject whose tables are built by the table kernels (grim_tables.h)
+struct PairRec {
+  uint64_t k1, k2;  // 60-bit haplotype keys
+  double prob;
+  uint32_t e1, e2;  // entities: haplotype id (24 bits) | population (8 bits)
+};                  // 32 bytes
+
+struct TabWork {    // "build the tables of subject si from records [off, off + n) of the pair pool"
+  uint32_t si, n, off, mask;
+};
+#define GRIM_TAB_T1_MAX 256  // work items up to this many pairs go to the one-wave table kernel
+struct TabAux {     // per bigger work item: where its buckets and cells live, what the bucket kernel found
+  uint32_t boff[2];      // first slot in the bucket-start array, genotype / haplotype-pair table
+  uint32_t nb[2];        // buckets (0: the table is not split)
+  uint32_t ng[2];        // groups found so far
+  uint32_t overflow[2];  // a bucket held more pairs than a wave's arena
+  uint32_t cell_base;    // first slot of its population cells (bucket-start array and cell records)
+  uint32_t pad[3];
+};
+struct GrpRec {     // a group the bucket kernel found: sum of its pairs' probabilities in pair order, its first pair
+  double sum;
+  uint32_t head, pad;
+};
+struct CellRec {    // a population cell: sum, first pair (GRIM_NONE: empty)
+  double sum;
+  uint32_t first, pad;
+};
+struct TabUnit {    // work unit of the bucket kernel: bucket (table 0 / 1) or population cell (table 2) `tb & 0x0FFFFFFF`
+  uint32_t item, tb;
+  uint32_t off;     // the item's first record in the pair pool
+  uint32_t lo, n;   // the bucket's / cell's pairs: [lo, lo + n) of the item's bucket order
+  uint32_t pad[3];
+};                  // 32 bytes
+
 #define GRIM_SMALL_ROWS_FIXED 3  // umug, umug.pops, pmug.pops; then up to 16 pmug rows
 
 // subject classes (which kernel opens the subject)

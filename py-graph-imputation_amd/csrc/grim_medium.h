@@ -45,7 +45,7 @@ struct WaveMed {
   uint32_t cnode[64];
   uint8_t cside[64];
   uint32_t poff[GRIM_MAXPH + 1];
-  uint32_t useq[64];
+  uint16_t useq[MW_NP];  // accepted pairs in sequence order
   double uprob[64];
   grim_subject subj;
   uint32_t toff[GRIM_MAXL][2];
@@ -70,8 +70,8 @@ __device__ __forceinline__ PairRef med_pair(const WaveMed &M, uint32_t f) {
   return pr;
 }
 
-// returns 0 = done (result written), 1 / 2 = hand over to the general kernel (1: only the number of accepted
-// pairs was too large, a light subject for that kernel; 2: a size limit before that, a heavier one)
+// returns 0 = done (result written, or -- more than 64 accepted pairs -- the tables queued for the table kernels),
+// 2 = hand over to the general kernel (a size limit was exceeded)
 // acc: the wave's algorithmic-byte counts (probes, CSR ids, frequency vectors) of the subjects it completed
 __device__ inline int medium_subject(const DevArgs &A, WaveMed &M, uint32_t si, unsigned long long (&acc)[3], RowBlock &rb) {
   const DevGraph &g = A.g;
@@ -314,10 +314,8 @@ __device__ inline int medium_subject(const DevArgs &A, WaveMed &M, uint32_t si, 
         const uint64_t m = __ballot(win);
         if (emit && win) {
           uint32_t pos = nU + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-          if (pos < 64) {
-            M.useq[pos] = f;
-            M.uprob[pos] = prob;
-          }
+          M.useq[pos] = (uint16_t)f;
+          if (pos < 64) M.uprob[pos] = prob;
         }
         nU += (uint32_t)__popcll(m);
       }
@@ -329,7 +327,53 @@ __device__ inline int medium_subject(const DevArgs &A, WaveMed &M, uint32_t si, 
       eps = mx / 100000.0;
       WAVE_SYNC();
     }
-    if (nU > 64) return nU > 256 ? 2 : 1;  // the count is exact: hundreds of accepted pairs are not a light subject
+    if (nU > 64) {
+      // more pairs than the one-wave shuffle code holds: the tables are the table kernels' work (grim_tables.h).  The
+      // accepted pairs become records of the batch's pair pool, in sequence order, and a work item.
+      uint32_t off = 0;
+      if (lane == 0) {
+        off = atomicAdd(A.queue + 8, nU);
+        if (off + nU > A.ppool_cap) {
+          atomicExch(&A.counters[4], 1ull);
+          off = GRIM_NONE;
+        }
+      }
+      off = __shfl(off, 0);
+      if (off != GRIM_NONE) {
+        for (uint32_t u = lane; u < nU; u += 64) {
+          const PairRef pr = med_pair(M, M.useq[u]);
+          PairRec r;
+          r.k1 = g.node_key[ENT_HAP(pr.e1)];
+          r.k2 = g.node_key[ENT_HAP(pr.e2)];
+          r.prob = pair_prob(pr, prior[ENT_POP(pr.e1) * P + ENT_POP(pr.e2)]);
+          r.e1 = pr.e1;
+          r.e2 = pr.e2;
+          A.ppool[off + u] = r;
+        }
+        if (lane == 0) {
+          TabWork w;
+          w.si = si;
+          w.n = nU;
+          w.off = off;
+          w.mask = 3;
+          if (nU <= GRIM_TAB_T1_MAX)
+            A.t1_list[atomicAdd(A.queue + 9, 1u)] = w;
+          else
+            A.t2_list[atomicAdd(A.queue + 10, 1u)] = w;
+        }
+      }
+      grim_subject_result out;
+      memset(&out, 0, sizeof(out));
+      out.plan = 'a';
+      out.n_pairs = nU;
+      out.max_prob = mx;
+      out.status = GRIM_ST_OK;
+      if (lane == 0) A.res[si] = out;
+      acc[0] += c_probe;
+      acc[1] += c_nbr;
+      acc[2] += c_freq;
+      return 0;
+    }
   }
   WAVE_SYNC();
   // ---- result ----------------------------------------------------------------------------------------

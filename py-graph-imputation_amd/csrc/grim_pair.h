@@ -54,11 +54,29 @@ struct WgShared {
   uint32_t bc[8];
   unsigned long long wctr[GRIM_NWAVE][4];
   grim_subject_result out;
+  // Work areas of the pair and table stages.  They live in the LDS the waves' top-K work areas (WaveTop) occupy
+  // while the phase sides are built -- the two uses never overlap -- which keeps a workgroup at 51 KB of LDS
+  // (three workgroups per CU instead of two).  Set once per kernel by wg_arena().
+  uint32_t *hist;    // [16 * GRIM_WG] radix histograms, ranking scratch
+  double *qprob;     // [1024] staging for the population-cell walk / small-pass keys
+  uint16_t *qcell;   // [1024]
+};
+
+struct WgArena {
   uint32_t hist[16 * GRIM_WG];
-  // staging for the population-cell walk
   double qprob[1024];
   uint16_t qcell[1024];
 };
+static_assert(sizeof(WgArena) <= sizeof(WaveTop) * GRIM_NWAVE, "the pair-stage work areas must fit the top-K work areas");
+
+__device__ __forceinline__ void wg_arena(WgShared &sh, WaveTop *wt) {
+  if (threadIdx.x == 0) {
+    WgArena *a = (WgArena *)wt;
+    sh.hist = a->hist;
+    sh.qprob = a->qprob;
+    sh.qcell = a->qcell;
+  }
+}
 
 struct Slot {
   double *Tp, *Tm;
@@ -377,532 +395,6 @@ __device__ inline uint32_t pair_pass(const DevArgs &A, WgShared &sh, const Slot 
   return nU;
 }
 
-// ---- grouping of U by a 64/128-bit key, ordered sums, stable ranking -------------------------------
-// kind: 0 = genotype (impute.py:497-504), 1 = unordered haplotype pair (write_best_prob, impute.py:24-39),
-//       2 = every pair its own group (write_best_hap_race_pairs, impute.py:79-85)
-// On return: ng groups; rank order in sva/svb (group ids, best first) -> *order_buf; gsum/ghead filled.
-__device__ inline uint32_t group_and_rank(const DevArgs &A, WgShared &sh, const Slot &S, uint32_t nU, int kind,
-                                          uint32_t **order_out, uint32_t want) {
-  const int tid = threadIdx.x;
-  uint32_t ng = 0;
-  // one population: U is already unique per unordered haplotype pair (the dedup key of the pair pass is
-  // {(hap,pop),(hap,pop)}), so every pair is its own group
-  if (kind == 2 || (kind == 1 && A.g.P == 1)) {
-    ng = nU;
-    for (uint32_t u = tid; u < nU; u += GRIM_WG) {
-      S.gsum[u] = S.Uprob[u];
-      S.ghead[u] = u;
-    }
-    __syncthreads();
-  } else {
-    uint32_t cap = 64;
-    while (cap < 2 * nU) cap <<= 1;
-    if (cap > A.tab_cap) cap = A.tab_cap;
-    const uint32_t mask = cap - 1;
-    for (uint32_t s = tid; s < cap; s += GRIM_WG) {
-      S.k0[s] = 0;
-      S.k1[s] = 0;
-      S.tmin[s] = GRIM_NONE;
-    }
-    __syncthreads();
-    // GRIM_GROUP_NB pairs per thread and step: their (dependent) key gathers are in flight together, then the inserts
-    for (uint32_t u0 = tid; u0 < nU; u0 += GRIM_GROUP_NB * GRIM_WG) {
-      uint64_t klo[GRIM_GROUP_NB], khi[GRIM_GROUP_NB];
-#pragma unroll
-      for (int q = 0; q < GRIM_GROUP_NB; ++q) {
-        const uint32_t u = u0 + q * GRIM_WG;
-        klo[q] = khi[q] = 0;
-        if (u < nU) {
-          PairRef pr = pair_ref(sh, S, S.Useq[u]);
-          uint32_t h1 = ENT_HAP(pr.e1), h2 = ENT_HAP(pr.e2);
-          if (kind == 1) {
-            uint32_t lo = h1 < h2 ? h1 : h2, hi = h1 < h2 ? h2 : h1;
-            klo[q] = (((uint64_t)lo << 32) | hi) | GRIM_VALID;
-          } else {
-            uint64_t a = hap_key(A.g, S, h1), b = hap_key(A.g, S, h2);
-            uint64_t lo = 0, hi = 0;
-#pragma unroll
-            for (int l = 0; l < GRIM_MAXL; ++l) {
-              uint64_t x = (a >> (GRIM_ABITS * l)) & 0xFFF, y = (b >> (GRIM_ABITS * l)) & 0xFFF;
-              lo |= (x < y ? x : y) << (GRIM_ABITS * l);
-              hi |= (x < y ? y : x) << (GRIM_ABITS * l);
-            }
-            klo[q] = lo | GRIM_VALID;
-            khi[q] = hi | GRIM_VALID;
-          }
-        }
-      }
-      bool on[GRIM_GROUP_NB];
-      uint32_t slot[GRIM_GROUP_NB];
-#pragma unroll
-      for (int q = 0; q < GRIM_GROUP_NB; ++q) on[q] = u0 + q * GRIM_WG < nU;
-      if (kind == 1)
-        tab_insert_n<false, GRIM_GROUP_NB>(S.k0, S.k1, mask, klo, khi, on, slot);
-      else
-        tab_insert_n<true, GRIM_GROUP_NB>(S.k0, S.k1, mask, klo, khi, on, slot);
-#pragma unroll
-      for (int q = 0; q < GRIM_GROUP_NB; ++q) {
-        const uint32_t u = u0 + q * GRIM_WG;
-        if (on[q]) {
-          S.Uslot[u] = slot[q];
-          atomicMin(&S.tmin[slot[q]], u);
-        }
-      }
-    }
-    __syncthreads();
-    // heads in first-seen order -> dense group ids; 4 x 256 pairs per barrier round, their (dependent) slot and
-    // tmin reads in flight together
-    for (uint32_t u0 = 0; u0 < nU; u0 += 4 * GRIM_WG) {
-      uint32_t slot[4];
-      bool head[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const uint32_t u = u0 + q * GRIM_WG + tid;
-        slot[q] = u < nU ? S.Uslot[u] : 0;
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const uint32_t u = u0 + q * GRIM_WG + tid;
-        head[q] = u < nU && ALOAD(&S.tmin[slot[q]]) == u;
-      }
-      uint64_t m[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        m[q] = __ballot(head[q]);
-        if (lane_id() == 0) sh.tmp[q * GRIM_NWAVE + wave_id()] = (uint32_t)__popcll(m[q]);
-      }
-      __syncthreads();
-      uint32_t run = ng, base[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        for (int w2 = 0; w2 < GRIM_NWAVE; ++w2) {
-          if (w2 == wave_id()) base[q] = run;
-          run += sh.tmp[q * GRIM_NWAVE + w2];
-        }
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (head[q]) {
-          const uint32_t gid = base[q] + (uint32_t)__popcll(m[q] & ((1ull << lane_id()) - 1ull));
-          S.tgid[slot[q]] = gid;
-          S.ghead[gid] = u0 + q * GRIM_WG + tid;
-          S.gcnt[gid] = 0;
-        }
-      ng = run;
-      __syncthreads();
-    }
-    // stable sort of u by group id, then per-group left-to-right sums
-    for (uint32_t u0 = tid; u0 < nU; u0 += 4 * GRIM_WG) {
-      uint32_t gid[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const uint32_t u = u0 + q * GRIM_WG;
-        gid[q] = u < nU ? S.tgid[S.Uslot[u]] : 0;
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const uint32_t u = u0 + q * GRIM_WG;
-        if (u < nU) {
-          S.ska[u] = gid[q];
-          S.sva[u] = u;
-          atomicAdd(&S.gcnt[gid[q]], 1u);
-        }
-      }
-    }
-    __syncthreads();
-    for (uint32_t g = tid; g < ng; g += GRIM_WG) S.gstart[g] = S.gcnt[g];
-    __syncthreads();
-    wg_scan_array(S.gstart, ng, sh.tmp);
-    int w = wg_radix_sort(S.ska, S.sva, S.skb, S.svb, nU, bits_for(ng), sh.hist, sh.tmp);
-    const uint32_t *sorted = w ? S.svb : S.sva;
-    for (uint32_t g = tid; g < ng; g += GRIM_WG) {
-      uint32_t a = S.gstart[g], b = S.gstart[g + 1];
-      double s = S.Uprob[sorted[a]];
-      uint32_t r = a + 1;
-      for (; r + 4 <= b; r += 4) {  // four independent gathers in flight, adds stay in order
-        double v0 = S.Uprob[sorted[r]], v1 = S.Uprob[sorted[r + 1]], v2 = S.Uprob[sorted[r + 2]], v3 = S.Uprob[sorted[r + 3]];
-        s = s + v0;
-        s = s + v1;
-        s = s + v2;
-        s = s + v3;
-      }
-      for (; r < b; ++r) s = s + S.Uprob[sorted[r]];
-      S.gsum[g] = s;
-    }
-    __syncthreads();
-  }
-  // ranking: stable sort by probability, bigger first; input order = first-seen order
-  if (ng <= 512) {
-    // small: rank by counting, sums staged in LDS (the radix histogram area is free here)
-    double *ls = (double *)sh.hist;
-    for (uint32_t g = tid; g < ng; g += GRIM_WG) ls[g] = S.gsum[g];
-    __syncthreads();
-    for (uint32_t g = tid; g < ng; g += GRIM_WG) {
-      double s = ls[g];
-      uint32_t rank = 0;
-      for (uint32_t g2 = 0; g2 < ng; ++g2) {
-        double s2 = ls[g2];
-        rank += (s2 > s || (s2 == s && g2 < g)) ? 1u : 0u;
-      }
-      S.sva[rank] = g;
-    }
-    __syncthreads();
-    *order_out = S.sva;
-    return ng;
-  }
-  for (uint32_t g = tid; g < ng; g += GRIM_WG) {
-    S.ska[g] = ~f64_ord(S.gsum[g]);
-    S.sva[g] = g;
-  }
-  __syncthreads();
-  if (want > 0 && want <= 1024 && want * 4 <= ng) {
-    // Only rows [0,want) are written.  First try ONE pass: a 4096-bin histogram over the keys' top 12 bits
-    // (sign and exponent of the sum) in LDS locates the bin B that holds the want-th smallest key; when the
-    // groups of the bins <= B fit the LDS list they are gathered in id order and ranked by counting.
-    {
-      uint32_t *h12 = sh.hist;
-      for (int i = tid; i < 4096; i += GRIM_WG) h12[i] = 0;
-      __syncthreads();
-      for (uint32_t g0 = tid; g0 < ng; g0 += 4 * GRIM_WG) {
-        uint64_t k[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) k[q] = g0 + q * GRIM_WG < ng ? S.ska[g0 + q * GRIM_WG] : 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (g0 + q * GRIM_WG < ng) atomicAdd(&h12[(uint32_t)(k[q] >> 52)], 1u);
-      }
-      __syncthreads();
-      uint32_t part = 0;
-      for (int e = 0; e < 16; ++e) part += h12[tid * 16 + e];
-      uint32_t total;
-      const uint32_t before = wg_excl_scan(part, sh.tmp, total);
-      if (before < want && want <= before + part) {
-        uint32_t cum = before;
-#pragma nounroll
-        for (int e = 0; e < 16; ++e) {
-          const uint32_t c = h12[tid * 16 + e];
-          if (cum + c >= want) {
-            sh.bc[4] = (uint32_t)(tid * 16 + e);
-            sh.bc[5] = cum + c;
-            break;
-          }
-          cum += c;
-        }
-      }
-      __syncthreads();
-      const uint32_t B = sh.bc[4], upto = sh.bc[5];  // groups in bins <= B
-      __syncthreads();
-      if (upto <= 1024) {
-        uint64_t *lk = (uint64_t *)sh.hist;      // [1024] keys (the histogram is spent)
-        uint32_t *lg = (uint32_t *)(lk + 1024);  // [1024] group ids
-        uint32_t taken = 0;
-        for (uint32_t g0 = 0; g0 < ng; g0 += GRIM_WG) {
-          const uint32_t g = g0 + tid;
-          const uint64_t k = g < ng ? S.ska[g] : ~0ull;
-          const bool pick = g < ng && (uint32_t)(k >> 52) <= B;
-          const uint64_t mp = __ballot(pick);
-          if (lane_id() == 0) sh.tmp[wave_id()] = (uint32_t)__popcll(mp);
-          __syncthreads();
-          uint32_t pbase = taken, ptot = 0;
-          for (int w2 = 0; w2 < GRIM_NWAVE; ++w2) {
-            const uint32_t t = sh.tmp[w2];
-            if (w2 < wave_id()) pbase += t;
-            ptot += t;
-          }
-          if (pick) {
-            const uint32_t pos = pbase + (uint32_t)__popcll(mp & ((1ull << lane_id()) - 1ull));
-            lk[pos] = k;
-            lg[pos] = g;
-          }
-          taken += ptot;
-          __syncthreads();
-        }
-        // rank by (key asc, id asc); ids were gathered in ascending order
-        for (uint32_t i = tid; i < taken; i += GRIM_WG) {
-          const uint64_t k = lk[i];
-          uint32_t rank = 0;
-          for (uint32_t j = 0; j < taken; ++j) {
-            const uint64_t k2 = lk[j];
-            rank += (k2 < k || (k2 == k && j < i)) ? 1u : 0u;
-          }
-          if (rank < want) S.svb[rank] = lg[i];
-        }
-        __syncthreads();
-        *order_out = S.svb;
-        return ng;
-      }
-    }
-    // Otherwise MSD radix select finds the want-th smallest key T; groups
-    // with key < T plus the first ties (group id order = first-seen order) are gathered in id
-    // order and ranked by counting in LDS.
-    uint64_t prefix = 0;
-    uint32_t remaining = want;
-    uint32_t *bins = sh.tmp + GRIM_NWAVE;  // [16]
-    for (int shift = 60; shift >= 0; shift -= 4) {
-      if (tid < 16) bins[tid] = 0;
-      __syncthreads();
-      const uint64_t himask = shift == 60 ? 0ull : (~0ull << (shift + 4));
-      uint32_t loc[16];
-#pragma unroll
-      for (int d = 0; d < 16; ++d) loc[d] = 0;
-      for (uint32_t g = tid; g < ng; g += GRIM_WG) {
-        uint64_t k = S.ska[g];
-        if ((k & himask) == (prefix & himask)) {
-          uint32_t dg = (uint32_t)(k >> shift) & 15u;
-#pragma unroll
-          for (int d = 0; d < 16; ++d) loc[d] += (dg == (uint32_t)d) ? 1u : 0u;
-        }
-      }
-#pragma unroll
-      for (int d = 0; d < 16; ++d) {
-        uint32_t v = loc[d];
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-        if (lane_id() == 0 && v) atomicAdd(&bins[d], v);
-      }
-      __syncthreads();
-      uint32_t cum = 0, dsel = 15;
-      for (uint32_t d = 0; d < 16; ++d) {
-        if (cum + bins[d] >= remaining) {
-          dsel = d;
-          break;
-        }
-        cum += bins[d];
-      }
-      remaining -= cum;
-      prefix |= (uint64_t)dsel << shift;
-      __syncthreads();
-    }
-    const uint64_t T = prefix;  // `remaining` ties with key == T are taken, the earliest ones
-    uint32_t taken = 0, ties = 0;
-    uint64_t *lk = (uint64_t *)sh.hist;          // [1024] keys
-    uint32_t *lg = (uint32_t *)(lk + 1024);      // [1024] group ids
-    for (uint32_t g0 = 0; g0 < ng; g0 += GRIM_WG) {
-      uint32_t g = g0 + tid;
-      uint64_t k = g < ng ? S.ska[g] : ~0ull;
-      bool less = g < ng && k < T, tie = g < ng && k == T;
-      // ties in id order
-      uint64_t mt = __ballot(tie);
-      if (lane_id() == 0) sh.tmp[wave_id()] = (uint32_t)__popcll(mt);
-      __syncthreads();
-      uint32_t tbase = ties, ttot = 0;
-      for (int w2 = 0; w2 < GRIM_NWAVE; ++w2) {
-        uint32_t t = sh.tmp[w2];
-        if (w2 < wave_id()) tbase += t;
-        ttot += t;
-      }
-      __syncthreads();
-      bool pick = less || (tie && tbase + (uint32_t)__popcll(mt & ((1ull << lane_id()) - 1ull)) < remaining);
-      ties += ttot;
-      uint64_t mp = __ballot(pick);
-      if (lane_id() == 0) sh.tmp[wave_id()] = (uint32_t)__popcll(mp);
-      __syncthreads();
-      uint32_t pbase = taken, ptot = 0;
-      for (int w2 = 0; w2 < GRIM_NWAVE; ++w2) {
-        uint32_t t = sh.tmp[w2];
-        if (w2 < wave_id()) pbase += t;
-        ptot += t;
-      }
-      if (pick) {
-        uint32_t pos = pbase + (uint32_t)__popcll(mp & ((1ull << lane_id()) - 1ull));
-        if (pos < 1024) {
-          lk[pos] = k;
-          lg[pos] = g;
-        }
-      }
-      taken += ptot;
-      __syncthreads();
-    }
-    // taken == want; rank by (key asc, id asc) -- ids were gathered in ascending order
-    for (uint32_t i = tid; i < taken; i += GRIM_WG) {
-      uint64_t k = lk[i];
-      uint32_t rank = 0;
-      for (uint32_t j = 0; j < taken; ++j) {
-        uint64_t k2 = lk[j];
-        rank += (k2 < k || (k2 == k && j < i)) ? 1u : 0u;
-      }
-      S.svb[rank] = lg[i];
-    }
-    __syncthreads();
-    *order_out = S.svb;
-    return ng;
-  }
-  int w = wg_radix_sort(S.ska, S.sva, S.skb, S.svb, ng, 64, sh.hist, sh.tmp);
-  *order_out = w ? S.svb : S.sva;
-  return ng;
-}
-
-__device__ inline uint32_t alloc_rows(const DevArgs &A, WgShared &sh, uint32_t n) {
-  if (threadIdx.x == 0) {
-    uint32_t off = n ? atomicAdd(A.row_head, n) : 0;
-    if (n && off + n > A.row_cap) {
-      atomicExch(&A.counters[4], 1ull);
-      off = GRIM_NONE;
-    }
-    sh.bc[1] = off;
-  }
-  __syncthreads();
-  uint32_t off = sh.bc[1];
-  __syncthreads();
-  return off;
-}
-
-// population-pair table: one lane per unordered cell walks U in order (sums are left-to-right,
-// impute.py:535-543 and 24-39); both display orientations come from the same sums.
-__device__ inline void pop_tables(const DevArgs &A, WgShared &sh, const Slot &S, uint32_t nU, grim_subject_result &out,
-                                  uint32_t mask) {
-  const int tid = threadIdx.x;
-  const int P = A.g.P;
-  const int ncell = P * P;
-  for (int c = tid; c < ncell; c += GRIM_WG) {
-    S.qsum[c] = 0.0;
-    S.qfirst[c] = GRIM_NONE;
-  }
-  __syncthreads();
-  if (ncell == 1) {
-    // One population: every pair falls into the single cell -- one strict left-to-right chain of nU fp64 adds.
-    // Wave 0 runs the chain over one half of the staging buffer (16 broadcast LDS reads issued ahead of their 16
-    // dependent adds) while the other three waves fetch the next 512 probabilities into the other half.
-    constexpr uint32_t HALF = 512;
-    for (uint32_t r = tid; r < HALF && r < nU; r += GRIM_WG) sh.qprob[r] = S.Uprob[r];
-    double s = 0.0;
-    for (uint32_t u0 = 0, half = 0; u0 < nU; u0 += HALF, half ^= 1) {
-      __syncthreads();  // this half is filled, the other one is free
-      const uint32_t cnt = nU - u0 < HALF ? nU - u0 : HALF;
-      if (wave_id() == 0) {
-        const double *v = sh.qprob + half * HALF;
-        uint32_t r = 0;
-        if (u0 == 0) {
-          s = v[0];
-          r = 1;
-        }
-        for (; r + 16 <= cnt; r += 16) {
-          double x[16];
-#pragma unroll
-          for (int j = 0; j < 16; ++j) x[j] = v[r + j];
-#pragma unroll
-          for (int j = 0; j < 16; ++j) s = s + x[j];
-        }
-        for (; r < cnt; ++r) s = s + v[r];
-      } else {
-        const uint32_t n0 = u0 + HALF;
-        double *dst = sh.qprob + (half ^ 1) * HALF;
-        for (uint32_t r = tid - 64; r < HALF && n0 + r < nU; r += GRIM_WG - 64) dst[r] = S.Uprob[n0 + r];
-      }
-    }
-    if (tid == 0) {
-      S.qsum[0] = s;
-      S.qfirst[0] = 0;
-    }
-    __syncthreads();
-  }
-  for (uint32_t u0 = 0; ncell > 1 && u0 < nU; u0 += 1024) {
-    uint32_t cnt = nU - u0 < 1024 ? nU - u0 : 1024;
-    for (uint32_t r = tid; r < cnt; r += GRIM_WG) {
-      uint32_t cell = 0;
-      if (ncell > 1) {  // one population: the only cell, no need to look the pair up
-        PairRef pr = pair_ref(sh, S, S.Useq[u0 + r]);
-        uint32_t a = ENT_POP(pr.e1), b = ENT_POP(pr.e2);
-        uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
-        cell = lo * P + hi;
-      }
-      sh.qcell[r] = (uint16_t)cell;
-      sh.qprob[r] = S.Uprob[u0 + r];
-    }
-    __syncthreads();
-    // walk the chunk in order.  Each wave takes 64 entries into registers (one per lane) and replays
-    // them through v_readlane, so the strict left-to-right fp64 chain of a cell runs at register
-    // speed instead of LDS latency; lane = cell (waves whose cells do not exist skip the walk).
-    for (int c0 = wave_id() * 64; c0 < ncell; c0 += GRIM_WG) {
-      const int c = c0 + lane_id();
-      const bool mine = c < ncell && (c / P) <= (c % P);
-      double s = mine ? S.qsum[c] : 0.0;
-      uint32_t first = mine ? S.qfirst[c] : 0;
-      for (uint32_t r0 = 0; r0 < cnt; r0 += 64) {
-        const uint32_t r = r0 + lane_id();
-        const uint32_t cell = r < cnt ? (uint32_t)sh.qcell[r] : 0xFFFFFFFFu;
-        const double pv = r < cnt ? sh.qprob[r] : 0.0;
-        const int lim = (cnt - r0) < 64 ? (int)(cnt - r0) : 64;
-        for (int j = 0; j < lim; ++j) {
-          const uint32_t cj = lane_get(cell, j);
-          const double pj = lane_get(pv, j);
-          if (mine && cj == (uint32_t)c) {
-            if (first == GRIM_NONE) {
-              first = u0 + r0 + j;
-              s = pj;
-            } else {
-              s = s + pj;
-            }
-          }
-        }
-      }
-      if (mine) {
-        S.qsum[c] = s;
-        S.qfirst[c] = first;
-      }
-    }
-    __syncthreads();
-  }
-  // rank the non-empty cells: bigger sum first, earlier first-seen breaks ties
-  uint32_t nq = 0;
-  // compact non-empty cells in first-seen order is not needed: rank by counting
-  for (int c = tid; c < ncell; c += GRIM_WG) {
-    uint32_t first = S.qfirst[c];
-    if (first == GRIM_NONE) continue;
-    double s = S.qsum[c];
-    uint32_t rank = 0;
-    for (int c2 = 0; c2 < ncell; ++c2) {
-      uint32_t f2 = S.qfirst[c2];
-      if (f2 == GRIM_NONE || c2 == c) continue;
-      double s2 = S.qsum[c2];
-      if (s2 > s || (s2 == s && f2 < first)) ++rank;
-    }
-    S.gcnt[c] = rank;
-    atomicAdd(&sh.bc[2], 1u);
-  }
-  __syncthreads();
-  nq = sh.bc[2];
-  __syncthreads();
-  uint32_t nrow = nq < A.prm.n_pop_results ? nq : A.prm.n_pop_results;
-  if (A.prm.em_mr) {
-    // hap_pop_pair mode writes only the single best population pair to the phased pops file
-    // (impute.py:2088) and leaves the MUUG pops file as usual
-  }
-  for (int t = 0; t < 2; ++t) {
-    if (!((mask >> t) & 1u)) continue;  // this half of the tables belongs to another pass
-    int table = t == 0 ? GRIM_T_UMUG_POPS : GRIM_T_PMUG_POPS;
-    bool on = t == 0 ? A.prm.out_muug : A.prm.out_haps;
-    uint32_t want = nrow;
-    if (t == 1 && A.prm.em_mr) want = nq < 1 ? nq : 1;
-    if (!on) want = 0;
-    uint32_t off = alloc_rows(A, sh, want);
-    if (tid == 0) {
-      out.row_off[table] = off == GRIM_NONE ? 0 : off;
-      out.n_rows[table] = off == GRIM_NONE ? 0 : want;
-    }
-    if (off == GRIM_NONE || want == 0) continue;
-    for (int c = tid; c < ncell; c += GRIM_WG) {
-      uint32_t first = S.qfirst[c];
-      if (first == GRIM_NONE) continue;
-      uint32_t rank = S.gcnt[c];
-      if (rank >= want) continue;
-      PairRef pr = pair_ref(sh, S, S.Useq[first]);
-      uint32_t a = ENT_POP(pr.e1), b = ENT_POP(pr.e2);
-      if (t == 0 && A.prm.pop_rank[a] > A.prm.pop_rank[b]) {
-        uint32_t x = a;
-        a = b;
-        b = x;
-      }
-      grim_row r;
-      r.a = a;
-      r.b = b;
-      r.prob = S.qsum[c];
-      r.popa = a;
-      r.popb = b;
-      A.rows[off + rank] = r;
-    }
-  }
-  __syncthreads();
-}
-
 // ---- <= 64 accepted pairs: the four tables by ONE wave with shuffles (no hash table, no barriers) ----
 // Every lane holds one pair; lanes with equal group key form a group, the lowest lane is its
 // first-seen member, every member adds the group's probabilities in lane (= sequence) order.
@@ -1079,11 +571,53 @@ __device__ inline void emit_small(const DevArgs &A, WgShared &sh, const Slot &S,
   emit_small_core(A, nU, e1, e2, prob, k1, k2, out, rb, mask);
 }
 
+// ---- more than 64 accepted pairs: the tables are another kernel's work (grim_tables.h) --------------------------------
+// The accepted pairs (in the reference's pair order, as the final pass left them in Useq / Uprob) become 32-byte records
+// in the batch's pair pool and a work item tells the table kernels where they are and which halves of the tables to
+// build.  All threads call.
+__device__ inline void queue_tables(const DevArgs &A, WgShared &sh, const Slot &S, uint32_t nU, uint32_t si, uint32_t mask) {
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    uint32_t off = atomicAdd(A.queue + 8, nU);
+    if (off + nU > A.ppool_cap) {
+      atomicExch(&A.counters[4], 1ull);  // the run reports the overflow; the caller splits the batch and runs it again
+      off = GRIM_NONE;
+    }
+    sh.bc[1] = off;
+  }
+  __syncthreads();
+  const uint32_t off = sh.bc[1];
+  __syncthreads();
+  if (off == GRIM_NONE) return;
+  for (uint32_t u = tid; u < nU; u += GRIM_WG) {
+    const PairRef pr = pair_ref(sh, S, S.Useq[u]);
+    PairRec r;
+    r.k1 = hap_key(A.g, S, ENT_HAP(pr.e1));
+    r.k2 = hap_key(A.g, S, ENT_HAP(pr.e2));
+    r.prob = S.Uprob[u];
+    r.e1 = pr.e1;
+    r.e2 = pr.e2;
+    A.ppool[off + u] = r;
+  }
+  if (tid == 0) {
+    TabWork w;
+    w.si = si;
+    w.n = nU;
+    w.off = off;
+    w.mask = mask;
+    if (nU <= GRIM_TAB_T1_MAX)
+      A.t1_list[atomicAdd(A.queue + 9, 1u)] = w;
+    else
+      A.t2_list[atomicAdd(A.queue + 10, 1u)] = w;
+  }
+  __syncthreads();
+}
+
 // Everything after the final pass: the four output tables of one subject.
 // mask: bit 0 = the MUUG half (.umug, .umug.pops), bit 1 = the phased half (.pmug, .pmug.pops).  The two
 // halves come from different passes when the MUUG pass ended in Plan C (impute.py:1637-1654).
 __device__ inline void emit_tables(const DevArgs &A, WgShared &sh, const Slot &S, uint32_t nU, grim_subject_result &out,
-                                   uint32_t mask = 3) {
+                                   uint32_t si, uint32_t mask = 3) {
   const int tid = threadIdx.x;
   if (tid == 0) {
     sh.bc[2] = 0;
@@ -1095,61 +629,5 @@ __device__ inline void emit_tables(const DevArgs &A, WgShared &sh, const Slot &S
     __syncthreads();
     return;
   }
-  STAMP_BEGIN();
-  pop_tables(A, sh, S, nU, out, mask);
-  STAMP(13);
-  // genotype table (.umug)
-  if (mask & 1u) {
-    uint32_t *order = nullptr;
-    uint32_t ng = group_and_rank(A, sh, S, nU, 0, &order, A.prm.out_muug ? A.prm.n_results : 0);
-    STAMP(14);
-    uint32_t want = A.prm.out_muug ? (ng < A.prm.n_results ? ng : A.prm.n_results) : 0;
-    uint32_t off = alloc_rows(A, sh, want);
-    if (tid == 0) {
-      out.n_genotypes = ng;
-      out.row_off[GRIM_T_UMUG] = off == GRIM_NONE ? 0 : off;
-      out.n_rows[GRIM_T_UMUG] = off == GRIM_NONE ? 0 : want;
-    }
-    if (off != GRIM_NONE)
-      for (uint32_t r = tid; r < want; r += GRIM_WG) {
-        uint32_t g = order[r];
-        PairRef pr = pair_ref(sh, S, S.Useq[S.ghead[g]]);
-        grim_row row;
-        row.a = hap_key(A.g, S, ENT_HAP(pr.e1));
-        row.b = hap_key(A.g, S, ENT_HAP(pr.e2));
-        row.prob = S.gsum[g];
-        row.popa = ENT_POP(pr.e1);
-        row.popb = ENT_POP(pr.e2);
-        A.rows[off + r] = row;
-      }
-    __syncthreads();
-  }
-  // haplotype-pair table (.pmug)
-  if (mask & 2u) {
-    uint32_t *order = nullptr;
-    uint32_t ng = 0, want = 0;
-    if (A.prm.out_haps) {
-      ng = group_and_rank(A, sh, S, nU, A.prm.em_mr ? 2 : 1, &order, A.prm.n_results);
-      STAMP(15);
-      want = ng < A.prm.n_results ? ng : A.prm.n_results;
-    }
-    uint32_t off = alloc_rows(A, sh, want);
-    if (tid == 0) {
-      out.row_off[GRIM_T_PMUG] = off == GRIM_NONE ? 0 : off;
-      out.n_rows[GRIM_T_PMUG] = off == GRIM_NONE ? 0 : want;
-    }
-    if (off != GRIM_NONE)
-      for (uint32_t r = tid; r < want; r += GRIM_WG) {
-        uint32_t g = order[r];
-        PairRef pr = pair_ref(sh, S, S.Useq[S.ghead[g]]);
-        grim_row row;
-        row.a = hap_key(A.g, S, ENT_HAP(pr.e1));
-        row.b = hap_key(A.g, S, ENT_HAP(pr.e2));
-        row.prob = S.gsum[g];
-        row.popa = ENT_POP(pr.e1);
-        row.popb = ENT_POP(pr.e2);
-        A.rows[off + r] = row;
-      }
-    __syncthreads();
-  }
+  queue_tables(A, sh, S, nU, si, mask);
 }

@@ -692,7 +692,7 @@ __device__ inline uint32_t pb_plan_c(const DevArgs &A, WgShared &sh, const Slot 
   return pb_pairs(A, sh, S, prior, mx);
 }
 
-__global__ __launch_bounds__(GRIM_WG, 2) void grim_plan_b_kernel(DevArgs A) {
+__global__ __launch_bounds__(GRIM_WG, GRIM_PLANB_WG_PER_CU) void grim_plan_b_kernel(DevArgs A) {
   __shared__ WgShared sh;
   __shared__ WaveTop wt[GRIM_NWAVE];
   __shared__ PbState st;
@@ -700,6 +700,8 @@ __global__ __launch_bounds__(GRIM_WG, 2) void grim_plan_b_kernel(DevArgs A) {
   const int P = A.g.P;
   const uint32_t n_heavy = A.queue[6], n_work = *A.next_count + n_heavy;
   Slot S = make_slot(A, blockIdx.x);
+  wg_arena(sh, wt);  // the pair-stage work areas: free whenever pairs are scored, every pass has finished its sides by then
+  __syncthreads();
   for (;;) {
     if (tid == 0) sh.bc[3] = atomicAdd(A.queue + 3, 1u);  // own counter: no reset between kernels
     __syncthreads();
@@ -731,7 +733,7 @@ __global__ __launch_bounds__(GRIM_WG, 2) void grim_plan_b_kernel(DevArgs A) {
     uint32_t nU = pb_levels(A, sh, S, wt, st, tok, &mx);
     STAMP(0);
     if (nU) {
-      emit_tables(A, sh, S, nU, sh.out, 3);
+      emit_tables(A, sh, S, nU, sh.out, si, 3);
       STAMP(3);
       status = GRIM_ST_OK;
     } else if (!A.prm.out_muug && A.prm.em) {
@@ -769,7 +771,7 @@ __global__ __launch_bounds__(GRIM_WG, 2) void grim_plan_b_kernel(DevArgs A) {
           }
           STAMP(6);
           if (nH) {
-            emit_tables(A, sh, S, nH, sh.out, 2u);
+            emit_tables(A, sh, S, nH, sh.out, si, 2u);
             status = GRIM_ST_OK;
             phased_done = true;
           } else if (!A.prm.em) {
@@ -781,7 +783,7 @@ __global__ __launch_bounds__(GRIM_WG, 2) void grim_plan_b_kernel(DevArgs A) {
         STAMP(4);
         if (nU) {
           const uint32_t halves = !two_pass ? 3u : (phased_done || A.prm.em) ? 1u : 3u;
-          emit_tables(A, sh, S, nU, sh.out, halves);
+          emit_tables(A, sh, S, nU, sh.out, si, halves);
           status = GRIM_ST_OK;
         }
         STAMP(3);

@@ -263,7 +263,7 @@ static int device_part(grim_stream *s, Chunk *c, uint32_t lo, uint32_t hi, bool 
     fprintf(stderr, "grim stream: chunk %llu lines [%u,%u) small %zu medium %zu general %u -> rc %d, rows %u (pool %llu)\n",
             (unsigned long long)c->index, lo, hi, s1 - s0, m1 - m0, ng, rc, grim_batch_total_rows(b), (unsigned long long)s->rows_per_chunk);
   if (s->opt.timing) {
-    for (int k = 0; k < 6; ++k) s->st.kernel_ms[k] += grim_batch_kernel_ms(b, k);
+    for (int k = 0; k < 7; ++k) s->st.kernel_ms[k] += grim_batch_kernel_ms(b, k);
     uint64_t ctr[4];
     if (grim_batch_counters(b, ctr) == 0)
       for (int k = 0; k < 4; ++k) s->st.counters[k] += ctr[k];

@@ -1,0 +1,1131 @@
+// grim_tables.h -- the four output tables of a subject with more than 64 accepted haplotype pairs, as kernels of their own.
+//
+// The kernels that score pairs (one-wave, general, Plan B/C) leave the accepted pairs of such a subject as 32-byte
+// records {haplotype keys, probability, entities} in a pool in HBM, in the reference's pair order, plus a work item;
+// the tables -- population pairs, genotypes (.umug), haplotype pairs (.pmug) with their left-to-right sums and stable
+// rankings (impute.py:24-99, 497-543) -- are built afterwards by
+//   grim_tables_wave_kernel : ONE WAVE per subject with <= 256 pairs, everything in 11 KB of LDS, no workgroup barrier,
+//                             14 waves per CU (the mass of the mixed workloads: hundreds of pairs per subject);
+//   grim_tables_wg_kernel   : one workgroup per subject with more pairs: the pairs are dealt into buckets of <= 256 by
+//                             the hash of their group key (a group never spans buckets), every wave runs the same
+//                             LDS-resident grouping on one bucket after the other, the groups are renumbered in
+//                             first-seen order and ranked; population pairs (few, huge groups) are partitioned by cell
+//                             and summed by register-speed chains, one wave per cell.
+// Grouping of <= 256 pairs by a wave: find-or-insert of every pair's key into an LDS hash table whose slot keeps the
+// group's first pair (atomicMin = first seen), a bitonic sort of (slot, pair number) so that a group is a run in pair
+// order, one lane per run adds the probabilities left to right.  Same groups, same summation order, same tie rule as
+// the hash-table + radix-sort path in HBM scratch this replaces for all but pathological inputs (it stays as the
+// fallback when a bucket overflows, and GRIM_TABLES_HBM=1 forces it: the tests hold the two together).
+#pragma once
+#include "grim_pair.h"
+
+#define TAB_N 256        // pairs one wave groups at a time
+#define TAB_SH 18        // bits of a pair number inside a sort key (pair_cap = 16 * 128 * 128 < 2^18)
+#define TAB_MAXB 4096    // buckets of one table of one work item (pair_cap / 48 fits)
+#define GRIM_F_TABLES_HBM 1u  // DevArgs.flags: the workgroup kernel groups through HBM scratch (diagnostic / test switch)
+
+template <int N>
+struct WaveTab {
+  double prob[N];          // probabilities in sorted order
+  uint64_t klo[N], khi[N];
+  uint32_t tab[2 * N];     // hash slots: a local pair of the group; afterwards the group sums (double[N])
+  uint32_t skey[N];        // slot << TAB_SH | pair number, sorted (a wave's sort is instruction bound: 32-bit keys)
+  uint32_t uidx[N];        // pair number (record index inside the work item) of local pair i
+  uint16_t rs[N + 2];      // run starts
+};
+struct WaveTabT1 : WaveTab<TAB_N> {
+  uint16_t hd[TAB_N];      // (one-wave kernel) head pair of run j
+};
+#ifndef TAB_NB
+#define TAB_NB 256         // pairs per bucket the bucket kernel holds
+#endif
+#ifndef TAB_DIV
+#define TAB_DIV 96u         // a table of n pairs is dealt into the power of two >= n / TAB_DIV buckets (48..96 pairs on average:
+                           // measured 2.1 ms against 2.5 ms per 400 000 buckets with 24..48)
+#endif
+
+struct TabShared {
+  uint32_t tmp[GRIM_NWAVE + 24];
+  double dtmp[GRIM_NWAVE];
+  uint32_t bc[8];
+  uint32_t *hist;   // [16 * GRIM_WG]: radix histograms, ranking scratch (a WgArena of the kernel)
+  double *qprob;    // [1024]
+  uint16_t *qcell;  // [1024]
+  uint32_t ng, overflow;
+  TabWork work;
+  uint32_t bcnt[TAB_MAXB + 1];
+};
+
+// group key of a pair under `kind`: 0 genotype (impute.py:497-504), 1 unordered haplotype pair (impute.py:24-39),
+// 3 unordered population pair (impute.py:535-543).  (kind 2, every pair its own group -- write_best_hap_race_pairs,
+// impute.py:79-85 -- needs no grouping.)
+__device__ __forceinline__ void tab_key(int kind, int P, const PairRec &r, uint64_t &lo, uint64_t &hi) {
+  if (kind == 0) {
+    lo = hi = 0;
+#pragma unroll
+    for (int l = 0; l < GRIM_MAXL; ++l) {
+      const uint64_t x = (r.k1 >> (GRIM_ABITS * l)) & 0xFFF, y = (r.k2 >> (GRIM_ABITS * l)) & 0xFFF;
+      lo |= (x < y ? x : y) << (GRIM_ABITS * l);
+      hi |= (x < y ? y : x) << (GRIM_ABITS * l);
+    }
+    lo |= GRIM_VALID;
+  } else if (kind == 1) {
+    const uint32_t h1 = ENT_HAP(r.e1), h2 = ENT_HAP(r.e2);
+    lo = (((uint64_t)(h1 < h2 ? h1 : h2)) << 32 | (h1 < h2 ? h2 : h1)) | GRIM_VALID;
+    hi = 0;
+  } else {
+    const uint32_t a = ENT_POP(r.e1), b = ENT_POP(r.e2);
+    lo = (uint64_t)((a < b ? a : b) * (uint32_t)P + (a < b ? b : a)) | GRIM_VALID;
+    hi = 0;
+  }
+}
+// 64-bit hash of a group key from 32-bit operations (a wave's grouping is instruction bound; mix64's three 64-bit multiplies
+// were a tenth of it): bits 0..31 pick the slot inside a bucket, bits 40..51 the bucket
+__device__ __forceinline__ uint64_t tab_hash(uint64_t lo, uint64_t hi) {
+  uint32_t a = (uint32_t)lo ^ (uint32_t)(hi >> 32) * 0x85EBCA6Bu, b = (uint32_t)(lo >> 32) ^ (uint32_t)hi * 0xC2B2AE35u;
+  a ^= b >> 15;
+  a *= 0x9E3779B1u;
+  b ^= a >> 13;
+  b *= 0x85EBCA6Bu;
+  a ^= b >> 16;
+  return ((uint64_t)b << 32) | a;
+}
+
+// ---- one wave groups n <= N pairs --------------------------------------------------------------------------------------
+// In: W.uidx[0..n) = the pairs' numbers (any order, n <= N <= 256), rec = the work item's records.  Out: the number of groups
+// (runs); run j: first pair W.skey[W.rs[j]] & UM (the smallest number in the group = first seen), sum
+// ((double *)W.tab)[j].
+template <int N>
+__device__ inline uint32_t wave_group_pairs(WaveTab<N> &W, int kind, int P, const PairRec *rec, uint32_t n) {
+  const int lane = lane_id();
+  constexpr uint32_t UM = (1u << TAB_SH) - 1u;
+  for (uint32_t i = lane; i < n; i += 64) {
+    const PairRec r = rec[W.uidx[i]];
+    uint64_t lo, hi;
+    tab_key(kind, P, r, lo, hi);
+    W.klo[i] = lo;
+    W.khi[i] = hi;
+  }
+  for (int i = lane; i < 2 * N; i += 64) W.tab[i] = GRIM_NONE;
+  uint32_t M = 64;  // sort size: a power of two >= n
+  while (M < n) M <<= 1;
+  WAVE_SYNC();
+  volatile uint32_t *tab = W.tab;
+  for (uint32_t i = lane; i < M; i += 64) {
+    uint32_t key = 0xFFFFFFFFu;
+    if (i < n) {
+      const uint64_t lo = W.klo[i], hi = W.khi[i];
+      uint32_t h = (uint32_t)tab_hash(lo, hi) & (2 * N - 1);
+      for (;;) {
+        uint32_t cur = tab[h];
+        if (cur == GRIM_NONE) {
+          cur = atomicCAS(&W.tab[h], GRIM_NONE, i);
+          if (cur == GRIM_NONE) break;  // claimed: this pair stands for the group
+        }
+        if (W.klo[cur] == lo && W.khi[cur] == hi) break;  // joins the group that pair stands for
+        h = (h + 1) & (2 * N - 1);
+      }
+      key = (h << TAB_SH) | W.uidx[i];
+    }
+    W.skey[i] = key;
+  }
+  WAVE_SYNC();
+  for (uint32_t k = 2; k <= M; k <<= 1)
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t q = lane; q < (M >> 1); q += 64) {
+        const uint32_t lo = ((q & ~(j - 1)) << 1) | (q & (j - 1)), hi = lo + j;
+        const bool up = (lo & k) == 0;
+        const uint32_t a = W.skey[lo], b = W.skey[hi];
+        if ((a > b) == up) {
+          W.skey[lo] = b;
+          W.skey[hi] = a;
+        }
+      }
+      WAVE_SYNC();
+    }
+  // runs of equal slot; probabilities in sorted order
+  uint32_t nruns = 0;
+  for (uint32_t r0 = 0; r0 < n; r0 += 64) {
+    const uint32_t r = r0 + lane;
+    bool start = false;
+    if (r < n) {
+      const uint32_t k = W.skey[r];
+      start = r == 0 || (W.skey[r - 1] >> TAB_SH) != (k >> TAB_SH);
+      W.prob[r] = rec[k & UM].prob;
+    }
+    const uint64_t m = __ballot(start);
+    if (start) W.rs[nruns + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)r;
+    nruns += (uint32_t)__popcll(m);
+  }
+  if (lane == 0) W.rs[nruns] = (uint16_t)n;
+  WAVE_SYNC();
+  double *gsum = (double *)W.tab;  // the hash table is spent
+  for (uint32_t j = lane; j < nruns; j += 64) {
+    const uint32_t a = W.rs[j], b = W.rs[j + 1];
+    double s = W.prob[a];
+    for (uint32_t r = a + 1; r < b; ++r) s = s + W.prob[r];
+    gsum[j] = s;
+  }
+  WAVE_SYNC();
+  return nruns;
+}
+
+// ---- the one-wave kernel ----------------------------------------------------------------------------------------------
+// rank of run j among nruns: bigger sum first, the group seen first on ties (stable sort by probability)
+__device__ __forceinline__ uint32_t wave_run_rank(const WaveTabT1 &W, uint32_t nruns, uint32_t j) {
+  const double *gsum = (const double *)W.tab;
+  const double s = gsum[j];
+  const uint32_t h = W.hd[j];
+  uint32_t rank = 0;
+  for (uint32_t j2 = 0; j2 < nruns; ++j2) {
+    const double s2 = gsum[j2];
+    const uint32_t h2 = W.hd[j2];
+    rank += (s2 > s || (s2 == s && h2 < h)) ? 1u : 0u;
+  }
+  return rank;
+}
+
+__device__ inline void tables_wave(const DevArgs &A, WaveTabT1 &W, const TabWork &w, RowBlock &rb) {
+  const int lane = lane_id();
+  const int P = A.g.P;
+  const PairRec *rec = A.ppool + w.off;
+  const uint32_t n = w.n, mask = w.mask;
+  constexpr uint32_t UM = (1u << TAB_SH) - 1u;
+  grim_subject_result *out = A.res + w.si;
+  const double *gsum = (const double *)W.tab;
+  for (uint32_t i = lane; i < n; i += 64) W.uidx[i] = i;
+  WAVE_SYNC();
+  // ---- population pairs (both pops files share the sums) -------------------------------------------------------------
+  {
+    const uint32_t nq = wave_group_pairs(W, 3, P, rec, n);
+    for (uint32_t j = lane; j < nq; j += 64) W.hd[j] = (uint16_t)(W.skey[W.rs[j]] & UM);
+    WAVE_SYNC();
+    for (int t = 0; t < 2; ++t) {
+      if (!((mask >> t) & 1u)) continue;
+      const int table = t == 0 ? GRIM_T_UMUG_POPS : GRIM_T_PMUG_POPS;
+      uint32_t want = nq < A.prm.n_pop_results ? nq : A.prm.n_pop_results;
+      if (t == 1 && A.prm.em_mr) want = nq < 1 ? nq : 1;
+      if (!(t == 0 ? A.prm.out_muug : A.prm.out_haps)) want = 0;
+      const uint32_t off = wave_alloc_rows(A, rb, want);
+      if (lane == 0) {
+        out->row_off[table] = off == GRIM_NONE ? 0 : off;
+        out->n_rows[table] = off == GRIM_NONE ? 0 : want;
+      }
+      if (off == GRIM_NONE || want == 0) continue;
+      for (uint32_t j = lane; j < nq; j += 64) {
+        const uint32_t rank = wave_run_rank(W, nq, j);
+        if (rank >= want) continue;
+        const PairRec r0 = rec[W.hd[j]];
+        uint32_t a = ENT_POP(r0.e1), b = ENT_POP(r0.e2);
+        if (t == 0 && A.prm.pop_rank[a] > A.prm.pop_rank[b]) {
+          const uint32_t x = a;
+          a = b;
+          b = x;
+        }
+        grim_row r;
+        r.a = a; r.b = b; r.prob = gsum[j]; r.popa = a; r.popb = b;
+        A.rows[off + rank] = r;
+      }
+    }
+    WAVE_SYNC();
+  }
+  // ---- genotypes (.umug) and haplotype pairs (.pmug) -------------------------------------------------------------------
+  for (int t = 0; t < 2; ++t) {
+    if (!((mask >> t) & 1u)) continue;
+    const int table = t == 0 ? GRIM_T_UMUG : GRIM_T_PMUG;
+    const bool on = t == 0 ? A.prm.out_muug : A.prm.out_haps;
+    uint32_t ng = 0, want = 0;
+    const bool own = t == 1 && (A.prm.em_mr || P == 1);  // every pair its own group (one population: the pair pass
+                                                         // already made the pairs unique per unordered haplotype pair)
+    if (t == 0 || on) {  // the genotype count is reported even when the MUUG file is off
+      if (own) {
+        ng = n;
+      } else {
+        ng = wave_group_pairs(W, t == 0 ? 0 : 1, P, rec, n);
+        for (uint32_t j = lane; j < ng; j += 64) W.hd[j] = (uint16_t)(W.skey[W.rs[j]] & UM);
+        WAVE_SYNC();
+      }
+      want = on ? (ng < A.prm.n_results ? ng : A.prm.n_results) : 0;
+    }
+    const uint32_t off = wave_alloc_rows(A, rb, want);
+    if (lane == 0) {
+      if (t == 0) out->n_genotypes = ng;
+      out->row_off[table] = off == GRIM_NONE ? 0 : off;
+      out->n_rows[table] = off == GRIM_NONE ? 0 : want;
+    }
+    if (off != GRIM_NONE && want > 0) {
+      if (own) {  // rank the pairs themselves
+        double *pr = (double *)W.tab;
+        for (uint32_t i = lane; i < n; i += 64) {
+          pr[i] = rec[i].prob;
+          W.hd[i] = (uint16_t)i;
+        }
+        WAVE_SYNC();
+      }
+      for (uint32_t j = lane; j < ng; j += 64) {
+        const uint32_t rank = wave_run_rank(W, ng, j);
+        if (rank >= want) continue;
+        const PairRec r0 = rec[W.hd[j]];
+        grim_row row;
+        row.a = r0.k1;
+        row.b = r0.k2;
+        row.prob = gsum[j];
+        row.popa = ENT_POP(r0.e1);
+        row.popb = ENT_POP(r0.e2);
+        A.rows[off + rank] = row;
+      }
+    }
+    WAVE_SYNC();
+  }
+}
+
+// one wave = one work item at a time; waves are independent (no __syncthreads)
+__global__ __launch_bounds__(64) void grim_tables_wave_kernel(DevArgs A) {
+  __shared__ WaveTabT1 W;
+  const uint32_t n_items = A.queue[9];  // written by the kernels before this one in the stream
+  RowBlock rb = {0, 0, GRIM_ROW_GRAB};
+  // one item per visit to the work counter: an item keeps a wave busy for 50-150 us (the kernel is instruction-issue bound,
+  // 14 waves share a CU's four SIMDs), so the counter's ~12 ns per atomic is noise and the tail stays one item long
+  constexpr uint32_t CH = 1;
+  for (;;) {
+    uint32_t w0 = 0;
+    if (lane_id() == 0) w0 = atomicAdd(A.queue + 11, CH);
+    w0 = __shfl(w0, 0);
+    if (w0 >= n_items) break;
+    const uint32_t w1 = w0 + CH < n_items ? w0 + CH : n_items;
+    for (uint32_t w = w0; w < w1; ++w) {
+      const TabWork item = A.t1_list[w];
+      tables_wave(A, W, item, rb);
+    }
+  }
+  // a later launch (after Plan B) continues behind this one's items: the counter must not run past the list
+  if (lane_id() == 0) atomicMin(A.queue + 11, n_items);
+}
+
+// ---- the workgroup kernel ----------------------------------------------------------------------------------------------
+template <typename SH>
+__device__ inline uint32_t tab_alloc_rows(const DevArgs &A, SH &sh, uint32_t n) {
+  if (threadIdx.x == 0) {
+    uint32_t off = n ? atomicAdd(A.row_head, n) : 0;
+    if (n && off + n > A.row_cap) {
+      atomicExch(&A.counters[4], 1ull);
+      off = GRIM_NONE;
+    }
+    sh.bc[1] = off;
+  }
+  __syncthreads();
+  uint32_t off = sh.bc[1];
+  __syncthreads();
+  return off;
+}
+
+// left-to-right sum of v[0..n), n >= 1, by one wave at register speed: 256 values per step sit in four registers per
+// lane (the next 256 are loaded before the current ones are added) and are replayed in order through v_readlane
+__device__ inline double wave_chain(const double *v, uint32_t n) {
+  const int lane = lane_id();
+  double x[4], y[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) x[q] = (uint32_t)(64 * q + lane) < n ? v[64 * q + lane] : 0.0;
+  double s = 0.0;
+  bool first = true;
+  for (uint32_t base = 0; base < n; base += 256) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) y[q] = base + 256 + 64 * q + lane < n ? v[base + 256 + 64 * q + lane] : 0.0;
+    const uint32_t cnt = n - base < 256 ? n - base : 256;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int lim = (int)cnt - 64 * q < 64 ? (int)cnt - 64 * q : 64;
+      for (int j = 0; j < lim; ++j) {
+        const double pj = lane_get(x[q], j);
+        s = first ? pj : s + pj;
+        first = false;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) x[q] = y[q];
+  }
+  return s;
+}
+
+// groups of the nU pairs under `kind` through hash tables and a radix sort in HBM scratch (the path of round 1, on
+// records): gsum / ghead in first-seen order.  Fallback of tab_group_buckets and the GRIM_TABLES_HBM=1 path.
+__device__ inline uint32_t tab_group_hbm(const DevArgs &A, TabShared &sh, const Slot &S, const PairRec *rec, uint32_t nU, int kind) {
+
+  const int tid = threadIdx.x;
+  uint32_t ng = 0;
+  // one population: U is already unique per unordered haplotype pair (the dedup key of the pair pass is
+  // {(hap,pop),(hap,pop)}), so every pair is its own group
+  if (kind == 2 || (kind == 1 && A.g.P == 1)) {
+    ng = nU;
+    for (uint32_t u = tid; u < nU; u += GRIM_WG) {
+      S.gsum[u] = rec[u].prob;
+      S.ghead[u] = u;
+    }
+    __syncthreads();
+  } else {
+    uint32_t cap = 64;
+    while (cap < 2 * nU) cap <<= 1;
+    if (cap > A.tab_cap) cap = A.tab_cap;
+    const uint32_t mask = cap - 1;
+    for (uint32_t s = tid; s < cap; s += GRIM_WG) {
+      S.k0[s] = 0;
+      S.k1[s] = 0;
+      S.tmin[s] = GRIM_NONE;
+    }
+    __syncthreads();
+    // GRIM_GROUP_NB pairs per thread and step: their (dependent) key gathers are in flight together, then the inserts
+    for (uint32_t u0 = tid; u0 < nU; u0 += GRIM_GROUP_NB * GRIM_WG) {
+      uint64_t klo[GRIM_GROUP_NB], khi[GRIM_GROUP_NB];
+#pragma unroll
+      for (int q = 0; q < GRIM_GROUP_NB; ++q) {
+        const uint32_t u = u0 + q * GRIM_WG;
+        klo[q] = khi[q] = 0;
+        if (u < nU) {
+          const PairRec pr = rec[u];
+          uint32_t h1 = ENT_HAP(pr.e1), h2 = ENT_HAP(pr.e2);
+          if (kind == 1) {
+            uint32_t lo = h1 < h2 ? h1 : h2, hi = h1 < h2 ? h2 : h1;
+            klo[q] = (((uint64_t)lo << 32) | hi) | GRIM_VALID;
+          } else {
+            uint64_t a = pr.k1, b = pr.k2;
+            uint64_t lo = 0, hi = 0;
+#pragma unroll
+            for (int l = 0; l < GRIM_MAXL; ++l) {
+              uint64_t x = (a >> (GRIM_ABITS * l)) & 0xFFF, y = (b >> (GRIM_ABITS * l)) & 0xFFF;
+              lo |= (x < y ? x : y) << (GRIM_ABITS * l);
+              hi |= (x < y ? y : x) << (GRIM_ABITS * l);
+            }
+            klo[q] = lo | GRIM_VALID;
+            khi[q] = hi | GRIM_VALID;
+          }
+        }
+      }
+      bool on[GRIM_GROUP_NB];
+      uint32_t slot[GRIM_GROUP_NB];
+#pragma unroll
+      for (int q = 0; q < GRIM_GROUP_NB; ++q) on[q] = u0 + q * GRIM_WG < nU;
+      if (kind == 1)
+        tab_insert_n<false, GRIM_GROUP_NB>(S.k0, S.k1, mask, klo, khi, on, slot);
+      else
+        tab_insert_n<true, GRIM_GROUP_NB>(S.k0, S.k1, mask, klo, khi, on, slot);
+#pragma unroll
+      for (int q = 0; q < GRIM_GROUP_NB; ++q) {
+        const uint32_t u = u0 + q * GRIM_WG;
+        if (on[q]) {
+          S.Uslot[u] = slot[q];
+          atomicMin(&S.tmin[slot[q]], u);
+        }
+      }
+    }
+    __syncthreads();
+    // heads in first-seen order -> dense group ids; 4 x 256 pairs per barrier round, their (dependent) slot and
+    // tmin reads in flight together
+    for (uint32_t u0 = 0; u0 < nU; u0 += 4 * GRIM_WG) {
+      uint32_t slot[4];
+      bool head[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t u = u0 + q * GRIM_WG + tid;
+        slot[q] = u < nU ? S.Uslot[u] : 0;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t u = u0 + q * GRIM_WG + tid;
+        head[q] = u < nU && ALOAD(&S.tmin[slot[q]]) == u;
+      }
+      uint64_t m[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        m[q] = __ballot(head[q]);
+        if (lane_id() == 0) sh.tmp[q * GRIM_NWAVE + wave_id()] = (uint32_t)__popcll(m[q]);
+      }
+      __syncthreads();
+      uint32_t run = ng, base[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        for (int w2 = 0; w2 < GRIM_NWAVE; ++w2) {
+          if (w2 == wave_id()) base[q] = run;
+          run += sh.tmp[q * GRIM_NWAVE + w2];
+        }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (head[q]) {
+          const uint32_t gid = base[q] + (uint32_t)__popcll(m[q] & ((1ull << lane_id()) - 1ull));
+          S.tgid[slot[q]] = gid;
+          S.ghead[gid] = u0 + q * GRIM_WG + tid;
+          S.gcnt[gid] = 0;
+        }
+      ng = run;
+      __syncthreads();
+    }
+    // stable sort of u by group id, then per-group left-to-right sums
+    for (uint32_t u0 = tid; u0 < nU; u0 += 4 * GRIM_WG) {
+      uint32_t gid[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t u = u0 + q * GRIM_WG;
+        gid[q] = u < nU ? S.tgid[S.Uslot[u]] : 0;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t u = u0 + q * GRIM_WG;
+        if (u < nU) {
+          S.ska[u] = gid[q];
+          S.sva[u] = u;
+          atomicAdd(&S.gcnt[gid[q]], 1u);
+        }
+      }
+    }
+    __syncthreads();
+    for (uint32_t g = tid; g < ng; g += GRIM_WG) S.gstart[g] = S.gcnt[g];
+    __syncthreads();
+    wg_scan_array(S.gstart, ng, sh.tmp);
+    int w = wg_radix_sort(S.ska, S.sva, S.skb, S.svb, nU, bits_for(ng), sh.hist, sh.tmp);
+    const uint32_t *sorted = w ? S.svb : S.sva;
+    for (uint32_t g = tid; g < ng; g += GRIM_WG) {
+      uint32_t a = S.gstart[g], b = S.gstart[g + 1];
+      double s = rec[sorted[a]].prob;
+      uint32_t r = a + 1;
+      for (; r + 4 <= b; r += 4) {  // four independent gathers in flight, adds stay in order
+        double v0 = rec[sorted[r]].prob, v1 = rec[sorted[r + 1]].prob, v2 = rec[sorted[r + 2]].prob, v3 = rec[sorted[r + 3]].prob;
+        s = s + v0;
+        s = s + v1;
+        s = s + v2;
+        s = s + v3;
+      }
+      for (; r < b; ++r) s = s + rec[sorted[r]].prob;
+      S.gsum[g] = s;
+    }
+    __syncthreads();
+  }
+  return ng;
+}
+
+// ranking of ng groups (ids in first-seen order) by their sums: stable sort by probability, bigger first; only rows
+// [0, want) of *order_out are valid when want is small (impute.py:24-76)
+__device__ inline void tab_rank(const DevArgs &A, TabShared &sh, const Slot &S, const double *gsum, uint32_t ng, uint32_t want,
+                                uint32_t **order_out) {
+  const int tid = threadIdx.x;
+  // ranking: stable sort by probability, bigger first; input order = first-seen order
+  if (ng <= 512) {
+    // small: rank by counting, sums staged in LDS (the radix histogram area is free here)
+    double *ls = (double *)sh.hist;
+    for (uint32_t g = tid; g < ng; g += GRIM_WG) ls[g] = gsum[g];
+    __syncthreads();
+    for (uint32_t g = tid; g < ng; g += GRIM_WG) {
+      double s = ls[g];
+      uint32_t rank = 0;
+      for (uint32_t g2 = 0; g2 < ng; ++g2) {
+        double s2 = ls[g2];
+        rank += (s2 > s || (s2 == s && g2 < g)) ? 1u : 0u;
+      }
+      S.sva[rank] = g;
+    }
+    __syncthreads();
+    *order_out = S.sva;
+    return;
+  }
+  for (uint32_t g = tid; g < ng; g += GRIM_WG) {
+    S.ska[g] = ~f64_ord(gsum[g]);
+    S.sva[g] = g;
+  }
+  __syncthreads();
+  if (want > 0 && want <= 1024 && want * 4 <= ng) {
+    // Only rows [0,want) are written.  First try ONE pass: a 4096-bin histogram over the keys' top 12 bits
+    // (sign and exponent of the sum) in LDS locates the bin B that holds the want-th smallest key; when the
+    // groups of the bins <= B fit the LDS list they are gathered in id order and ranked by counting.
+    {
+      uint32_t *h12 = sh.hist;
+      for (int i = tid; i < 4096; i += GRIM_WG) h12[i] = 0;
+      __syncthreads();
+      for (uint32_t g0 = tid; g0 < ng; g0 += 4 * GRIM_WG) {
+        uint64_t k[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) k[q] = g0 + q * GRIM_WG < ng ? S.ska[g0 + q * GRIM_WG] : 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (g0 + q * GRIM_WG < ng) atomicAdd(&h12[(uint32_t)(k[q] >> 52)], 1u);
+      }
+      __syncthreads();
+      uint32_t part = 0;
+      for (int e = 0; e < 16; ++e) part += h12[tid * 16 + e];
+      uint32_t total;
+      const uint32_t before = wg_excl_scan(part, sh.tmp, total);
+      if (before < want && want <= before + part) {
+        uint32_t cum = before;
+#pragma nounroll
+        for (int e = 0; e < 16; ++e) {
+          const uint32_t c = h12[tid * 16 + e];
+          if (cum + c >= want) {
+            sh.bc[4] = (uint32_t)(tid * 16 + e);
+            sh.bc[5] = cum + c;
+            break;
+          }
+          cum += c;
+        }
+      }
+      __syncthreads();
+      const uint32_t B = sh.bc[4], upto = sh.bc[5];  // groups in bins <= B
+      __syncthreads();
+      if (upto <= 1024) {
+        uint64_t *lk = (uint64_t *)sh.hist;      // [1024] keys (the histogram is spent)
+        uint32_t *lg = (uint32_t *)(lk + 1024);  // [1024] group ids
+        uint32_t taken = 0;
+        for (uint32_t g0 = 0; g0 < ng; g0 += GRIM_WG) {
+          const uint32_t g = g0 + tid;
+          const uint64_t k = g < ng ? S.ska[g] : ~0ull;
+          const bool pick = g < ng && (uint32_t)(k >> 52) <= B;
+          const uint64_t mp = __ballot(pick);
+          if (lane_id() == 0) sh.tmp[wave_id()] = (uint32_t)__popcll(mp);
+          __syncthreads();
+          uint32_t pbase = taken, ptot = 0;
+          for (int w2 = 0; w2 < GRIM_NWAVE; ++w2) {
+            const uint32_t t = sh.tmp[w2];
+            if (w2 < wave_id()) pbase += t;
+            ptot += t;
+          }
+          if (pick) {
+            const uint32_t pos = pbase + (uint32_t)__popcll(mp & ((1ull << lane_id()) - 1ull));
+            lk[pos] = k;
+            lg[pos] = g;
+          }
+          taken += ptot;
+          __syncthreads();
+        }
+        // rank by (key asc, id asc); ids were gathered in ascending order
+        for (uint32_t i = tid; i < taken; i += GRIM_WG) {
+          const uint64_t k = lk[i];
+          uint32_t rank = 0;
+          for (uint32_t j = 0; j < taken; ++j) {
+            const uint64_t k2 = lk[j];
+            rank += (k2 < k || (k2 == k && j < i)) ? 1u : 0u;
+          }
+          if (rank < want) S.svb[rank] = lg[i];
+        }
+        __syncthreads();
+        *order_out = S.svb;
+        return;
+      }
+    }
+    // Otherwise MSD radix select finds the want-th smallest key T; groups
+    // with key < T plus the first ties (group id order = first-seen order) are gathered in id
+    // order and ranked by counting in LDS.
+    uint64_t prefix = 0;
+    uint32_t remaining = want;
+    uint32_t *bins = sh.tmp + GRIM_NWAVE;  // [16]
+    for (int shift = 60; shift >= 0; shift -= 4) {
+      if (tid < 16) bins[tid] = 0;
+      __syncthreads();
+      const uint64_t himask = shift == 60 ? 0ull : (~0ull << (shift + 4));
+      uint32_t loc[16];
+#pragma unroll
+      for (int d = 0; d < 16; ++d) loc[d] = 0;
+      for (uint32_t g = tid; g < ng; g += GRIM_WG) {
+        uint64_t k = S.ska[g];
+        if ((k & himask) == (prefix & himask)) {
+          uint32_t dg = (uint32_t)(k >> shift) & 15u;
+#pragma unroll
+          for (int d = 0; d < 16; ++d) loc[d] += (dg == (uint32_t)d) ? 1u : 0u;
+        }
+      }
+#pragma unroll
+      for (int d = 0; d < 16; ++d) {
+        uint32_t v = loc[d];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane_id() == 0 && v) atomicAdd(&bins[d], v);
+      }
+      __syncthreads();
+      uint32_t cum = 0, dsel = 15;
+      for (uint32_t d = 0; d < 16; ++d) {
+        if (cum + bins[d] >= remaining) {
+          dsel = d;
+          break;
+        }
+        cum += bins[d];
+      }
+      remaining -= cum;
+      prefix |= (uint64_t)dsel << shift;
+      __syncthreads();
+    }
+    const uint64_t T = prefix;  // `remaining` ties with key == T are taken, the earliest ones
+    uint32_t taken = 0, ties = 0;
+    uint64_t *lk = (uint64_t *)sh.hist;          // [1024] keys
+    uint32_t *lg = (uint32_t *)(lk + 1024);      // [1024] group ids
+    for (uint32_t g0 = 0; g0 < ng; g0 += GRIM_WG) {
+      uint32_t g = g0 + tid;
+      uint64_t k = g < ng ? S.ska[g] : ~0ull;
+      bool less = g < ng && k < T, tie = g < ng && k == T;
+      // ties in id order
+      uint64_t mt = __ballot(tie);
+      if (lane_id() == 0) sh.tmp[wave_id()] = (uint32_t)__popcll(mt);
+      __syncthreads();
+      uint32_t tbase = ties, ttot = 0;
+      for (int w2 = 0; w2 < GRIM_NWAVE; ++w2) {
+        uint32_t t = sh.tmp[w2];
+        if (w2 < wave_id()) tbase += t;
+        ttot += t;
+      }
+      __syncthreads();
+      bool pick = less || (tie && tbase + (uint32_t)__popcll(mt & ((1ull << lane_id()) - 1ull)) < remaining);
+      ties += ttot;
+      uint64_t mp = __ballot(pick);
+      if (lane_id() == 0) sh.tmp[wave_id()] = (uint32_t)__popcll(mp);
+      __syncthreads();
+      uint32_t pbase = taken, ptot = 0;
+      for (int w2 = 0; w2 < GRIM_NWAVE; ++w2) {
+        uint32_t t = sh.tmp[w2];
+        if (w2 < wave_id()) pbase += t;
+        ptot += t;
+      }
+      if (pick) {
+        uint32_t pos = pbase + (uint32_t)__popcll(mp & ((1ull << lane_id()) - 1ull));
+        if (pos < 1024) {
+          lk[pos] = k;
+          lg[pos] = g;
+        }
+      }
+      taken += ptot;
+      __syncthreads();
+    }
+    // taken == want; rank by (key asc, id asc) -- ids were gathered in ascending order
+    for (uint32_t i = tid; i < taken; i += GRIM_WG) {
+      uint64_t k = lk[i];
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < taken; ++j) {
+        uint64_t k2 = lk[j];
+        rank += (k2 < k || (k2 == k && j < i)) ? 1u : 0u;
+      }
+      S.svb[rank] = lg[i];
+    }
+    __syncthreads();
+    *order_out = S.svb;
+    return;
+  }
+  int w = wg_radix_sort(S.ska, S.sva, S.skb, S.svb, ng, 64, sh.hist, sh.tmp);
+  *order_out = w ? S.svb : S.sva;
+  return;
+}
+
+// ---- work items with more than GRIM_TAB_T1_MAX pairs: three kernels ---------------------------------------------------
+// A subject with thousands of accepted pairs is not one workgroup's job: its pairs are dealt into buckets of <= 256
+// by the hash of their group key (a group never spans buckets), the buckets of ALL such subjects become work units of one
+// wave each (grim_tables_bucket_kernel, 14 waves per CU, the same LDS grouping as the one-wave kernel), and a third
+// kernel puts a subject's groups into first-seen order, ranks them and writes the rows.  Population pairs -- few, huge
+// groups -- are partitioned by cell (stable radix sort) in the first kernel; a cell's left-to-right sum is a work unit
+// of the second (one wave, register-speed chain).
+//   grim_tables_split_kernel  : workgroup per item : bucket / cell partition, work units
+//   grim_tables_bucket_kernel : wave per unit      : groups of a bucket (head, sum) / sum of a cell
+//   grim_tables_merge_kernel  : workgroup per item : first-seen order, ranking, rows
+
+// first kernel, one table: bucket of every pair, bucket starts, the pairs dealt out, one work unit per bucket
+__device__ inline void tab_split_table(const DevArgs &A, TabShared &sh, const Slot &S, const TabWork &w, uint32_t item, int t, int kind) {
+  const int tid = threadIdx.x;
+  const int P = A.g.P;
+  const PairRec *rec = A.ppool + w.off;
+  const uint32_t nU = w.n;
+  uint32_t nb = 1;
+  while (nb * TAB_DIV < nU && nb < TAB_MAXB) nb <<= 1;
+  for (uint32_t b = tid; b <= nb; b += GRIM_WG) sh.bcnt[b] = 0;
+  if (tid == 0) {
+    uint32_t base = atomicAdd(A.queue + 13, nb + 1), ubase = atomicAdd(A.queue + 14, nb);
+    if (base + nb + 1 > A.tboff_cap || ubase + nb > A.tunits_cap) {
+      atomicExch(&A.counters[4], 1ull);  // reported like a row-pool overflow: the caller splits the batch
+      base = ubase = GRIM_NONE;
+    }
+    sh.bc[4] = base;
+    sh.bc[5] = ubase;
+    TabAux &x = A.taux[item];
+    x.boff[t] = base;
+    x.nb[t] = base == GRIM_NONE ? 0 : nb;
+    x.ng[t] = 0;
+    x.overflow[t] = 0;
+  }
+  __syncthreads();
+  const uint32_t base = sh.bc[4], ubase = sh.bc[5];
+  if (base == GRIM_NONE) return;
+  for (uint32_t u = tid; u < nU; u += GRIM_WG) {
+    uint64_t lo, hi;
+    tab_key(kind, P, rec[u], lo, hi);
+    const uint32_t b = (uint32_t)(tab_hash(lo, hi) >> 40) & (nb - 1);  // high bits: the waves' slot hash uses the low ones
+    S.svb[u] = b;
+    atomicAdd(&sh.bcnt[b], 1u);
+  }
+  __syncthreads();
+  {  // exclusive scan in place: bcnt[b] = first position of bucket b
+    const uint32_t per = (nb + GRIM_WG - 1) / GRIM_WG;
+    uint32_t b0 = tid * per, b1 = b0 + per;
+    if (b0 > nb) b0 = nb;
+    if (b1 > nb) b1 = nb;
+    uint32_t sum = 0;
+    for (uint32_t b = b0; b < b1; ++b) sum += sh.bcnt[b];
+    uint32_t total;
+    uint32_t at = wg_excl_scan(sum, sh.tmp, total);
+    for (uint32_t b = b0; b < b1; ++b) {
+      const uint32_t c = sh.bcnt[b];
+      sh.bcnt[b] = at;
+      A.tboff[base + b] = at;
+      at += c;
+    }
+    if (tid == 0) A.tboff[base + nb] = nU;
+  }
+  __syncthreads();
+  // any order inside a bucket: the sort key of the bucket kernel carries the pair number
+  uint32_t *dst = A.psort + (uint64_t)t * A.tstride + w.off;
+  for (uint32_t u = tid; u < nU; u += GRIM_WG) dst[atomicAdd(&sh.bcnt[S.svb[u]], 1u)] = u;
+  __syncthreads();  // bcnt[b] is now the END of bucket b
+  for (uint32_t b = tid; b < nb; b += GRIM_WG) {
+    TabUnit un;
+    un.item = item;
+    un.tb = ((uint32_t)t << 28) | b;
+    un.off = w.off;
+    un.lo = b ? sh.bcnt[b - 1] : 0u;
+    un.n = sh.bcnt[b] - un.lo;
+    un.pad[0] = un.pad[1] = un.pad[2] = 0;
+    A.tunits[ubase + b] = un;
+  }
+  __syncthreads();
+}
+
+// first kernel, population pairs: stable partition by cell, probabilities laid out cell after cell, a unit per cell
+__device__ inline void tab_split_pops(const DevArgs &A, TabShared &sh, const Slot &S, const TabWork &w, uint32_t item) {
+  const int tid = threadIdx.x;
+  const int P = A.g.P;
+  const int ncell = P * P;
+  const PairRec *rec = A.ppool + w.off;
+  const uint32_t nU = w.n;
+  uint32_t *cnt = ncell <= TAB_MAXB ? sh.bcnt : S.gstart;  // cell starts: LDS unless there are more cells than it holds
+  for (int c = tid; c <= ncell; c += GRIM_WG) cnt[c] = 0;
+  if (tid == 0) {
+    uint32_t base = atomicAdd(A.queue + 13, (uint32_t)ncell + 1);
+    if (base + ncell + 1 > A.tboff_cap) {
+      atomicExch(&A.counters[4], 1ull);
+      base = GRIM_NONE;
+    }
+    sh.bc[4] = base;
+    A.taux[item].cell_base = base;
+  }
+  __syncthreads();
+  const uint32_t base = sh.bc[4];
+  if (base == GRIM_NONE) return;
+  uint32_t *order = A.psort + 2ull * A.tstride + w.off;
+  double *pp = A.pprob + w.off;
+  if (ncell > 1) {
+    for (uint32_t u = tid; u < nU; u += GRIM_WG) {
+      const PairRec r = rec[u];
+      const uint32_t a = ENT_POP(r.e1), b = ENT_POP(r.e2);
+      const uint32_t cell = (a < b ? a : b) * (uint32_t)P + (a < b ? b : a);
+      S.ska[u] = cell;
+      S.sva[u] = u;
+      atomicAdd(&cnt[cell + 1], 1u);
+    }
+    __syncthreads();
+    const int wch = wg_radix_sort(S.ska, S.sva, S.skb, S.svb, nU, bits_for((uint32_t)ncell), sh.hist, sh.tmp);
+    const uint32_t *sorted = wch ? S.svb : S.sva;
+    if (tid == 0) {  // cell starts (the cells are few next to the pairs: a serial scan by one thread is noise)
+      uint32_t acc = 0;
+      for (int c = 0; c <= ncell; ++c) {
+        acc += cnt[c];
+        cnt[c] = acc;
+      }
+    }
+    __syncthreads();
+    for (uint32_t r = tid; r < nU; r += GRIM_WG) {
+      const uint32_t u = sorted[r];
+      order[r] = u;
+      pp[r] = rec[u].prob;
+    }
+  } else {
+    if (tid == 0) {
+      cnt[0] = 0;
+      cnt[1] = nU;
+    }
+    for (uint32_t r = tid; r < nU; r += GRIM_WG) {
+      order[r] = r;
+      pp[r] = rec[r].prob;
+    }
+    __syncthreads();
+  }
+  for (int c = tid; c <= ncell; c += GRIM_WG) A.tboff[base + c] = cnt[c];
+  for (int c = tid; c < ncell; c += GRIM_WG) {
+    CellRec cr;
+    cr.sum = 0.0;
+    cr.first = GRIM_NONE;
+    cr.pad = 0;
+    A.tcell[base + c] = cr;
+    if (cnt[c + 1] > cnt[c]) {  // a work unit per non-empty cell
+      const uint32_t k = atomicAdd(A.queue + 14, 1u);
+      if (k < A.tunits_cap) {
+        TabUnit un;
+        un.item = item;
+        un.tb = (2u << 28) | (uint32_t)c;
+        un.off = w.off;
+        un.lo = cnt[c];
+        un.n = cnt[c + 1] - cnt[c];
+        un.pad[0] = un.pad[1] = un.pad[2] = 0;
+        A.tunits[k] = un;
+      } else {
+        atomicExch(&A.counters[4], 1ull);
+      }
+    }
+  }
+  __syncthreads();
+}
+
+#ifndef GRIM_TAB_WG_PER_CU
+#define GRIM_TAB_WG_PER_CU 3
+#endif
+__global__ __launch_bounds__(GRIM_WG, GRIM_TAB_WG_PER_CU) void grim_tables_split_kernel(DevArgs A) {
+  __shared__ TabShared sh;
+  __shared__ WgArena arena;
+  const int tid = threadIdx.x;
+  const uint32_t n_items = A.queue[10];
+  Slot S = make_slot(A, blockIdx.x);
+  if (tid == 0) {
+    sh.hist = arena.hist;
+    sh.qprob = arena.qprob;
+    sh.qcell = arena.qcell;
+  }
+  __syncthreads();
+  for (;;) {
+    if (tid == 0) sh.bc[3] = atomicAdd(A.queue + 16, 1u);
+    __syncthreads();
+    const uint32_t item = sh.bc[3];
+    __syncthreads();
+    if (item >= n_items) break;
+    if (tid < (int)(sizeof(TabWork) / 4)) ((uint32_t *)&sh.work)[tid] = ((const uint32_t *)&A.t2_list[item])[tid];
+    __syncthreads();
+    const TabWork w = sh.work;
+    tab_split_pops(A, sh, S, w, item);
+    for (int t = 0; t < 2; ++t) {
+      if (!((w.mask >> t) & 1u)) continue;
+      if (t == 1 && !A.prm.out_haps) continue;
+      const int kind = t == 0 ? 0 : (A.prm.em_mr ? 2 : 1);
+      if (kind == 2 || (kind == 1 && A.g.P == 1) || (A.flags & GRIM_F_TABLES_HBM)) {
+        if (tid == 0) A.taux[item].nb[t] = 0;  // every pair its own group / HBM path: nothing to split
+        continue;
+      }
+      tab_split_table(A, sh, S, w, item, t, kind);
+    }
+    __syncthreads();
+  }
+  if (tid == 0) atomicMin(A.queue + 16, n_items);  // a later launch continues behind this one's items
+}
+
+// second kernel: one wave = one work unit at a time.  The units are dealt to the waves round robin: a shared work
+// counter is ONE address, and an atomic on it costs ~12 ns whoever issues it -- 800 000 units would spend 5 ms there.
+// queue[15] = units done by earlier launches of the run (the finish kernel moves it up).
+__global__ __launch_bounds__(64) void grim_tables_bucket_kernel(DevArgs A) {
+  __shared__ WaveTab<TAB_NB> W;
+  const uint32_t n_units = A.queue[14] < A.tunits_cap ? A.queue[14] : A.tunits_cap;
+  const int lane = lane_id();
+  const int P = A.g.P;
+  constexpr uint32_t UM = (1u << TAB_SH) - 1u;
+  // XCD-aware: blocks with equal blockIdx % 8 share an XCD (and its L2), and the buckets of one work item -- neighbours
+  // in the unit list -- gather from the same records, so each group of blocks takes a contiguous stretch of every round
+  // of units: an item's records are then pulled into one L2 instead of eight
+  const uint32_t nwg = gridDim.x, q8 = nwg / 8, r8 = nwg % 8, xcd = blockIdx.x % 8;
+  const uint32_t vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + blockIdx.x / 8;
+  for (uint32_t k = A.queue[15] + vid; k < n_units; k += nwg) {
+    const TabUnit un = A.tunits[k];
+    TabAux &x = A.taux[un.item];
+    const uint32_t t = un.tb >> 28, n = un.n;
+    if (n == 0) continue;
+    if (t == 2) {  // a population cell: the left-to-right sum of its probabilities
+      const double s = wave_chain(A.pprob + un.off + un.lo, n);
+      if (lane == 0) {
+        CellRec cr;
+        cr.sum = s;
+        cr.first = A.psort[2ull * A.tstride + un.off + un.lo];  // stable partition: the cell's first pair
+        cr.pad = 0;
+        A.tcell[x.cell_base + (un.tb & 0x0FFFFFFFu)] = cr;
+      }
+      continue;
+    }
+    if (n > TAB_NB) {  // a bucket the arena cannot hold: the merge kernel takes the HBM path for this table
+      if (lane == 0) atomicExch(&x.overflow[t], 1u);
+      continue;
+    }
+    const uint32_t *src = A.psort + (uint64_t)t * A.tstride + un.off + un.lo;
+    for (uint32_t i = lane; i < n; i += 64) W.uidx[i] = src[i];
+    WAVE_SYNC();
+    const uint32_t nruns = wave_group_pairs(W, t == 0 ? 0 : 1, P, A.ppool + un.off, n);
+    uint32_t g0 = 0;
+    if (lane == 0) g0 = atomicAdd(&x.ng[t], nruns);
+    g0 = __shfl(g0, 0);
+    const double *gs = (const double *)W.tab;
+    GrpRec *dst = A.pgrp + (uint64_t)t * A.tstride + un.off + g0;
+    for (uint32_t j = lane; j < nruns; j += 64) {
+      GrpRec gr;
+      gr.sum = gs[j];
+      gr.head = W.skey[W.rs[j]] & UM;
+      gr.pad = 0;
+      dst[j] = gr;
+    }
+    WAVE_SYNC();
+  }
+}
+
+// third kernel, one table: the groups the bucket kernel found (any order) -> gsum / ghead in first-seen order.
+// group id = number of groups whose first pair comes earlier = rank of its first pair among the first pairs (a bitmap
+// over the pair numbers and its prefix popcounts)
+__device__ inline void tab_merge_groups(const DevArgs &A, TabShared &sh, const Slot &S, const GrpRec *grp, uint32_t ng, uint32_t nU) {
+  const int tid = threadIdx.x;
+  const uint32_t nw = (nU + 31) / 32;
+  uint32_t *bm = S.tgid, *pre = S.gcnt;
+  for (uint32_t w = tid; w < nw; w += GRIM_WG) bm[w] = 0;
+  __syncthreads();
+  for (uint32_t g = tid; g < ng; g += GRIM_WG) {
+    const uint32_t h = grp[g].head;
+    atomicOr(&bm[h >> 5], 1u << (h & 31));
+  }
+  __syncthreads();
+  {
+    const uint32_t per = (nw + GRIM_WG - 1) / GRIM_WG;
+    uint32_t w0 = tid * per, w1 = w0 + per;
+    if (w0 > nw) w0 = nw;
+    if (w1 > nw) w1 = nw;
+    uint32_t s = 0;
+    for (uint32_t w = w0; w < w1; ++w) s += (uint32_t)__popc(bm[w]);
+    uint32_t total;
+    uint32_t base = wg_excl_scan(s, sh.tmp, total);
+    for (uint32_t w = w0; w < w1; ++w) {
+      pre[w] = base;
+      base += (uint32_t)__popc(bm[w]);
+    }
+  }
+  __syncthreads();
+  for (uint32_t g = tid; g < ng; g += GRIM_WG) {
+    const GrpRec gr = grp[g];
+    const uint32_t h = gr.head;
+    const uint32_t id = pre[h >> 5] + (uint32_t)__popc(bm[h >> 5] & ((1u << (h & 31)) - 1u));
+    S.gsum[id] = gr.sum;
+    S.ghead[id] = h;
+  }
+  __syncthreads();
+}
+
+// third kernel, population pairs: rank the non-empty cells (bigger sum first, earlier first pair on ties), write the rows
+__device__ inline void tab_merge_pops(const DevArgs &A, TabShared &sh, const TabWork &w, const TabAux &x, grim_subject_result *out) {
+  const int tid = threadIdx.x;
+  const int P = A.g.P;
+  const int ncell = P * P;
+  const PairRec *rec = A.ppool + w.off;
+  const uint32_t mask = w.mask;
+  if (x.cell_base == GRIM_NONE) return;
+  const CellRec *cells = A.tcell + x.cell_base;
+  if (tid == 0) sh.bc[2] = 0;
+  __syncthreads();
+  for (int c = tid; c < ncell; c += GRIM_WG)
+    if (cells[c].first != GRIM_NONE) atomicAdd(&sh.bc[2], 1u);
+  __syncthreads();
+  const uint32_t nq = sh.bc[2];
+  __syncthreads();
+  const uint32_t nrow = nq < A.prm.n_pop_results ? nq : A.prm.n_pop_results;
+  for (int t = 0; t < 2; ++t) {
+    if (!((mask >> t) & 1u)) continue;  // this half of the tables belongs to another pass
+    const int table = t == 0 ? GRIM_T_UMUG_POPS : GRIM_T_PMUG_POPS;
+    const bool on = t == 0 ? A.prm.out_muug : A.prm.out_haps;
+    uint32_t want = nrow;
+    if (t == 1 && A.prm.em_mr) want = nq < 1 ? nq : 1;  // hap_pop_pair mode: the single best pair (impute.py:2088)
+    if (!on) want = 0;
+    const uint32_t off = tab_alloc_rows(A, sh, want);
+    if (tid == 0) {
+      out->row_off[table] = off == GRIM_NONE ? 0 : off;
+      out->n_rows[table] = off == GRIM_NONE ? 0 : want;
+    }
+    if (off == GRIM_NONE || want == 0) continue;
+    for (int c = tid; c < ncell; c += GRIM_WG) {
+      const CellRec me = cells[c];
+      if (me.first == GRIM_NONE) continue;
+      uint32_t rank = 0;
+      for (int c2 = 0; c2 < ncell; ++c2) {
+        const CellRec o = cells[c2];
+        if (o.first == GRIM_NONE || c2 == c) continue;
+        if (o.sum > me.sum || (o.sum == me.sum && o.first < me.first)) ++rank;
+      }
+      if (rank >= want) continue;
+      const PairRec pr = rec[me.first];
+      uint32_t a = ENT_POP(pr.e1), b = ENT_POP(pr.e2);
+      if (t == 0 && A.prm.pop_rank[a] > A.prm.pop_rank[b]) {
+        const uint32_t y = a;
+        a = b;
+        b = y;
+      }
+      grim_row r;
+      r.a = a;
+      r.b = b;
+      r.prob = me.sum;
+      r.popa = a;
+      r.popb = b;
+      A.rows[off + rank] = r;
+    }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(GRIM_WG, GRIM_TAB_WG_PER_CU) void grim_tables_merge_kernel(DevArgs A) {
+  __shared__ TabShared sh;
+  __shared__ WgArena arena;
+  const int tid = threadIdx.x;
+  const uint32_t n_items = A.queue[10];
+  Slot S = make_slot(A, blockIdx.x);
+  if (tid == 0) {
+    sh.hist = arena.hist;
+    sh.qprob = arena.qprob;
+    sh.qcell = arena.qcell;
+  }
+  __syncthreads();
+  for (;;) {
+    if (tid == 0) sh.bc[3] = atomicAdd(A.queue + 17, 1u);
+    __syncthreads();
+    const uint32_t item = sh.bc[3];
+    __syncthreads();
+    if (item >= n_items) break;
+    if (tid < (int)(sizeof(TabWork) / 4)) ((uint32_t *)&sh.work)[tid] = ((const uint32_t *)&A.t2_list[item])[tid];
+    __syncthreads();
+    const TabWork w = sh.work;
+    const TabAux x = A.taux[item];
+    const PairRec *rec = A.ppool + w.off;
+    const uint32_t nU = w.n;
+    grim_subject_result *out = A.res + w.si;
+    tab_merge_pops(A, sh, w, x, out);
+    for (int t = 0; t < 2; ++t) {
+      if (!((w.mask >> t) & 1u)) continue;
+      const int table = t == 0 ? GRIM_T_UMUG : GRIM_T_PMUG;
+      const bool on = t == 0 ? A.prm.out_muug : A.prm.out_haps;
+      uint32_t ng = 0, want = 0;
+      uint32_t *order = nullptr;
+      if (t == 0 || on) {
+        const int kind = t == 0 ? 0 : (A.prm.em_mr ? 2 : 1);
+        if (x.nb[t] == 0 || x.overflow[t]) {
+          ng = tab_group_hbm(A, sh, S, rec, nU, kind);  // own groups, a bucket that overflowed, or GRIM_TABLES_HBM=1
+        } else {
+          ng = x.ng[t];
+          tab_merge_groups(A, sh, S, A.pgrp + (uint64_t)t * A.tstride + w.off, ng, nU);
+        }
+        want = on ? (ng < A.prm.n_results ? ng : A.prm.n_results) : 0;
+        if (want) tab_rank(A, sh, S, S.gsum, ng, want, &order);
+      }
+      const uint32_t off = tab_alloc_rows(A, sh, want);
+      if (tid == 0) {
+        if (t == 0) out->n_genotypes = ng;
+        out->row_off[table] = off == GRIM_NONE ? 0 : off;
+        out->n_rows[table] = off == GRIM_NONE ? 0 : want;
+      }
+      if (off != GRIM_NONE)
+        for (uint32_t r = tid; r < want; r += GRIM_WG) {
+          const uint32_t g = order[r];
+          const PairRec pr = rec[S.ghead[g]];
+          grim_row row;
+          row.a = pr.k1;
+          row.b = pr.k2;
+          row.prob = S.gsum[g];
+          row.popa = ENT_POP(pr.e1);
+          row.popb = ENT_POP(pr.e2);
+          A.rows[off + r] = row;
+        }
+      __syncthreads();
+    }
+  }
+  if (tid == 0) atomicMin(A.queue + 17, n_items);
+}

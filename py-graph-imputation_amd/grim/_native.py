@@ -324,7 +324,7 @@ class StreamOpts(C.Structure):
 class StreamStats(C.Structure):
     _fields_ = [("lines", C.c_uint64), ("subjects", C.c_uint64), ("chunks", C.c_uint64), ("reruns", C.c_uint64),
                 ("unsupported", C.c_uint64), ("wall_s", C.c_double), ("tokenize_cpu_s", C.c_double), ("format_cpu_s", C.c_double),
-                ("write_cpu_s", C.c_double), ("device_s", C.c_double), ("kernel_ms", C.c_double * 6), ("counters", C.c_uint64 * 4),
+                ("write_cpu_s", C.c_double), ("device_s", C.c_double), ("kernel_ms", C.c_double * 7), ("counters", C.c_uint64 * 4),
                 ("text_bytes", C.c_uint64 * 7), ("bytes_h2d", C.c_uint64), ("bytes_d2h", C.c_uint64)]
 
 
