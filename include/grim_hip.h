@@ -100,6 +100,9 @@ typedef struct {
   uint32_t n_pop_results;  /* number_of_pop_results          */
   uint8_t out_muug, out_haps, planb, em_mr;
   uint8_t em;              /* impute_file(em=True): the phased pass never falls back to Plan C (impute.py:1649) */
+  uint8_t eps_nonpositive; /* conf epsilon <= 0: call_comp_phase_prob never runs a pass and returns its "NaN" sentinel
+                              (impute.py:1663-1665); the writers raise on it, so every subject that has phases ends as its
+                              raw line in .problem (formatter rule; the ladder is empty) */
   uint8_t pop_rank[GRIM_MAXPOP]; /* rank of each population NAME in sorted order (impute.py:535) */
   double factor_missing_pow[GRIM_MAXL + 1]; /* factor_missing_data ** k for k = 0..5, evaluated by the
                                                host exactly as the reference does (impute.py:1168) */

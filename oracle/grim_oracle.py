@@ -874,9 +874,10 @@ class OracleImputer:
                         _write_merged(sid, haps, probs, n_res, out["pmug"], "+")
                         _write_merged(sid, pops, probs, n_pop, out["pmug_pops"], ",")
                 if cfg["output_MUUG"]:
-                    self.log.append(f"{i} Subject: {sid} {len(res_m['Haps'])} haplotypes")
-                    _write_sorted(sid, res_m["Haps"], n_res, out["umug"])
-                    _write_sorted(sid, res_m["Pops"], n_pop, out["umug_pops"])
+                    m_haps, m_pops = res_m["Haps"], res_m["Pops"]  # both are read before the print (impute.py:2103-2104)
+                    self.log.append(f"{i} Subject: {sid} {len(m_haps)} haplotypes")
+                    _write_sorted(sid, m_haps, n_res, out["umug"])
+                    _write_sorted(sid, m_pops, n_pop, out["umug_pops"])
             except Exception:  # reference: bare except (impute.py:2141-2144)
                 self.log.append(f"{i} Subject: {sid} - Exception")
                 out["problem"].append(str(line) + "\n")

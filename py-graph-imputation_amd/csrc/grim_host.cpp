@@ -767,6 +767,14 @@ void format_range(const FmtParams &fp, const char *text, const TokRange &tr, con
       }
       continue;
     }
+    if (prm->eps_nonpositive && kind != K_MISS_NO_DEVICE) {
+      // epsilon <= 0 (impute.py:1663-1665): no pass ever runs, both results are the {"Haps": "NaN"} sentinel without a
+      // "Pops" entry; .miss sees an empty MUUG result only when the MUUG pass is off, then a writer raises KeyError
+      if (prm->out_haps && !prm->out_muug) idx_id(o.t[4], i, sid);
+      raw_line(j);
+      if (fp.want_log) log_exception(i, sid);
+      continue;
+    }
     const uint32_t n_pairs = (r && prm->out_haps) ? r->n_pairs : 0, n_geno = (r && prm->out_muug) ? r->n_genotypes : 0;
     if (prm->out_haps && n_pairs == 0 && n_geno == 0) idx_id(o.t[4], i, sid);  // impute.py:2065-2068 (never when haplotype output is off)
     if (fp.want_log) {

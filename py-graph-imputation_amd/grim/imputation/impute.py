@@ -37,6 +37,40 @@ def clean_up_gl(gl):
     return "^".join(part for part in gl.split("^") if part.strip("U") == part)
 
 
+# ---- the reference's module-level writers (impute.py:24-99), for callers that format results themselves (the sibling
+# EM package does): same arguments, same rows.  impute_file does not go through them -- the library's formatter
+# threads produce the same text from the device's records.
+def write_best_prob(name_gl, res, probs, numOfResult, fout, sign=","):
+    """impute.py:24-58: pairs (a, b) and (b, a) are one entry, printed in the orientation seen first; probabilities
+    added in list order; stable sort, bigger first; the best numOfResult rows."""
+    total = {}
+    for (a, b), p in zip(res, probs):
+        key = a + sign + b
+        if key not in total:
+            swapped = b + sign + a
+            if swapped in total:
+                key = swapped
+        total[key] = p + total[key] if key in total else p
+    ranked = sorted(total.items(), key=lambda kv: kv[1], reverse=True)
+    for k, (key, p) in enumerate(ranked[:numOfResult]):
+        fout.write(name_gl + "," + str(key) + "," + str(p) + "," + str(k) + "\n")
+
+
+def write_best_prob_genotype(name_gl, res, numOfResult, fout):
+    """impute.py:61-76: {genotype: probability} -> the best numOfResult rows, stable on ties."""
+    ranked = sorted(res.items(), key=lambda kv: kv[1], reverse=True)
+    for k, (gl, p) in enumerate(ranked[:numOfResult]):
+        fout.write(name_gl + "," + str(gl) + "," + str(p) + "," + str(k) + "\n")
+
+
+def write_best_hap_race_pairs(name_gl, haps, pops, probs, numOfResult, fout):
+    """impute.py:79-99: every (haplotype pair, race pair) its own row "h1;r1,h2;r2", stable sort, bigger first."""
+    rows = [(probs[i], haps[i][0] + ";" + pops[i][0] + "," + haps[i][1] + ";" + pops[i][1]) for i in range(len(probs))]
+    rows.sort(key=lambda r: r[0], reverse=True)
+    for k, (p, pair) in enumerate(rows[:numOfResult]):
+        fout.write(name_gl + "," + str(pair) + "," + str(p) + "," + str(k) + "\n")
+
+
 class UnsupportedSubjects(NotImplementedError):
     def __init__(self, items):
         self.items = items
@@ -236,6 +270,7 @@ class Imputation(object):
         p.planb = 1 if planb else 0
         p.em = 1 if em else 0
         p.em_mr = 1 if em_mr else 0
+        p.eps_nonpositive = 0 if config["epsilon"] > 0 else 1
         order = sorted(range(len(self.populations)), key=lambda i: self.populations[i])
         for rank, i in enumerate(order):
             p.pop_rank[i] = rank
@@ -456,8 +491,6 @@ class Imputation(object):
     def _stream_run(self, config, planb, em_mr, em, out_paths=None, in_path=None, data=None, line_offset=0, as_bytes=False):
         if planb is None:
             planb = config["planb"]
-        if not config["epsilon"] > 0:
-            raise NotImplementedError("epsilon <= 0: the reference returns its 'NaN' sentinel and fails every subject")
         self.unsupported = []
         masks = None
         if os.path.isfile(config["bin_imputation_input_file"]):
@@ -516,8 +549,6 @@ class Imputation(object):
         priority = config["priority"]
         if planb is None:
             planb = config["planb"]
-        if not config["epsilon"] > 0:
-            raise NotImplementedError("epsilon <= 0: the reference returns its 'NaN' sentinel and fails every subject")
         self.unsupported = []
         text = "".join(l if l.endswith("\n") else l + "\n" for l in lines).encode()
         parsed = nat.Parsed(self.netGraph.adict, text, planb)

@@ -196,6 +196,119 @@ class Graph(object):
         self._dev = {}
         return self
 
+    # ---- the reference's look-ups over the loaded arrays (networkx_graph.py:215-321) ----------------
+    # The kernels do these on the device with integer keys; the methods below answer the same questions on the
+    # host, from the same arrays, for callers that use the Graph object directly (names in, names out, frequencies
+    # as lists of floats, dict insertion order as in the reference).
+    def _label_mask(self, label):
+        m = 0
+        for ch in str(label):
+            if ch not in self.full_loci:
+                return None
+            m |= 1 << self.full_loci.index(ch)
+        return m
+
+    def _mask_label(self, mask):
+        return "".join(self.full_loci[s] for s in range(len(self.full_loci)) if (int(mask) >> s) & 1)
+
+    def _node_index(self):
+        idx = getattr(self, "_name_index", None)
+        if idx is None:
+            idx = {}
+            keys = self.arrays["node_key"]
+            for i in range(len(keys)):  # a repeated name keeps the later row, like dict assignment (networkx_graph.py:53)
+                idx[int(keys[i])] = i
+            self._name_index = idx
+        return idx
+
+    def node_of_name(self, name):
+        """node id of a haplotype NAME as the graph files spell it (alleles joined by '~' in loci_map index order), or None"""
+        key = 0
+        for al in str(name).split("~"):
+            slot = self.locus_slot.get(al.split("*")[0])
+            if slot is None:
+                return None
+            i = nat.host_lib().grim_dict_find(self.adict.h, slot, al.encode())
+            if i < 0 or i >= self.n_graph_alleles[slot] or (key >> (nat.ABITS * slot)) & 0xFFF:
+                return None
+            key |= (i + 1) << (nat.ABITS * slot)
+        node = self._node_index().get(key)
+        if node is None or self.key_to_name(key) != name:  # the reference's dicts are keyed by the exact string
+            return None
+        return node
+
+    def node_name(self, node):
+        return self.key_to_name(int(self.arrays["node_key"][node]))
+
+    def _freqs(self, node):
+        return [float(x) for x in self.arrays["freq"][node]]
+
+    def haps_by_label(self, label):
+        """networkx_graph.py:215-236: names of every node of `label` (e.g. "125"), in node order."""
+        m = self._label_mask(label)
+        if m is None:
+            return []
+        a, b = int(self.arrays["lab_start"][m]), int(self.arrays["lab_start"][m + 1])
+        return [self.node_name(int(i)) for i in self.arrays["lab_nodes"][a:b]]
+
+    def haps_with_probs_by_label(self, label):
+        """networkx_graph.py:238-251"""
+        m = self._label_mask(label)
+        if m is None:
+            return {}
+        a, b = int(self.arrays["lab_start"][m]), int(self.arrays["lab_start"][m + 1])
+        return {self.node_name(int(i)): self._freqs(int(i)) for i in self.arrays["lab_nodes"][a:b]}
+
+    def adjs_query(self, alleleList):
+        """networkx_graph.py:253-278: full haplotypes (and their frequencies) each name stands for -- itself when it is a
+        full haplotype, else its top-link neighbours (row-start quirks of the loader included)."""
+        out = {}
+        full = self.arrays["full_mask"]
+        a_start, a_nbr = self.arrays["a_start"], self.arrays["a_nbr"]
+        for name in alleleList:
+            i = self.node_of_name(name)
+            if i is None:
+                continue
+            if int(self.arrays["node_mask"][i]) == full:
+                out[name] = self._freqs(i)
+            else:
+                for e in range(int(a_start[i]), int(a_start[i + 1])):  # empty when start[i+1] <= start[i] (the quirk)
+                    j = int(a_nbr[e])
+                    out[self.node_name(j)] = self._freqs(j)
+        return out
+
+    def node_probs(self, nodes, label):
+        """networkx_graph.py:309-321"""
+        out = {}
+        for name in nodes:
+            i = self.node_of_name(name)
+            if i is not None:
+                out[name] = self._freqs(i)
+        return out
+
+    def adjs_query_by_color(self, alleleList, labelA, labelB):
+        """networkx_graph.py:280-307: nodes of label `labelB` that contain each name (one locus more: the plan-B graph's
+        connector of (parent label, child))."""
+        if labelA == labelB:
+            return self.node_probs(alleleList, labelA)
+        out = {}
+        mb = self._label_mask(labelB)
+        b_conn, b_start, b_nbr = self.arrays["b_conn"], self.arrays["b_start"], self.arrays["b_nbr"]
+        for name in alleleList:
+            i = self.node_of_name(name)
+            if i is None or mb is None:
+                continue
+            added = mb & ~int(self.arrays["node_mask"][i])
+            if added == 0 or added & (added - 1) or (mb & int(self.arrays["node_mask"][i])) != int(self.arrays["node_mask"][i]):
+                continue  # no connector "labelB + name": the parent label must be the child's plus exactly one locus
+            c = int(b_conn[i * nat.MAXL + added.bit_length() - 1])
+            if c == 0xFFFFFFFF:
+                continue
+            for e in range(int(b_start[c]), int(b_start[c + 1])):
+                j = int(b_nbr[e])
+                out[self.node_name(j)] = self._freqs(j)
+        return out
+
     # ------------------------------------------------------------------------------------------
     def device(self, ctx):
         """Upload once per context; the handle keeps the HBM copy alive."""

@@ -306,6 +306,13 @@ def main():
     run_scenario("pop4_planc_em_haps", w4, POP4, synth.plan_c_cases("HIS"), {"UNK_priors": "MR", "output_MUUG": False}, em=True)
     run_scenario("pop4_em_mr", w4, POP4, synth.SubjectGen(cau, 14, pops=POP4).mixed(40), {"UNK_priors": "MR"},
                  hap_pop_pair=True)
+    # epsilon <= 0: call_comp_phase_prob never enters its loop and returns its {"Haps": "NaN"} sentinel (impute.py:1663-1665);
+    # the writers trip over the missing "Pops" key -> raw line in .problem (and .miss when only haplotypes are written)
+    eps_lines = synth.edge_cases("CAU") + synth.SubjectGen(cau, 18).mixed(25) + synth.plan_c_cases("CAU")[:3]
+    run_scenario("cau_eps0", w1, ["CAU"], eps_lines, {"epsilon": 0})
+    run_scenario("cau_eps0_haps", w1, ["CAU"], eps_lines, {"epsilon": 0.0, "output_MUUG": False})
+    run_scenario("cau_epsneg_muug", w1, ["CAU"], eps_lines, {"epsilon": -1e-3, "output_haplotypes": False})
+    run_scenario("cau_eps0_noplanb", w1, ["CAU"], eps_lines, {"epsilon": 0, "planb": False})
 
 
 if __name__ == "__main__":
