@@ -1,5 +1,6 @@
-"""N>1 path on CPU: world_size-2 gloo job, contiguous shards, ordered gather on rank 0.
-The per-shard compute is injected (the oracle) -- what is under test is grim/shard.py."""
+"""N>1 path on CPU: world_size-2 and -3 gloo jobs, chunks pulled from the job's store, part files concatenated by rank 0.
+The per-chunk compute is injected (the oracle) -- what is under test is grim/shard.py; the default (HIP) compute under a
+process group is tests/test_multi_rank_gpu.py."""
 import json
 import os
 import subprocess
@@ -24,9 +25,15 @@ def compute(cfg, lines, offset):
     texts = imp.impute_lines(pad + [l.rstrip("\n") for l in lines])
     texts["problem"] = "".join(l for l in texts["problem"].splitlines(True) if not l.endswith(",PAD\n"))
     return texts
-merged = shard.impute_sharded(CONF, compute=compute)
-if dist.get_rank() == 0:
-    json.dump(merged, open(OUT, "w"))
+if FAIL_RANK == dist.get_rank():
+    def compute(cfg, lines, offset):
+        raise ValueError("boom on rank %d" % dist.get_rank())
+try:
+    merged = shard.impute_sharded(CONF, compute=compute, chunk_lines=CHUNK)
+    if dist.get_rank() == 0:
+        json.dump(merged, open(OUT, "w"))
+except Exception as e:
+    open(OUT + ".err%d" % dist.get_rank(), "w").write("%s: %s" % (type(e).__name__, e))
 dist.barrier(); dist.destroy_process_group()
 '''
 
@@ -43,19 +50,39 @@ def test_shard_ranges():
             assert cover == list(range(n))
 
 
-def test_world_size_2_gloo(tmp_path):
+def test_chunk_offsets(tmp_path):
+    from grim import shard
+
+    for n, tail in ((0, ""), (1, "\n"), (1, ""), (7, "\n"), (16, "\n"), (17, ""), (100, "\n")):
+        text = "\n".join("L%d,xx" % i for i in range(n)) + (tail if n else "")
+        p = tmp_path / "f.csv"
+        p.write_text(text)
+        for chunk in (1, 4, 16, 1000):
+            offs = shard.chunk_offsets(str(p), chunk)
+            parts = [text[offs[c]:offs[c + 1]] for c in range(len(offs) - 1)]
+            assert "".join(parts) == text
+            assert all(len(x.splitlines()) == chunk for x in parts[:-1]) and (not parts or 0 < len(parts[-1].splitlines()) <= chunk)
+
+
+def _launch(tmp_path, world, chunk, lines, port, fail_rank=-1, tag="mr"):
     work = harness.ensure_graph("cau")
-    rows = synth.read_freqs(synth.CAU_FREQS)
-    lines = synth.SubjectGen(rows, 77).mixed(40) + synth.edge_cases("CAU") + synth.SubjectGen(rows, 78).full(41)
     conf = harness.base_conf(["CAU"])
-    conf, cpath = harness._write_inputs(work, conf, lines, "mr")
+    conf, cpath = harness._write_inputs(work, conf, lines, tag)
     out = str(tmp_path / "merged.json")
     script = tmp_path / "worker.py"
-    script.write_text("ROOT=%r\nWORK=%r\nCONF=%r\nOUT=%r\n" % (harness.ROOT, work, cpath, out) + WORKER)
+    script.write_text("ROOT=%r\nWORK=%r\nCONF=%r\nOUT=%r\nCHUNK=%d\nFAIL_RANK=%d\n" % (harness.ROOT, work, cpath, out, chunk, fail_rank) + WORKER)
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([harness.PKG, os.path.join(harness.ROOT, "oracle")]),
                MASTER_ADDR="127.0.0.1")
-    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                           "--master-addr", "127.0.0.1", "--master-port", "29517", str(script)], env=env, timeout=600)
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)], env=env, timeout=600)
+    return work, conf, out
+
+
+def test_world_size_2_gloo(tmp_path):
+    """uneven chunks (13 lines each of 95), pulled dynamically by two ranks"""
+    rows = synth.read_freqs(synth.CAU_FREQS)
+    lines = synth.SubjectGen(rows, 77).mixed(40) + synth.edge_cases("CAU") + synth.SubjectGen(rows, 78).full(41)
+    work, conf, out = _launch(tmp_path, 2, 13, lines, 29517)
     merged = json.load(open(out))
     single, _ = harness.run_oracle("cau", conf, lines, tag="mr_single")
     for k in single:
@@ -63,3 +90,26 @@ def test_world_size_2_gloo(tmp_path):
     got = harness.read_outputs(work, "mr")
     for k in single:
         assert got[k] == single[k], "file " + k
+    assert not [f for f in os.listdir(os.path.join(work, "output_mr")) if f.startswith(".grim_parts")]
+
+
+def test_world_size_3_more_ranks_than_chunks(tmp_path):
+    """two chunks for three ranks: one rank gets no line at all"""
+    rows = synth.read_freqs(synth.CAU_FREQS)
+    lines = synth.SubjectGen(rows, 79).mixed(30) + synth.edge_cases("CAU")[:6]
+    work, conf, out = _launch(tmp_path, 3, 20, lines, 29519, tag="mr3")
+    merged = json.load(open(out))
+    single, _ = harness.run_oracle("cau", conf, lines, tag="mr3_single")
+    for k in single:
+        assert merged[k] == single[k], k
+
+
+def test_a_failing_rank_does_not_hang_the_others(tmp_path):
+    """rank 1's compute raises: every rank leaves impute_sharded with an exception instead of waiting forever"""
+    rows = synth.read_freqs(synth.CAU_FREQS)
+    lines = synth.SubjectGen(rows, 80).full(60)
+    work, conf, out = _launch(tmp_path, 2, 5, lines, 29521, fail_rank=1, tag="mrf")
+    assert not os.path.exists(out)
+    e0, e1 = open(out + ".err0").read(), open(out + ".err1").read()
+    assert "rank(s) [1] failed" in e0 and "boom on rank 1" in e0
+    assert e1.startswith("ValueError: boom on rank 1")
