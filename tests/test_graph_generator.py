@@ -126,3 +126,80 @@ def test_cpp_generator_reports_errors(tmp_path):
     bad.write_text("hap,pop,freq\nA*01:01~B*08:01,XXX,0.1\n")
     with pytest.raises(ValueError):  # the reference dies with KeyError on a population it was not configured for
         nat.graphgen_csv(str(bad), ["CAU"], [1e-5], {"A": 1, "B": 2}, *[str(tmp_path / f) for f in "abcd"])
+
+
+import pytest as _pytest
+
+
+@_pytest.mark.parametrize("gname", ["cau", "pop4"])
+def test_loader_arrays_equal_reference_dump(gname):
+    """The C++ loader's arrays (grim_hostgraph_load_csv) against what the REFERENCE's Graph.build_graph holds for the same
+    CSVs (tests/golden/graphs/<name>/loader_arrays.json, written by tools/make_golden.py from the real reference): vertex
+    order, plan-A CSR with its sentinel quirk, plan-B CSR, connector pseudo-vertices in creation order."""
+    import hashlib
+    import json
+    import os
+
+    import numpy as np
+
+    import harness
+    from grim import _native as nat
+    from grim.imputation.networkx_graph import Graph
+    from grim.run_impute_def import load_config
+
+    ref = json.load(open(os.path.join(harness.GOLD, "graphs", gname, "loader_arrays.json")))
+    work = harness.ensure_graph(gname)
+    conf2, cpath = harness._write_inputs(work, harness.base_conf(harness.POPS[gname]), [], "la")
+    cwd = os.getcwd()
+    os.chdir(work)
+    try:
+        cfg, _ = load_config(cpath)
+        g = Graph(cfg).build_graph(cfg["node_file"], cfg["top_links_file"], cfg["edges_file"])
+    finally:
+        os.chdir(cwd)
+    A = g.arrays
+    V = A["n_nodes"]
+
+    def check_arr(a, want):
+        a = np.ascontiguousarray(a, dtype="<u4")
+        assert int(a.size) == want["n"]
+        assert [int(x) for x in a[:8]] == want["head"] and [int(x) for x in a[-8:]] == want["tail"]
+        assert hashlib.sha256(a.tobytes()).hexdigest() == want["sha256"]
+
+    def check_names(v, want):
+        assert len(v) == want["n"] and v[:3] == want["head"] and v[-3:] == want["tail"]
+        assert hashlib.sha256("\n".join(v).encode()).hexdigest() == want["sha256"]
+
+    assert V == ref["n_vertices"]
+    check_names([g.node_name(i) for i in range(V)], ref["Vertices"])
+    check_arr(A["a_nbr"], ref["Edges"])
+    check_arr(A["a_start"], ref["Neighbors_start"])
+    check_arr(A["b_nbr"], ref["Whole_Edges"])
+    # the reference's Whole_Neighbors_start covers real vertices and connectors; the device keeps the connector rows (the
+    # children reach their connectors through b_conn) -- the real vertices' rows are rebuilt here from b_conn to compare all
+    n_conn = len(A["b_start"]) - 1
+    assert V + n_conn == ref["n_whole_vertices"]
+    conn_names = [None] * n_conn
+    b_conn = A["b_conn"].reshape(V, nat.MAXL)
+    child_rows = [[] for _ in range(V)]
+    for i in range(V):
+        for s in range(nat.MAXL):
+            c = int(b_conn[i, s])
+            if c != 0xFFFFFFFF:
+                conn_names[c] = g._mask_label(int(A["node_mask"][i]) | (1 << s)) + g.node_name(i)
+                child_rows[i].append(V + c)
+    check_names(conn_names, ref["Whole_Vertices_connectors"])
+    # Whole_Edges = [edges of real vertices (child -> its connectors, ascending)] + [connector -> parents]: the first part
+    # must be exactly the children's connector lists in vertex order
+    flat = [x for row in child_rows for x in sorted(row)]
+    assert [int(x) for x in A["b_nbr"][:len(flat)]] == flat
+    starts = np.asarray(A["b_start"], dtype=np.int64)
+    assert int(starts[0]) == len(flat)  # the connector rows follow the children's rows
+    # full Whole_Neighbors_start, with the loader's forward fill and sentinel (networkx_graph.py:157-198)
+    counts = np.array([len(r) for r in child_rows], dtype=np.int64)
+    real_starts = np.concatenate([[0], np.cumsum(counts)[:-1]])
+    real_starts = np.where(counts > 0, real_starts, -1)
+    idx = np.maximum.accumulate(np.where(real_starts >= 0, np.arange(V), -1))
+    filled = np.where(idx >= 0, real_starts[np.maximum(idx, 0)], 0)
+    whole = np.concatenate([filled, starts[:-1], [V + n_conn]]).astype("<u4")
+    check_arr(whole, ref["Whole_Neighbors_start"])

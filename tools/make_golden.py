@@ -145,6 +145,45 @@ def build_graph(name, pops):
     return work
 
 
+def dump_loader_arrays(name, work, pops):
+    """tests/golden/graphs/<name>/loader_arrays.json: what the reference's Graph.build_graph (networkx_graph.py:42-213) holds
+    after loading the graph CSVs -- vertex order, the plan-A CSR (Edges / Neighbors_start, sentinel quirk included), the
+    plan-B CSR with its connector pseudo-vertices (Whole_*) -- as sizes, SHA-256 digests of the little-endian uint32
+    arrays / newline-joined name lists, and the first and last entries."""
+    import numpy as np
+    from grim.imputation.networkx_graph import Graph as RefGraph
+    from grim.run_impute_def import run_impute  # noqa: F401  (imports the module the config helper lives in)
+
+    conf = dict(BASE_CONF, populations=list(pops))
+    cwd = os.getcwd()
+    os.chdir(work)
+    try:
+        cfg = {"node_file": "output/csv/nodes.csv", "top_links_file": "output/csv/top_links.csv", "edges_file": "output/csv/edges.csv",
+               "full_loci": "".join(sorted(str(v) for v in conf["loci_map"].values())), "nodes_for_plan_A": [], "save_mode": False,
+               "pops": list(pops)}
+        g = RefGraph(cfg)
+        with contextlib.redirect_stdout(io.StringIO()):
+            g.build_graph(cfg["node_file"], cfg["top_links_file"], cfg["edges_file"])
+    finally:
+        os.chdir(cwd)
+
+    def arr(a):
+        a = np.ascontiguousarray(np.asarray(a), dtype="<u4")
+        return {"n": int(a.size), "sha256": hashlib.sha256(a.tobytes()).hexdigest(), "head": [int(x) for x in a[:8]], "tail": [int(x) for x in a[-8:]]}
+
+    def names(v):
+        v = [str(x) for x in v]
+        return {"n": len(v), "sha256": hashlib.sha256("\n".join(v).encode()).hexdigest(), "head": v[:3], "tail": v[-3:]}
+
+    V = len(g.Vertices)
+    out = {"Vertices": names(g.Vertices), "Edges": arr(g.Edges), "Neighbors_start": arr(g.Neighbors_start),
+           "Whole_Vertices_connectors": names(list(g.Whole_Vertices)[V:]), "Whole_Edges": arr(g.Whole_Edges),
+           "Whole_Neighbors_start": arr(g.Whole_Neighbors_start), "n_vertices": V, "n_whole_vertices": len(g.Whole_Vertices)}
+    with open(os.path.join(GOLD, "graphs", name, "loader_arrays.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    print("loader arrays %-6s V=%d Edges=%d Whole_V=%d Whole_Edges=%d" % (name, V, out["Edges"]["n"], out["n_whole_vertices"], out["Whole_Edges"]["n"]))
+
+
 def run_scenario(name, work, pops, lines, overrides=None, hap_pop_pair=False, bin_masks=None, em=False):
     only = os.environ.get("GOLDEN_ONLY")  # comma-separated scenario names: regenerate just those
     if only and name not in only.split(","):
@@ -253,6 +292,9 @@ def main():
 
     w1 = build_graph("cau", ["CAU"])
     w4 = build_graph("pop4", POP4)
+    if not os.environ.get("GOLDEN_ONLY") or "loader_arrays" in os.environ["GOLDEN_ONLY"].split(","):
+        dump_loader_arrays("cau", w1, ["CAU"])
+        dump_loader_arrays("pop4", w4, POP4)
 
     donor = [l.rstrip("\n") for l in open(os.path.join(REF, "data", "subjects", "donor.csv"))]
     run_scenario("cau_min", w1, ["CAU"], donor)
