@@ -127,6 +127,7 @@ def main():
             dist.barrier()
         work = wmda_scale.ensure()
         conf = wmda_scale.conf()
+        gname = wmda_scale.name_of()
     else:
         if rank == 0:
             harness.ensure_graph(gname)
@@ -353,6 +354,7 @@ def cpu_leg(args, work, conf, lines, rows, gname):
     if args.workload in ("config2", "config3"):
         sample = synth.SubjectGen(rows, 1000).full_fast(20000 * workers)
     elif args.workload == "config5":
+        workers = min(workers, 2)  # every worker loads the 1.1 M-node graph into Python dicts (minutes, gigabytes)
         sample = lines[: 2 * workers]
     else:
         sample = lines[: min(len(lines), 2500 * workers)]

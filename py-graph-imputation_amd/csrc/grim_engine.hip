@@ -66,7 +66,12 @@ __global__ __launch_bounds__(GRIM_WG, GRIM_WG_PER_CU) void grim_plan_a_kernel(De
     // open_phases; when no phase has candidates on both sides the reference rewrites the '/'-lists
     // (known alleles only, then the 10 most frequent) and opens again (impute.py:1619-1627)
     for (int stage = 0; fits; ++stage) {
-      for (int s = wave_id(); s < 2 * nph; s += GRIM_NWAVE) build_side_plan_a(A, sh, S, prior, wt[wave_id()], s >> 1, s & 1, s);
+      // one scan of the label for all sides when that is cheaper than opening them one by one (high ambiguity on a big graph)
+      bool done = false;
+      if (stage == 0 && shared_scan_wanted(A, sh)) done = build_sides_shared_scan(A, sh, S, prior, wt);
+      if (stage == 0) HIST(0, done ? 1 : 0, 1);  // (diagnostic build) subjects by opening: bucket 0 side by side, bucket 1 shared scan
+      if (!done)
+        for (int s = wave_id(); s < 2 * nph; s += GRIM_NWAVE) build_side_plan_a(A, sh, S, prior, wt[wave_id()], s >> 1, s & 1, s);
       __syncthreads();
       kept = false;
       for (int i = 0; i < nph; ++i) kept |= (sh.cand_any[2 * i] && sh.cand_any[2 * i + 1]);
@@ -76,7 +81,8 @@ __global__ __launch_bounds__(GRIM_WG, GRIM_WG_PER_CU) void grim_plan_a_kernel(De
     }
     STAMP(8);
     const unsigned long long t_sides = STAMP_NOW();
-    (void)t_sides;
+    HIST(1, sh.ntok, (t_sides - t_subject) / 100);  // us in the sides by number of alleles in the GL string
+    HIST(2, sh.ntok, 1);
     uint8_t status = GRIM_ST_MISS, reason = 0, plan = 'a';
     if (!fits) {
       status = GRIM_ST_UNSUPPORTED;  // more than GRIM_RTOK_CAP/3 alleles in one GL string
@@ -201,6 +207,8 @@ struct grim_batch {
   double *d_priors, *h_priors;  // prior matrices: their own small buffers, uploaded only when the set changes
   uint8_t *d_pool;              // the table kernels' arena (device only; grows at load time): pair records, per-item state,
   uint64_t pool_cap, pool_bytes; // bucket starts, cells, work units, bucket order, groups, probabilities in cell order
+  uint64_t pool_want;            // records the last run asked for when it ran out (the next load sizes the pool for it)
+  uint64_t pool_asked;           // pair records the last run asked for
   uint32_t priors_cap, priors_up;
   uint64_t row_limit;   // rows a run may use
   EnginePlan plan;      // what the arenas are laid out for
@@ -653,6 +661,18 @@ void engine_set_error(grim_ctx *c, const char *msg) {
 const EngineHost *engine_batch_host(grim_batch *b) { return b ? &b->h : nullptr; }
 uint64_t engine_bytes_moved(const grim_batch *, int dir) { return g_moved[dir ? 1 : 0]; }
 
+// After grim_batch_run returned -2: when the PAIR POOL was what ran out and the demand fits `max_records`, the next
+// engine_batch_load sizes the pool for it (returns 1: load and run the same subjects again); 0: something else
+// overflowed, or the demand is beyond the limit -- split the batch.
+int engine_batch_grow_pool(grim_batch *b, uint64_t max_records) {
+  if (!b || b->pool_asked <= b->a.ppool_cap) return 0;
+  uint64_t want = b->pool_asked + b->pool_asked / 8 + 4096;
+  if (want > max_records || want > 0x7FFFFFF0ull) return 0;
+  if (want <= b->pool_want) return 0;  // already tried with that much
+  b->pool_want = want;
+  return 1;
+}
+
 int engine_batch_load(grim_batch *b, const EngineLoad *ld) {
   if (!b || !ld) return -1;
   grim_ctx *c = b->ctx;
@@ -705,6 +725,10 @@ int engine_batch_load(grim_batch *b, const EngineLoad *ld) {
     // half-wave kernel's subjects (they get there through Plan B only), and the arrays of the three-kernel path sized by
     // it; running out of any of them is reported like a row-pool overflow
     uint64_t R = (1ull << 20) + 512ull * ((uint64_t)ld->n_medium + ld->n_general) + 16ull * ld->n_small;
+    // subjects the host classified as heavy (high ambiguity) can accept tens of thousands of pairs each: half a subject's
+    // worst case for the first 256 of them, so that a small batch of heavy subjects does not need a second run
+    R += (uint64_t)(ld->n_general < 256u ? ld->n_general : 256u) * (A.pair_cap / 2);
+    if (b->pool_want > R) R = b->pool_want;  // an earlier run of this batch ran out: it said how much it needed
     static const long env_pool = getenv("GRIM_PAIR_POOL") ? atol(getenv("GRIM_PAIR_POOL")) : 0;
     if (R > 0x7FFFFFF0ull) R = 0x7FFFFFF0ull;
     const uint64_t items = 2ull * ld->n_subj < R / 256 + 1 ? 2ull * ld->n_subj : R / 256 + 1;  // bigger work items at most
@@ -994,6 +1018,7 @@ extern "C" int grim_batch_run(grim_batch *b) {
   for (int sh = 0; sh < 64; ++sh)
     for (int k = 0; k < 3; ++k) b->counters[k] += b->hstate[8 + 4 * sh + k];
   b->rows_used = head[1];
+  b->pool_asked = head[8];
 #ifdef GRIM_STAMPS
   fprintf(stderr, "grim stamps (us):");
   for (int k = 0; k < 16; ++k) fprintf(stderr, " [%d]%.0f", k, b->hstate[GRIM_STAMP_BASE + k] / 100.0);

@@ -46,3 +46,6 @@ uint64_t engine_bytes_moved(const grim_batch *b, int dir);  // 0 = H2D, 1 = D2H 
 void engine_set_error(grim_ctx *ctx, const char *msg);
 // hand a batch back to its context: the next engine_batch_create on that context reuses its arenas
 void engine_batch_recycle(grim_batch *b);
+// after a run that returned -2: 1 = the pair pool ran out and the next load will make it big enough (run the same subjects
+// again), 0 = split the batch
+int engine_batch_grow_pool(grim_batch *b, uint64_t max_records);

@@ -45,6 +45,8 @@ struct WgShared {
   // The intersection opening tests a graph node against a side with one bit per position.
   uint32_t abits[GRIM_MAXL][2][128];
   uint32_t Tn[GRIM_SIDES];
+  uint32_t hitn[GRIM_SIDES];  // shared label scan: nodes found per side
+  uint32_t hitreq[GRIM_SIDES];  // ... and the membership bits a side requires (bit 2l + c: position l, column c)
   uint8_t cand_any[GRIM_SIDES];
   uint8_t ph_pat[GRIM_MAXPH];
   int nph;

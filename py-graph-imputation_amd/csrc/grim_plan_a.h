@@ -227,6 +227,191 @@ __device__ __forceinline__ void store_top(const Slot &S, WgShared &sh, WaveTop &
   WAVE_SYNC();
 }
 
+// ---- one label scan for ALL sides of a subject ----------------------------------------------------------------------
+// Every side of a subject opens over the same label (the typed loci) and differs only in which column of the subject's
+// '/'-lists it takes per position, so one pass over the label's key stream can serve all <= 32 sides: a node's ten
+// membership bits (position x column, sh.abits) decide for every side at once.  That replaces 32 scans of the label
+// (sides with >= number_of_options_threshold options, impute.py:947-981) or 32 x candidates random probes of the name index
+// (cartesian sides, cutils.pyx:4-31) -- on a WMDA-scale graph (240 000 full haplotypes, 64 MB index) 8-30 ms per subject --
+// by ~0.1 ms of streaming.  Hits are parked per side in the slot (label positions) and pushed through the ranked top-K
+// with the tie the in-order stream would have given them (cartesian position / label position), so the lists are bit for
+// bit what build_side_plan_a produces.
+// hits per side the slot holds: S.ska and S.skb (adjacent in the slot, 16 bytes per pair of pair_cap) viewed as u32
+__device__ __forceinline__ uint32_t hit_cap(const DevArgs &A) { return (uint32_t)((4ull * A.pair_cap) / GRIM_SIDES); }
+
+// decides (thread 0) whether the shared scan pays: sh.bc[6] = 1 / 0.  All threads call.
+__device__ inline bool shared_scan_wanted(const DevArgs &A, WgShared &sh) {
+  const DevGraph &g = A.g;
+  const grim_subject &sj = sh.subj;
+  if (threadIdx.x == 0) {
+    uint32_t ok = g.scan_ok && sj.n_loci >= 1 && sh.ntok > 2u * sj.n_loci && hit_cap(A) >= 1024u;
+    uint32_t mask = 0;
+    for (int l = 0; l < sj.n_loci; ++l) mask |= 1u << sj.slot[l];
+    const uint32_t la = g.lab_start[mask], lb = g.lab_start[mask + 1];
+    uint64_t work = 0;  // what the per-side openings would cost, in label nodes / probes
+    for (int s = 0; s < 2 * sh.nph && ok; ++s) {
+      if (sh.side_ver[s] != 0) ok = 0;  // reduced lists (impute.py:1620-1627): the bits describe the lists as typed
+      const uint32_t pat = sh.ph_pat[s >> 1];
+      uint64_t options = 1, ncand = 1;
+      for (int l = 0; l < sj.n_loci; ++l) {
+        const int c = (int)((pat >> l) & 1u) ^ (s & 1);
+        const ListVer lv = sh.lv[l][c][0];
+        options *= (uint64_t)lv.wid;
+        if (options > 0xFFFFFFFFFFFFull) options = 0xFFFFFFFFFFFFull;
+        ncand *= lv.cnt;
+        if (ncand > 0xFFFFFFFFFFFFull) ncand = 0xFFFFFFFFFFFFull;
+        if (options < A.prm.opt_threshold && lv.cnt > 64) ok = 0;  // a cartesian side ranks its hits through LDS lists of <= 64
+      }
+      if (options < A.prm.opt_threshold) {
+        if (ncand >= (1ull << 28)) ok = 0;
+        work += ncand;
+      } else {
+        work += lb - la;
+      }
+    }
+    if (lb - la >= (1u << 28) || work < 2ull * (lb - la)) ok = 0;
+    sh.bc[6] = ok;
+  }
+  __syncthreads();
+  const bool r = sh.bc[6] != 0;
+  __syncthreads();
+  return r;
+}
+
+// All sides of the subject by one scan.  Returns false when a side found more nodes than the slot holds (the caller opens
+// the sides one by one then).  All threads call.
+__device__ inline bool build_sides_shared_scan(const DevArgs &A, WgShared &sh, const Slot &S, const double *prior, WaveTop *wt) {
+  const DevGraph &g = A.g;
+  const grim_subject &sj = sh.subj;
+  const int tid = threadIdx.x, lane = lane_id();
+  const int n = sj.n_loci, nsides = 2 * sh.nph;
+  uint32_t mask = 0, sl[GRIM_MAXL];
+#pragma unroll
+  for (int l = 0; l < GRIM_MAXL; ++l) {
+    sl[l] = l < n ? sj.slot[l] : 0;
+    if (l < n) mask |= 1u << sl[l];
+  }
+  const uint32_t la = g.lab_start[mask], lb = g.lab_start[mask + 1];
+  uint32_t *hits = (uint32_t *)S.ska;  // [GRIM_SIDES][HCAP] label positions
+  const uint32_t HCAP = hit_cap(A);
+  if (tid < GRIM_SIDES) sh.hitn[tid] = 0;
+  if (tid == 0) sh.bc[7] = 0;
+  __syncthreads();
+  // ---- phase 1: the label's keys.  Eight keys per thread and step: the eight loads are in flight together (one workgroup
+  // per CU and four waves: nothing else hides the memory latency), and a side's requirement is one 10-bit mask
+  // (bit 2l + c: position l, column c), so matching a node against all sides is a compare per side.
+  if (tid < nsides) {
+    const uint32_t pat = sh.ph_pat[tid >> 1];
+    uint32_t r = 0;
+    for (int l = 0; l < n; ++l) r |= 1u << (2 * l + (int)(((pat >> l) & 1u) ^ (uint32_t)(tid & 1)));
+    sh.hitreq[tid] = r;
+  }
+  __syncthreads();
+  constexpr int NK = 8;
+  for (uint32_t i0 = la; i0 < lb; i0 += GRIM_WG * NK) {
+    uint64_t key[NK];
+#pragma unroll
+    for (int q = 0; q < NK; ++q) {
+      const uint32_t i = i0 + (uint32_t)q * GRIM_WG + tid;
+      key[q] = i < lb ? g.lab_key[i] : 0ull;
+    }
+#pragma unroll
+    for (int q = 0; q < NK; ++q) {
+      const uint32_t i = i0 + (uint32_t)q * GRIM_WG + tid;
+      if (i >= lb) continue;
+      uint32_t bits = 0;  // bit 2l + c: the node's allele at position l is in column c's list
+      bool possible = true;
+#pragma unroll
+      for (int l = 0; l < GRIM_MAXL; ++l)
+        if (l < n) {
+          const uint32_t al = ((uint32_t)(key[q] >> (GRIM_ABITS * sl[l])) & 0xFFFu) - 1u;
+          const uint32_t b0 = (sh.abits[l][0][(al >> 5) & 127u] >> (al & 31u)) & 1u, b1 = (sh.abits[l][1][(al >> 5) & 127u] >> (al & 31u)) & 1u;
+          bits |= (b0 << (2 * l)) | (b1 << (2 * l + 1));
+          possible = possible && (b0 | b1);
+        }
+      if (!possible) continue;  // some position matches neither column: no side takes the node (nearly every node)
+      for (int s = 0; s < nsides; ++s) {
+        const uint32_t r = sh.hitreq[s];
+        if ((bits & r) == r) {
+          const uint32_t pos = atomicAdd(&sh.hitn[s], 1u);
+          if (pos < HCAP)
+            hits[(uint32_t)s * HCAP + pos] = i;
+          else
+            sh.bc[7] = 1;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (sh.bc[7]) return false;
+  if (tid == 0) sh.wctr[0][0] += ((uint64_t)(lb - la) * 3) / 4;  // a scanned node costs 12 bytes (key + id), a probe 16
+  // ---- phase 2: a wave per side pushes the side's nodes through the ranked top-K ----------------------------------------
+  const bool full_nodes = (mask == g.full_mask);
+  for (int s = wave_id(); s < nsides; s += GRIM_NWAVE) {
+    WaveTop &L = wt[wave_id()];
+    const uint32_t pat = sh.ph_pat[s >> 1];
+    TopState st;
+    st.nrun = 0; st.nbuf = 0; st.K = (int)A.prm.top_n; st.full = false; st.ge = true; st.thr = 0;
+    uint32_t cn[GRIM_MAXL];
+    uint64_t options = 1;
+#pragma unroll
+    for (int l = 0; l < GRIM_MAXL; ++l) {
+      cn[l] = 1;
+      if (l < n) {
+        const int c = (int)((pat >> l) & 1u) ^ (s & 1);
+        const ListVer lv = sh.lv[l][c][0];
+        cn[l] = lv.cnt;
+        options = options * (uint64_t)lv.wid;
+        if (options > 0xFFFFFFFFFFFFull) options = 0xFFFFFFFFFFFFull;
+      }
+    }
+    const bool cartesian = options < A.prm.opt_threshold;
+    if (cartesian) {  // the side's lists in LDS: a hit's position in the cartesian order needs its digits
+#pragma unroll
+      for (int l = 0; l < GRIM_MAXL; ++l)
+        if (l < n) {
+          const int c = (int)((pat >> l) & 1u) ^ (s & 1);
+          const ListVer lv = sh.lv[l][c][0];
+          if ((uint32_t)lane < lv.cnt) L.toks[l * 64 + lane] = S.rtok[lv.off + lane];
+        }
+      WAVE_SYNC();
+    }
+    const uint32_t nh = sh.hitn[s];
+    uint64_t item_base = 0, c_nbr = 0, c_freq = 0;
+    for (uint32_t h0 = 0; h0 < nh; h0 += 64) {
+      const uint32_t h = h0 + lane;
+      uint32_t node = GRIM_NONE;
+      uint64_t rank = 0;
+      if (h < nh) {
+        const uint32_t i = hits[(uint32_t)s * HCAP + h];
+        node = g.lab_nodes[i];
+        if (cartesian) {  // mixed-radix position, position 0 most significant (as the expansion counts, cutils.pyx:21-29)
+          const uint64_t key = g.lab_key[i];
+#pragma unroll
+          for (int l = 0; l < GRIM_MAXL; ++l)
+            if (l < n) {
+              const uint32_t al = ((uint32_t)(key >> (GRIM_ABITS * sl[l])) & 0xFFFu) - 1u;
+              uint32_t d = 0;
+              while (d < cn[l] && (uint32_t)L.toks[l * 64 + d] != al) ++d;
+              rank = rank * cn[l] + d;
+            }
+        } else {
+          rank = i - la;  // the label scan keeps nodes in label order (impute.py:947-981)
+        }
+      }
+      expand_chunk<false, true>(A, prior, L, st, node, full_nodes, g.a_start, g.a_nbr, 1.0, rank, item_base, c_nbr, c_freq);
+    }
+    store_top<false>(S, sh, L, st, s);
+    if (lane == 0) {
+      sh.cand_any[s] = (cartesian || nh > 0) ? 1 : 0;
+      sh.wctr[wave_id()][1] += c_nbr;
+      sh.wctr[wave_id()][2] += c_freq;
+    }
+  }
+  __syncthreads();
+  return true;
+}
+
 // Build the top list of phase `ph` (index into sh.ph_pat), side `side` into list row `row`.
 __device__ inline void build_side_plan_a(const DevArgs &A, WgShared &sh, const Slot &S, const double *prior, WaveTop &L,
                                          int ph, int side, int row) {
@@ -402,29 +587,43 @@ __device__ inline void build_side_plan_a(const DevArgs &A, WgShared &sh, const S
     }
   } else {
     // label scan: every node of the typed-loci label whose alleles all belong to this side's
-    // alternatives, in node-id order (impute.py:947-981, cutils.pyx:33-51)
+    // alternatives, in node-id order (impute.py:947-981, cutils.pyx:33-51).  The label's keys are streamed (lab_key);
+    // membership is one bit per position while the lists are as typed (sh.abits), a walk over the list otherwise.
     const bool full_nodes = (mask == g.full_mask);
+    const bool by_bits = ver == 0 && sh.ntok > 2u * (uint32_t)n;  // the bitsets exist and describe this version
     uint32_t a = g.lab_start[mask], b = g.lab_start[mask + 1];
-    for (uint32_t i0 = a; i0 < b; i0 += 64) {
+    for (uint32_t j0 = a; j0 < b; j0 += 64 * 4) {
+      uint64_t kq[4];  // four chunks of 64 keys in flight
+#pragma unroll
+      for (int q = 0; q < 4; ++q) kq[q] = j0 + 64u * q + lane < b ? g.lab_key[j0 + 64u * q + lane] : 0ull;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+      const uint32_t i0 = j0 + 64u * q;
+      if (i0 >= b) break;
       uint32_t i = i0 + lane;
-      uint32_t node = GRIM_NONE;
-      if (i < b) {
-        uint32_t nd = g.lab_nodes[i];
-        uint64_t key = g.node_key[nd];
-        bool ok = true;
+      bool ok = i < b;
+      if (ok) {
+        const uint64_t key = kq[q];
 #pragma unroll
         for (int l = 0; l < GRIM_MAXL; ++l) {
           if (l < n && ok) {
-            uint32_t al = (uint32_t)((key >> (GRIM_ABITS * sl[l])) & 0xFFF) - 1u;
-            bool hit = false;
-            for (uint32_t t = 0; t < cn[l]; ++t) hit |= (tok[to[l] + t] == al);
-            ok = hit;
+            const uint32_t al = (uint32_t)((key >> (GRIM_ABITS * sl[l])) & 0xFFF) - 1u;
+            if (by_bits) {
+              const int c = (int)((pat >> l) & 1u) ^ side;
+              ok = (sh.abits[l][c][(al >> 5) & 127u] >> (al & 31u)) & 1u;
+            } else {
+              bool hit = false;
+              for (uint32_t t = 0; t < cn[l]; ++t) hit |= (tok[to[l] + t] == al);
+              ok = hit;
+            }
           }
         }
-        if (ok) node = nd;
       }
-      if (__ballot(node != GRIM_NONE)) any_cand = true;
+      if (__ballot(ok) == 0) continue;
+      any_cand = true;
+      const uint32_t node = ok ? g.lab_nodes[i] : GRIM_NONE;
       expand_chunk<false>(A, prior, L, st, node, full_nodes, g.a_start, g.a_nbr, 1.0, 0, item_base, c_nbr, c_freq);
+      }
     }
   }
   store_top<false>(S, sh, L, st, row);

@@ -269,6 +269,12 @@ static int device_part(grim_stream *s, Chunk *c, uint32_t lo, uint32_t hi, bool 
       for (int k = 0; k < 4; ++k) s->st.counters[k] += ctr[k];
   }
   if (rc == -2) {
+    // subjects with tens of thousands of accepted pairs: give the table kernels' pair pool what the run asked for (up to
+    // 256 M records, 21 GB with the arrays sized by it) and run the same subjects again, before halving the batch
+    if (engine_batch_grow_pool(b, 256ull << 20)) {
+      ++s->st.reruns;
+      return device_part(s, c, lo, hi, whole, og_sorted);
+    }
     if (hi - lo <= 1) return -1;  // cannot happen: see grim_stream_open
     ++s->st.reruns;
     const uint32_t mid = lo + (hi - lo) / 2;

@@ -9,6 +9,9 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import harness
 
 gname, conf_path, subj_path, lo, hi = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5])
+if gname.startswith("wmda"):  # the synthetic WMDA-scale graph of tools/wmda_scale.py (built there on first use)
+    import wmda_scale
+    wmda_scale.ensure(int(gname[4:]))
 conf = json.load(open(conf_path))
 lines = [l.rstrip("\n") for l in open(subj_path)][lo:hi]
 t0 = time.perf_counter()
