@@ -254,26 +254,19 @@ __device__ __forceinline__ uint32_t nbr_count(const uint32_t *start, uint32_t i)
 }
 
 // ---- per-slot hash table over 64- or 128-bit keys (open addressing, insert-only) -----------------
-// k0 == 0 marks an empty slot, so callers OR GRIM_VALID into k0 (and into k1 when WIDE).
-template <bool WIDE>
-__device__ __forceinline__ uint32_t tab_insert(uint64_t *k0, uint64_t *k1, uint32_t mask, uint64_t a, uint64_t b) {
-  uint32_t s = (uint32_t)mix64(a ^ (b * 0x9E3779B97F4A7C15ull)) & mask;
+// k0 == 0 marks an empty slot, so callers OR GRIM_VALID into k0 (and into k1 when the key is 128 bits wide).
+// Single 64-bit insert: one CAS claims a slot; there is no second word to publish, hence nothing to wait for.  (128-bit
+// keys go through tab_insert_n only: its claim, publish and re-read steps sit in one loop body with one exit, so a lane
+// that waits for a sibling lane's second word can never be parked behind it.)
+__device__ __forceinline__ uint32_t tab_insert(uint64_t *k0, uint32_t mask, uint64_t a) {
+  uint32_t s = (uint32_t)mix64(a) & mask;
   for (;;) {
     uint64_t c0 = ALOAD(&k0[s]);
     if (c0 == 0) {
-      uint64_t old = atomicCAS((unsigned long long *)&k0[s], 0ull, (unsigned long long)a);
-      if (old == 0) {
-        if (WIDE) ASTORE(&k1[s], b);
-        return s;
-      }
-      c0 = old;
+      const uint64_t old = atomicCAS((unsigned long long *)&k0[s], 0ull, (unsigned long long)a);
+      c0 = old == 0 ? a : old;
     }
-    if (c0 == a) {
-      if (!WIDE) return s;
-      uint64_t c1 = ALOAD(&k1[s]);
-      if (c1 == 0) continue;  // claimed a moment ago, second word not published yet: look again
-      if (c1 == b) return s;
-    }
+    if (c0 == a) return s;
     s = (s + 1) & mask;
   }
 }

@@ -289,7 +289,7 @@ __device__ inline bool side_blocks(const DevArgs &A, WgShared &sh, const Slot &S
                   const uint32_t nd = g.lab_nodes[i];
                   if (node_passes(g, sp, tok, nd)) {
                     const uint64_t key = g.node_key[nd] & tbmask;
-                    const uint32_t slot = tab_insert<false>(pk, nullptr, pcap - 1, key | GRIM_VALID, 0);
+                    const uint32_t slot = tab_insert(pk, pcap - 1, key | GRIM_VALID);
                     if (pass == 0) {
                       atomicMin(&pp[slot], i);
                     } else if (ALOAD(&pp[slot]) == i) {

@@ -1,17 +1,29 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for profiles/ on a GPU box:  bash tools/profile_round.sh <tag>
-# (kernel-trace stats for config 2 and the mixed workload; FETCH_SIZE / WRITE_SIZE / SQ counters in separate passes)
+# Per workload (config2 = BASELINE configs[1], config3 = 1 M subjects, config4 = 4 populations x 100k, config5 = WMDA-scale
+# graph x 256 high-ambiguity subjects): kernel-trace stats of `bench.py --workload W`, and FETCH_SIZE / WRITE_SIZE in
+# SEPARATE --pmc passes (MI355X_MICROARCH.md, HBM section); SQ counters for config 2.  Summaries land in gpurun_out/prof_<tag>/.
 set -e
-TAG=${1:-r1}
+TAG=${1:-r2}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/full -o r -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $O/full.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/mixed -o r -- python3 $R/bench.py --workload mixed --steps 10 --warmup 2 --no-cpu-baseline > $O/mixed.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -o r -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -o r -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/write.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --kernel-trace --output-format csv -d $O/sq -o r -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/sq.log 2>&1
+B="--no-cpu-baseline --no-file"
+run() {  # name, rocprof options, bench options
+  rocprofv3 $2 --output-format csv -d $O/$1 -o r -- python3 $R/bench.py $3 > $O/$1.log 2>&1
+}
+run config2        "--kernel-trace --stats" "--steps 50 --warmup 5 $B"
+run config2_fetch  "--pmc FETCH_SIZE --kernel-trace" "--steps 10 --warmup 2 --kernel-steps 10 $B"
+run config2_write  "--pmc WRITE_SIZE --kernel-trace" "--steps 10 --warmup 2 --kernel-steps 10 $B"
+run config2_sq     "--pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --kernel-trace" "--steps 10 --warmup 2 --kernel-steps 10 $B"
+run config3        "--kernel-trace --stats" "--workload config3 --steps 3 --warmup 1 --kernel-steps 10 $B"
+run config4        "--kernel-trace --stats" "--workload config4 --steps 3 --warmup 1 --kernel-steps 5 $B"
+run config4_fetch  "--pmc FETCH_SIZE --kernel-trace" "--workload config4 --steps 2 --warmup 1 --kernel-steps 3 $B"
+run config4_write  "--pmc WRITE_SIZE --kernel-trace" "--workload config4 --steps 2 --warmup 1 --kernel-steps 3 $B"
+run config5        "--kernel-trace --stats" "--workload config5 --steps 3 --warmup 1 --kernel-steps 5 $B"
+run config5_fetch  "--pmc FETCH_SIZE --kernel-trace" "--workload config5 --steps 2 --warmup 1 --kernel-steps 3 $B"
+run config5_write  "--pmc WRITE_SIZE --kernel-trace" "--workload config5 --steps 2 --warmup 1 --kernel-steps 3 $B"
 cd $R
-python tools/pmc_traffic.py $O/fetch/r_counter_collection.csv $O/write/r_counter_collection.csv $O/pmc_traffic.json > /dev/null
-head -n 8 $O/full/r_kernel_stats.csv $O/mixed/r_kernel_stats.csv
+python tools/pmc_traffic.py $O $O/pmc_traffic.json > /dev/null
+for w in config2 config3 config4 config5; do echo "== $w"; head -n 9 $O/$w/r_kernel_stats.csv | cut -c1-120; done
