@@ -64,6 +64,12 @@ struct WgShared {
   uint16_t *qcell;   // [1024]
 };
 
+// the pair pass keeps its dedup table in LDS (over hist / qprob) when a pass accepted at most this many pairs
+#define GRIM_PASS_LDS_SLOTS 2048u
+#define GRIM_PASS_LDS_MAX 1400u
+typedef __attribute__((address_space(3))) uint64_t lds_u64;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+
 struct WgArena {
   uint32_t hist[16 * GRIM_WG];
   double qprob[1024];
@@ -270,78 +276,146 @@ __device__ inline uint32_t pair_pass(const DevArgs &A, WgShared &sh, const Slot 
     *maxp = mx;
     return tot;
   }
-  uint32_t cap = 64;
-  while (cap < 2 * np) cap <<= 1;
-  if (cap > A.tab_cap) cap = A.tab_cap;
-  const uint32_t mask = cap - 1;
-  for (uint32_t s = tid; s < cap; s += GRIM_WG) {
-    S.k0[s] = 0;
-    S.tmin[s] = GRIM_NONE;
-  }
-  __syncthreads();
-  // Pass 1: accepted pairs claim a slot per unordered entity pair; the smallest pair number wins it.
-  // GRIM_PAIR_NB pairs per thread and step so that their (dependent) top-list gathers and their table
-  // accesses are in flight together; the slot of every accepted pair is parked in sva for pass 2.
-  for (uint32_t f0 = tid; f0 < np; f0 += GRIM_PAIR_NB * GRIM_WG) {
-    PairRef pr[GRIM_PAIR_NB];
-    double w[GRIM_PAIR_NB];
+  // Stage A: the accepted pairs, in pair order, with their dedup key and probability (4 x 256 pairs per barrier
+  // round).  Everything after this works on the accepted list only: its length, not the number of scored pairs,
+  // sizes the dedup table -- which lives in LDS when the list is short, so that the common subject's dedup
+  // causes no HBM traffic at all (clearing a 2 x np-slot table per pass was 8.5 GB of writes per 100 k mixed subjects).
+  uint32_t *Af = S.sva, *Aslot = S.svb;
+  uint64_t *Akey = S.ska;
+  double *Aprob = (double *)S.skb;
+  uint32_t nA = 0;
+  for (uint32_t f0 = 0; f0 < np; f0 += 4 * GRIM_WG) {
+    bool on[4];
+    uint64_t key[4];
+    double prob[4];
 #pragma unroll
-    for (int q = 0; q < GRIM_PAIR_NB; ++q) {
-      const uint32_t f = f0 + q * GRIM_WG;
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t f = f0 + q * GRIM_WG + tid;
+      on[q] = false;
+      key[q] = 0;
+      prob[q] = 0.0;
       if (f < np) {
-        pr[q] = pair_ref(sh, S, f);
-        w[q] = prior[ENT_POP(pr[q].e1) * P + ENT_POP(pr[q].e2)];
+        const PairRef pr = pair_ref(sh, S, f);
+        const double w = prior[ENT_POP(pr.e1) * P + ENT_POP(pr.e2)];
+        if (pair_accept(eps, pr, w)) {
+          on[q] = true;
+          const uint32_t lo = pr.e1 < pr.e2 ? pr.e1 : pr.e2, hi = pr.e1 < pr.e2 ? pr.e2 : pr.e1;
+          key[q] = ((uint64_t)lo << 32) | hi | GRIM_VALID;
+          prob[q] = pair_prob(pr, w);
+        }
       }
     }
-    uint64_t key[GRIM_PAIR_NB], none[GRIM_PAIR_NB];
-    bool on[GRIM_PAIR_NB];
-    uint32_t slot[GRIM_PAIR_NB];
+    uint64_t m[4];
 #pragma unroll
-    for (int q = 0; q < GRIM_PAIR_NB; ++q) {
-      const uint32_t f = f0 + q * GRIM_WG;
-      key[q] = none[q] = 0;
-      on[q] = f < np && pair_accept(eps, pr[q], w[q]);
+    for (int q = 0; q < 4; ++q) {
+      m[q] = __ballot(on[q]);
+      if (lane_id() == 0) sh.tmp[q * GRIM_NWAVE + wave_id()] = (uint32_t)__popcll(m[q]);
+    }
+    __syncthreads();
+    uint32_t run = nA, base[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      for (int w2 = 0; w2 < GRIM_NWAVE; ++w2) {
+        if (w2 == wave_id()) base[q] = run;
+        run += sh.tmp[q * GRIM_NWAVE + w2];
+      }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
       if (on[q]) {
-        uint32_t lo = pr[q].e1 < pr[q].e2 ? pr[q].e1 : pr[q].e2, hi = pr[q].e1 < pr[q].e2 ? pr[q].e2 : pr[q].e1;
-        key[q] = ((uint64_t)lo << 32) | hi | GRIM_VALID;
+        const uint32_t pos = base[q] + (uint32_t)__popcll(m[q] & ((1ull << lane_id()) - 1ull));
+        Af[pos] = f0 + q * GRIM_WG + tid;
+        Akey[pos] = key[q];
+        Aprob[pos] = prob[q];
       }
+    nA = run;
+    __syncthreads();
+  }
+  // Stage B: one slot per unordered entity pair; the smallest position in the accepted list wins it
+  const bool in_lds = nA <= GRIM_PASS_LDS_MAX;
+  lds_u64 *lk = (lds_u64 *)sh.hist;
+  lds_u32 *lm = (lds_u32 *)sh.qprob;
+  uint32_t cap = 64;
+  if (in_lds) {
+    cap = GRIM_PASS_LDS_SLOTS;
+    for (uint32_t s = tid; s < cap; s += GRIM_WG) {
+      lk[s] = 0;
+      lm[s] = GRIM_NONE;
     }
-    tab_insert_n<false, GRIM_PAIR_NB>(S.k0, S.k1, mask, key, none, on, slot);
+  } else {
+    while (cap < 2 * nA) cap <<= 1;
+    if (cap > A.tab_cap) cap = A.tab_cap;
+    for (uint32_t s = tid; s < cap; s += GRIM_WG) {
+      S.k0[s] = 0;
+      S.tmin[s] = GRIM_NONE;
+    }
+  }
+  const uint32_t mask = cap - 1;
+  __syncthreads();
+  if (in_lds) {
+    for (uint32_t u = tid; u < nA; u += GRIM_WG) {
+      const uint64_t a = Akey[u];
+      uint32_t s = (uint32_t)mix64(a) & mask;
+      for (;;) {
+        uint64_t c = __hip_atomic_load(&lk[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (c == 0) {
+          uint64_t expect = 0;
+          c = __hip_atomic_compare_exchange_strong(&lk[s], &expect, a, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                  ? a : expect;
+        }
+        if (c == a) break;
+        s = (s + 1) & mask;
+      }
+      __hip_atomic_fetch_min(&lm[s], u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      Aslot[u] = s;
+    }
+  } else {
+    for (uint32_t u0 = tid; u0 < nA; u0 += GRIM_PAIR_NB * GRIM_WG) {
+      uint64_t key[GRIM_PAIR_NB], none[GRIM_PAIR_NB];
+      bool on[GRIM_PAIR_NB];
+      uint32_t slot[GRIM_PAIR_NB];
 #pragma unroll
-    for (int q = 0; q < GRIM_PAIR_NB; ++q) {
-      const uint32_t f = f0 + q * GRIM_WG;
-      if (on[q]) atomicMin(&S.tmin[slot[q]], f);
-      if (f < np) S.sva[f] = slot[q];
+      for (int q = 0; q < GRIM_PAIR_NB; ++q) {
+        const uint32_t u = u0 + q * GRIM_WG;
+        on[q] = u < nA;
+        none[q] = 0;
+        key[q] = on[q] ? Akey[u] : 0;
+      }
+      tab_insert_n<false, GRIM_PAIR_NB>(S.k0, S.k1, mask, key, none, on, slot);
+#pragma unroll
+      for (int q = 0; q < GRIM_PAIR_NB; ++q) {
+        const uint32_t u = u0 + q * GRIM_WG;
+        if (on[q]) {
+          atomicMin(&S.tmin[slot[q]], u);
+          Aslot[u] = slot[q];
+        }
+      }
     }
   }
   __syncthreads();
-  // Pass 2: winners in pair order, 4 x 256 pairs per barrier round
+  // Stage C: winners in pair order
   uint32_t nU = 0;
   double mx = 0.0;
-  for (uint32_t f0 = 0; f0 < np; f0 += 4 * GRIM_WG) {
+  for (uint32_t u0 = 0; u0 < nA; u0 += 4 * GRIM_WG) {
     bool win[4];
     double prob[4];
     uint32_t slot[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const uint32_t f = f0 + q * GRIM_WG + tid;
-      slot[q] = f < np ? S.sva[f] : GRIM_NONE;
+      const uint32_t u = u0 + q * GRIM_WG + tid;
+      slot[q] = u < nA ? Aslot[u] : GRIM_NONE;
+      prob[q] = u < nA ? Aprob[u] : 0.0;
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const uint32_t f = f0 + q * GRIM_WG + tid;
-      win[q] = slot[q] != GRIM_NONE && ALOAD(&S.tmin[slot[q]]) == f;
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      prob[q] = 0.0;
-      if (win[q]) {
-        PairRef pr = pair_ref(sh, S, f0 + q * GRIM_WG + tid);
-        prob[q] = pair_prob(pr, prior[ENT_POP(pr.e1) * P + ENT_POP(pr.e2)]);
-        if (prob[q] > mx) mx = prob[q];
-      }
+      const uint32_t u = u0 + q * GRIM_WG + tid;
+      win[q] = false;
+      if (slot[q] != GRIM_NONE) win[q] = (in_lds ? (uint32_t)lm[slot[q]] : ALOAD(&S.tmin[slot[q]])) == u;
+      if (win[q] && prob[q] > mx) mx = prob[q];
     }
     if (emit) {
+      uint32_t fq[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) fq[q] = win[q] ? Af[u0 + q * GRIM_WG + tid] : 0;
       uint64_t m[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -359,11 +433,9 @@ __device__ inline uint32_t pair_pass(const DevArgs &A, WgShared &sh, const Slot 
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         if (win[q]) {
-          uint32_t pos = base[q] + (uint32_t)__popcll(m[q] & ((1ull << lane_id()) - 1ull));
-          if (pos < A.pair_cap) {
-            S.Useq[pos] = f0 + q * GRIM_WG + tid;
-            S.Uprob[pos] = prob[q];
-          }
+          const uint32_t pos = base[q] + (uint32_t)__popcll(m[q] & ((1ull << lane_id()) - 1ull));
+          S.Useq[pos] = fq[q];
+          S.Uprob[pos] = prob[q];
         }
       nU = run;
       __syncthreads();
