@@ -101,6 +101,14 @@ def main():
             print(json.dumps(r), flush=True)
             out["runs"].append(r)
     path = os.path.join(ROOT, "profiles", "r2_ref_anchor.json")
+    if os.path.exists(path):  # keep the runs of earlier invocations (other workloads / sizes / process counts)
+        try:
+            old = json.load(open(path)).get("runs", [])
+        except ValueError:
+            old = []
+        key = lambda r: (r.get("config"), r.get("procs"), r.get("subjects"))
+        new = {key(r) for r in out["runs"]}
+        out["runs"] = [r for r in old if key(r) not in new] + out["runs"]
     json.dump(out, open(path, "w"), indent=1)
     print("wrote", path)
 
