@@ -26,12 +26,12 @@
 
 template <int N>
 struct WaveTab {
-  double prob[N];          // probabilities in sorted order
-  uint64_t klo[N], khi[N];
-  uint32_t tab[2 * N];     // hash slots: a local pair of the group; afterwards the group sums (double[N])
-  uint32_t skey[N];        // slot << TAB_SH | pair number, sorted (a wave's sort is instruction bound: 32-bit keys)
-  uint32_t uidx[N];        // pair number (record index inside the work item) of local pair i
-  uint16_t rs[N + 2];      // run starts
+  double prob[N];          // sum of the group local pair i represents
+  uint64_t klo[N], khi[N]; // group keys
+  uint32_t tab[2 * N];     // hash slots: the local pair that represents the group; afterwards the group sums (double[N])
+  uint32_t skey[N];        // first pair (record index) of the group local pair i represents
+  uint32_t uidx[N];        // pair number (record index inside the work item) of local pair i, increasing
+  uint16_t rs[N + 2];      // run j -> its representative
 };
 struct WaveTabT1 : WaveTab<TAB_N> {
   uint16_t hd[TAB_N];      // (one-wave kernel) head pair of run j
@@ -54,6 +54,7 @@ struct TabShared {
   uint32_t ng, overflow;
   TabWork work;
   uint32_t bcnt[TAB_MAXB + 1];
+  uint16_t *wcnt;   // [GRIM_NWAVE][nb]: pairs of bucket b in wave w's stretch of the item, then its cursor (split kernel)
 };
 
 // group key of a pair under `kind`: 0 genotype (impute.py:497-504), 1 unordered haplotype pair (impute.py:24-39),
@@ -92,79 +93,121 @@ __device__ __forceinline__ uint64_t tab_hash(uint64_t lo, uint64_t hi) {
 }
 
 // ---- one wave groups n <= N pairs --------------------------------------------------------------------------------------
-// In: W.uidx[0..n) = the pairs' numbers (any order, n <= N <= 256), rec = the work item's records.  Out: the number of groups
-// (runs); run j: first pair W.skey[W.rs[j]] & UM (the smallest number in the group = first seen), sum
-// ((double *)W.tab)[j].
+// In: W.uidx[0..n) = the pairs' numbers IN INCREASING ORDER (n <= N <= 256), rec = the work item's records.  Out: the number
+// of groups ("runs", in no particular order); run j: first pair W.skey[W.rs[j]] & UM (the smallest number in the group = first
+// seen), sum ((double *)W.tab)[j] = its probabilities added in pair order (impute.py:497-543: the reference's dict updates).
+// 64 pairs at a time, in order: find-or-insert of the pair's key into an LDS hash table whose slot names the group's
+// representative (the pair that claimed it); the lanes of a chunk that share a representative are found with ballots over
+// the representative's bits; round r adds the r-th of them to the group's sum -- so a sum receives its terms in lane = pair
+// order, one chunk after the other, without sorting anything.  (Until round 2's last day this was a bitonic sort of
+// (slot, pair) per bucket followed by run sums: 36 LDS compare-exchange stages for 256 keys.)
 template <int N>
 __device__ inline uint32_t wave_group_pairs(WaveTab<N> &W, int kind, int P, const PairRec *rec, uint32_t n) {
   const int lane = lane_id();
-  constexpr uint32_t UM = (1u << TAB_SH) - 1u;
-  for (uint32_t i = lane; i < n; i += 64) {
-    const PairRec r = rec[W.uidx[i]];
-    uint64_t lo, hi;
-    tab_key(kind, P, r, lo, hi);
-    W.klo[i] = lo;
-    W.khi[i] = hi;
-  }
+  const uint64_t lt = (1ull << lane) - 1ull;
   for (int i = lane; i < 2 * N; i += 64) W.tab[i] = GRIM_NONE;
-  uint32_t M = 64;  // sort size: a power of two >= n
-  while (M < n) M <<= 1;
+  for (uint32_t i = lane; i < n; i += 64) {
+    W.prob[i] = 0.0;          // sum of the group pair i represents
+    W.skey[i] = GRIM_NONE;    // ... and its first pair
+  }
   WAVE_SYNC();
   volatile uint32_t *tab = W.tab;
-  for (uint32_t i = lane; i < M; i += 64) {
-    uint32_t key = 0xFFFFFFFFu;
-    if (i < n) {
-      const uint64_t lo = W.klo[i], hi = W.khi[i];
+  uint32_t nruns = 0;
+  for (uint32_t c0 = 0; c0 < n; c0 += 64) {
+    const uint32_t i = c0 + lane;
+    const bool act = i < n;
+    uint32_t rep = 0, u = 0;
+    double p = 0.0;
+    uint64_t lo = 0, hi = 0;
+    if (act) {
+      u = W.uidx[i];
+      const PairRec r = rec[u];
+      p = r.prob;
+      tab_key(kind, P, r, lo, hi);
+      W.klo[i] = lo;
+      W.khi[i] = hi;
+    }
+    WAVE_SYNC();  // a probe compares against the keys of this chunk's representatives too
+    bool claimed = false;
+    if (act) {
       uint32_t h = (uint32_t)tab_hash(lo, hi) & (2 * N - 1);
       for (;;) {
         uint32_t cur = tab[h];
         if (cur == GRIM_NONE) {
           cur = atomicCAS(&W.tab[h], GRIM_NONE, i);
-          if (cur == GRIM_NONE) break;  // claimed: this pair stands for the group
+          if (cur == GRIM_NONE) {  // claimed: this pair stands for the group
+            claimed = true;
+            rep = i;
+            break;
+          }
         }
-        if (W.klo[cur] == lo && W.khi[cur] == hi) break;  // joins the group that pair stands for
+        if (W.klo[cur] == lo && W.khi[cur] == hi) {  // joins the group that pair stands for
+          rep = cur;
+          break;
+        }
         h = (h + 1) & (2 * N - 1);
       }
-      key = (h << TAB_SH) | W.uidx[i];
     }
-    W.skey[i] = key;
-  }
-  WAVE_SYNC();
-  for (uint32_t k = 2; k <= M; k <<= 1)
-    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      for (uint32_t q = lane; q < (M >> 1); q += 64) {
-        const uint32_t lo = ((q & ~(j - 1)) << 1) | (q & (j - 1)), hi = lo + j;
-        const bool up = (lo & k) == 0;
-        const uint32_t a = W.skey[lo], b = W.skey[hi];
-        if ((a > b) == up) {
-          W.skey[lo] = b;
-          W.skey[hi] = a;
-        }
-      }
+    // the lanes of this chunk with my representative (N <= 256: eight bits)
+    uint64_t same = __ballot(act);
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+      if ((N >> bit) == 0) break;
+      const bool sbit = (rep >> bit) & 1u;
+      const uint64_t m = __ballot(act && sbit);
+      same &= sbit ? m : ~m;
+    }
+    const uint32_t pos = (uint32_t)__popcll(same & lt);
+    if (act && pos == 0 && W.skey[rep] == GRIM_NONE) W.skey[rep] = u;  // chunks and lanes come in pair order
+    for (uint32_t r = 0; __ballot(act && pos >= r) != 0; ++r) {
+      if (act && pos == r) W.prob[rep] = W.prob[rep] + p;
       WAVE_SYNC();
     }
-  // runs of equal slot; probabilities in sorted order
-  uint32_t nruns = 0;
-  for (uint32_t r0 = 0; r0 < n; r0 += 64) {
-    const uint32_t r = r0 + lane;
-    bool start = false;
-    if (r < n) {
-      const uint32_t k = W.skey[r];
-      start = r == 0 || (W.skey[r - 1] >> TAB_SH) != (k >> TAB_SH);
-      W.prob[r] = rec[k & UM].prob;
-    }
-    const uint64_t m = __ballot(start);
-    if (start) W.rs[nruns + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)r;
-    nruns += (uint32_t)__popcll(m);
+    const uint64_t cm = __ballot(claimed);
+    if (claimed) W.rs[nruns + (uint32_t)__popcll(cm & lt)] = (uint16_t)i;
+    nruns += (uint32_t)__popcll(cm);
   }
-  if (lane == 0) W.rs[nruns] = (uint16_t)n;
   WAVE_SYNC();
   double *gsum = (double *)W.tab;  // the hash table is spent
-  for (uint32_t j = lane; j < nruns; j += 64) {
-    const uint32_t a = W.rs[j], b = W.rs[j + 1];
-    double s = W.prob[a];
-    for (uint32_t r = a + 1; r < b; ++r) s = s + W.prob[r];
-    gsum[j] = s;
+  for (uint32_t j = lane; j < nruns; j += 64) gsum[j] = W.prob[W.rs[j]];
+  WAVE_SYNC();
+  return nruns;
+}
+
+// population pairs of n <= N pairs (few groups, many members each: rounds would serialise): one LANE per cell walks the
+// pairs in order.  Same outputs as wave_group_pairs.
+template <int N>
+__device__ inline uint32_t wave_group_cells(WaveTab<N> &W, int P, const PairRec *rec, uint32_t n) {
+  const int lane = lane_id();
+  const uint64_t lt = (1ull << lane) - 1ull;
+  uint16_t *cellid = (uint16_t *)W.klo;
+  for (uint32_t i = lane; i < n; i += 64) {
+    const PairRec r = rec[W.uidx[i]];
+    const uint32_t a = ENT_POP(r.e1), b = ENT_POP(r.e2);
+    cellid[i] = (uint16_t)((a < b ? a : b) * (uint32_t)P + (a < b ? b : a));
+    W.prob[i] = r.prob;
+  }
+  WAVE_SYNC();
+  double *gsum = (double *)W.tab;
+  const uint32_t ncell = (uint32_t)(P * P);
+  uint32_t nruns = 0;
+  for (uint32_t c0 = 0; c0 < ncell; c0 += 64) {
+    const uint32_t cell = c0 + lane;
+    double s = 0.0;
+    uint32_t first = GRIM_NONE;
+    for (uint32_t i = 0; i < n; ++i)
+      if (cellid[i] == cell) {
+        if (first == GRIM_NONE) first = W.uidx[i];
+        s = s + W.prob[i];
+      }
+    const uint64_t m = __ballot(first != GRIM_NONE);
+    if (first != GRIM_NONE) {
+      const uint32_t j = nruns + (uint32_t)__popcll(m & lt);
+      W.rs[j] = (uint16_t)j;
+      W.skey[j] = first;
+      gsum[j] = s;
+    }
+    nruns += (uint32_t)__popcll(m);
   }
   WAVE_SYNC();
   return nruns;
@@ -197,7 +240,7 @@ __device__ inline void tables_wave(const DevArgs &A, WaveTabT1 &W, const TabWork
   WAVE_SYNC();
   // ---- population pairs (both pops files share the sums) -------------------------------------------------------------
   {
-    const uint32_t nq = wave_group_pairs(W, 3, P, rec, n);
+    const uint32_t nq = wave_group_cells(W, P, rec, n);
     for (uint32_t j = lane; j < nq; j += 64) W.hd[j] = (uint16_t)(W.skey[W.rs[j]] & UM);
     WAVE_SYNC();
     for (int t = 0; t < 2; ++t) {
@@ -723,6 +766,11 @@ __device__ inline void tab_split_table(const DevArgs &A, TabShared &sh, const Sl
   const int P = A.g.P;
   const PairRec *rec = A.ppool + w.off;
   const uint32_t nU = w.n;
+  if (nU > GRIM_NWAVE * 65472u) {  // a wave's stretch would not fit its 16-bit counts: this table goes the HBM way
+    if (tid == 0) A.taux[item].nb[t] = 0;
+    __syncthreads();
+    return;
+  }
   uint32_t nb = 1;
   while (nb * TAB_DIV < nU && nb < TAB_MAXB) nb <<= 1;
   for (uint32_t b = tid; b <= nb; b += GRIM_WG) sh.bcnt[b] = 0;
@@ -743,12 +791,37 @@ __device__ inline void tab_split_table(const DevArgs &A, TabShared &sh, const Sl
   __syncthreads();
   const uint32_t base = sh.bc[4], ubase = sh.bc[5];
   if (base == GRIM_NONE) return;
-  for (uint32_t u = tid; u < nU; u += GRIM_WG) {
+  // STABLE deal: wave w owns the w-th quarter of the item's pairs and keeps its own count / cursor per bucket, so a
+  // bucket receives its pairs in increasing pair number -- the bucket kernel then adds a group's probabilities in the
+  // reference's order without sorting.
+  const int wv = wave_id(), lane = lane_id();
+  const uint64_t lt = (1ull << lane) - 1ull;
+  const uint32_t q = ((nU + GRIM_NWAVE * 64 - 1) / (GRIM_NWAVE * 64)) * 64;  // pairs per wave, whole chunks of 64
+  uint16_t *wc = sh.wcnt;
+  {
+    uint32_t *wz = (uint32_t *)wc;
+    for (uint32_t k = tid; k < (GRIM_NWAVE * nb + 1) / 2; k += GRIM_WG) wz[k] = 0;
+  }
+  __syncthreads();
+  const uint32_t u0 = wv * q, u1 = u0 + q < nU ? u0 + q : nU;
+  for (uint32_t u = u0 + lane; u < u1; u += 64) {
     uint64_t lo, hi;
     tab_key(kind, P, rec[u], lo, hi);
     const uint32_t b = (uint32_t)(tab_hash(lo, hi) >> 40) & (nb - 1);  // high bits: the waves' slot hash uses the low ones
     S.svb[u] = b;
-    atomicAdd(&sh.bcnt[b], 1u);
+    const uint32_t k = wv * nb + b;
+    atomicAdd((uint32_t *)wc + (k >> 1), 1u << (16 * (k & 1)));  // q < 65536: a half never carries into its neighbour
+  }
+  __syncthreads();
+  // bucket sizes; per-wave counts become cursors relative to the bucket's start
+  for (uint32_t b2 = tid; b2 < nb; b2 += GRIM_WG) {
+    uint32_t run = 0;
+    for (int w2 = 0; w2 < GRIM_NWAVE; ++w2) {
+      const uint32_t c = wc[w2 * nb + b2];
+      wc[w2 * nb + b2] = (uint16_t)run;
+      run += c;
+    }
+    sh.bcnt[b2] = run;
   }
   __syncthreads();
   {  // exclusive scan in place: bcnt[b] = first position of bucket b
@@ -756,32 +829,72 @@ __device__ inline void tab_split_table(const DevArgs &A, TabShared &sh, const Sl
     uint32_t b0 = tid * per, b1 = b0 + per;
     if (b0 > nb) b0 = nb;
     if (b1 > nb) b1 = nb;
-    uint32_t sum = 0;
-    for (uint32_t b = b0; b < b1; ++b) sum += sh.bcnt[b];
+    uint32_t sum = 0, big = 0;
+    for (uint32_t b2 = b0; b2 < b1; ++b2) {
+      sum += sh.bcnt[b2];
+      big |= sh.bcnt[b2] > TAB_NB ? 1u : 0u;
+    }
     uint32_t total;
     uint32_t at = wg_excl_scan(sum, sh.tmp, total);
-    for (uint32_t b = b0; b < b1; ++b) {
-      const uint32_t c = sh.bcnt[b];
-      sh.bcnt[b] = at;
-      A.tboff[base + b] = at;
+    for (uint32_t b2 = b0; b2 < b1; ++b2) {
+      const uint32_t c = sh.bcnt[b2];
+      sh.bcnt[b2] = at;
+      A.tboff[base + b2] = at;
       at += c;
     }
-    if (tid == 0) A.tboff[base + nb] = nU;
+    if (tid == 0) {
+      A.tboff[base + nb] = nU;
+      sh.bcnt[nb] = nU;
+    }
+    if (big) atomicExch(&A.taux[item].overflow[t], 1u);  // a bucket beyond a wave's arena: the merge kernel takes the HBM path
   }
   __syncthreads();
-  // any order inside a bucket: the sort key of the bucket kernel carries the pair number
   uint32_t *dst = A.psort + (uint64_t)t * A.tstride + w.off;
-  for (uint32_t u = tid; u < nU; u += GRIM_WG) dst[atomicAdd(&sh.bcnt[S.svb[u]], 1u)] = u;
-  __syncthreads();  // bcnt[b] is now the END of bucket b
-  for (uint32_t b = tid; b < nb; b += GRIM_WG) {
+  int nbits = 0;
+  while ((1u << nbits) < nb) ++nbits;
+  // four chunks of 64 per step: their bucket loads and ballots are in flight together, only the cursor updates are serial
+  for (uint32_t c0 = u0; c0 < u1; c0 += 4 * 64) {
+    uint32_t bk[4];
+    bool act[4];
+    uint64_t same[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const uint32_t u = c0 + k * 64 + lane;
+      act[k] = u < u1;
+      bk[k] = act[k] ? S.svb[u] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) same[k] = __ballot(act[k]);
+    for (int bit = 0; bit < nbits; ++bit) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool sbit = (bk[k] >> bit) & 1u;
+        const uint64_t m = __ballot(act[k] && sbit);
+        same[k] &= sbit ? m : ~m;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (act[k]) {
+        const uint32_t rank = (uint32_t)__popcll(same[k] & lt), cnt = (uint32_t)__popcll(same[k]);
+        const uint32_t cur = wc[wv * nb + bk[k]];
+        const uint32_t pos = sh.bcnt[bk[k]] + cur + rank;
+        if (pos < nU) dst[pos] = c0 + k * 64 + lane;
+        if (rank + 1 == cnt) wc[wv * nb + bk[k]] = (uint16_t)(cur + cnt);
+      }
+      WAVE_SYNC();
+    }
+  }
+  __syncthreads();
+  for (uint32_t b2 = tid; b2 < nb; b2 += GRIM_WG) {
     TabUnit un;
     un.item = item;
-    un.tb = ((uint32_t)t << 28) | b;
+    un.tb = ((uint32_t)t << 28) | b2;
     un.off = w.off;
-    un.lo = b ? sh.bcnt[b - 1] : 0u;
-    un.n = sh.bcnt[b] - un.lo;
+    un.lo = sh.bcnt[b2];
+    un.n = sh.bcnt[b2 + 1] - un.lo;
     un.pad[0] = un.pad[1] = un.pad[2] = 0;
-    A.tunits[ubase + b] = un;
+    A.tunits[ubase + b2] = un;
   }
   __syncthreads();
 }
@@ -874,16 +987,21 @@ __device__ inline void tab_split_pops(const DevArgs &A, TabShared &sh, const Slo
 #ifndef GRIM_TAB_WG_PER_CU
 #define GRIM_TAB_WG_PER_CU 3
 #endif
+union SplitArena {  // the cell partition's radix sort and the bucket partition's per-wave cursors never overlap in time
+  WgArena a;
+  uint16_t wcnt[GRIM_NWAVE * TAB_MAXB];
+};
 __global__ __launch_bounds__(GRIM_WG, GRIM_TAB_WG_PER_CU) void grim_tables_split_kernel(DevArgs A) {
   __shared__ TabShared sh;
-  __shared__ WgArena arena;
+  __shared__ SplitArena arena;
   const int tid = threadIdx.x;
   const uint32_t n_items = A.queue[10];
   Slot S = make_slot(A, blockIdx.x);
   if (tid == 0) {
-    sh.hist = arena.hist;
-    sh.qprob = arena.qprob;
-    sh.qcell = arena.qcell;
+    sh.hist = arena.a.hist;
+    sh.qprob = arena.a.qprob;
+    sh.qcell = arena.a.qcell;
+    sh.wcnt = arena.wcnt;
   }
   __syncthreads();
   for (;;) {
