@@ -89,6 +89,14 @@ void grim_hostgraph_free(grim_hostgraph *h);
 int grim_graphgen_csv(const char *hpf_csv, const char *const *pops, const double *cutoff, uint32_t n_pops,
                       const char *const *locus_names, const uint32_t *locus_index, uint32_t n_locus_names, const char *nodes_csv,
                       const char *edges_csv, const char *top_links_csv, const char *info_csv, char *err, uint64_t err_cap);
+/* grim_hostgraph_from_hpf: both of the above in one call -- hpf.csv -> loaded arrays, the generator's texts handed to the
+ *   loader in memory (graph_freqs + Graph.build_graph, grim/grim.py:53-87, without the four files in between).  Each CSV
+ *   path may be NULL; a path that is given is written exactly as grim_graphgen_csv writes it. */
+grim_hostgraph *grim_hostgraph_from_hpf(grim_dict *dict, const char *full_loci, const char *hpf_csv, const char *const *pops,
+                                        const double *cutoff, uint32_t n_pops, const char *const *locus_names,
+                                        const uint32_t *locus_index, uint32_t n_locus_names, const char *nodes_csv,
+                                        const char *edges_csv, const char *top_links_csv, const char *info_csv, char *err,
+                                        uint64_t err_cap);
 
 /* ---- run parameters: the conf keys of run_impute_def.py:63-129 that reach the hot path ------ */
 typedef struct {

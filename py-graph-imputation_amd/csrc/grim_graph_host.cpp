@@ -116,13 +116,8 @@ struct grim_hostgraph {
 
 // ids_are_rows: every node id is the decimal text of its row number (what the generator writes), so an id is
 // parsed instead of looked up
-static bool read_pairs(const char *path, const std::unordered_map<std::string, uint32_t> &id_to_row, bool ids_are_rows,
-                       uint32_t n_nodes, std::vector<uint32_t> &a, std::vector<uint32_t> &b, std::string &err) {
-  std::string text;
-  if (!read_file(path, text)) {
-    err = std::string("cannot read ") + path;
-    return false;
-  }
+static bool read_pairs(const std::string &text, const char *path, const std::unordered_map<std::string, uint32_t> &id_to_row,
+                       bool ids_are_rows, uint32_t n_nodes, std::vector<uint32_t> &a, std::vector<uint32_t> &b, std::string &err) {
   size_t pos = 0;
   sv line;
   next_line(text, pos, line);  // header
@@ -161,14 +156,15 @@ static bool read_pairs(const char *path, const std::unordered_map<std::string, u
   return true;
 }
 
-extern "C" grim_hostgraph *grim_hostgraph_load_csv(grim_dict *d, const char *full_loci, const char *nodes_csv,
-                                                   const char *top_links_csv, const char *edges_csv, char *err, uint64_t err_cap) {
+// the three CSV texts -> arrays (the texts come from files, or straight from the generator: grim_hostgraph_from_hpf)
+static grim_hostgraph *load_texts(grim_dict *d, const char *full_loci, const std::string &nodes_text, const std::string &top_text,
+                                  const std::string &edges_text, const char *nodes_csv, const char *top_links_csv,
+                                  const char *edges_csv, char *err, uint64_t err_cap) {
   std::string e;
   auto fail = [&](const std::string &m) -> grim_hostgraph * {
     set_err(err, err_cap, m);
     return nullptr;
   };
-  if (!d || !full_loci || !nodes_csv || !top_links_csv || !edges_csv) return fail("grim_hostgraph_load_csv: null argument");
   const uint32_t nl = (uint32_t)strlen(full_loci);
   if (nl == 0 || nl > GRIM_MAXL || nl != d->n_loci) return fail("grim_hostgraph_load_csv: locus count mismatch");
   grim_hostgraph *h = new grim_hostgraph();
@@ -179,8 +175,7 @@ extern "C" grim_hostgraph *grim_hostgraph_load_csv(grim_dict *d, const char *ful
   std::unordered_map<std::string, uint32_t> id_to_row;
   bool ids_are_rows = true;
   {
-    std::string text;
-    if (!read_file(nodes_csv, text)) return fail(std::string("cannot read ") + nodes_csv);
+    const std::string &text = nodes_text;
     size_t pos = 0;
     sv line;
     next_line(text, pos, line);
@@ -236,7 +231,7 @@ extern "C" grim_hostgraph *grim_hostgraph_load_csv(grim_dict *d, const char *ful
   // ---- plan A: partial -> full (networkx_graph.py:71-88, 136-207) --------------------------------------
   {
     std::vector<uint32_t> n1, n2;
-    if (!read_pairs(top_links_csv, id_to_row, ids_are_rows, V, n1, n2, e)) return fail(e);
+    if (!read_pairs(top_text, top_links_csv, id_to_row, ids_are_rows, V, n1, n2, e)) return fail(e);
     std::vector<uint64_t> pr(n1.size());
     for (size_t i = 0; i < n1.size(); ++i) {
       const bool flip = h->node_mask[n1[i]] == h->full_mask;
@@ -255,7 +250,7 @@ extern "C" grim_hostgraph *grim_hostgraph_load_csv(grim_dict *d, const char *ful
   // ---- plan B: child -> connector(parent label, child) -> parents (networkx_graph.py:91-130) ------------
   {
     std::vector<uint32_t> n1, n2;
-    if (!read_pairs(edges_csv, id_to_row, ids_are_rows, V, n1, n2, e)) return fail(e);
+    if (!read_pairs(edges_text, edges_csv, id_to_row, ids_are_rows, V, n1, n2, e)) return fail(e);
     const size_t E = n1.size();
     std::vector<uint32_t> child(E), parent(E), conn(E);
     std::unordered_map<uint64_t, uint32_t> conn_id;  // (child, parent label) -> id, in order of first appearance
@@ -305,6 +300,21 @@ extern "C" grim_hostgraph *grim_hostgraph_load_csv(grim_dict *d, const char *ful
   return h;
 }
 
+extern "C" grim_hostgraph *grim_hostgraph_load_csv(grim_dict *d, const char *full_loci, const char *nodes_csv,
+                                                   const char *top_links_csv, const char *edges_csv, char *err, uint64_t err_cap) {
+  if (!d || !full_loci || !nodes_csv || !top_links_csv || !edges_csv) {
+    set_err(err, err_cap, "grim_hostgraph_load_csv: null argument");
+    return nullptr;
+  }
+  std::string nodes, top, edges;
+  for (auto pr : {std::make_pair(nodes_csv, &nodes), std::make_pair(top_links_csv, &top), std::make_pair(edges_csv, &edges)})
+    if (!read_file(pr.first, *pr.second)) {
+      set_err(err, err_cap, std::string("cannot read ") + pr.first);
+      return nullptr;
+    }
+  return load_texts(d, full_loci, nodes, top, edges, nodes_csv, top_links_csv, edges_csv, err, err_cap);
+}
+
 extern "C" int grim_hostgraph_desc(const grim_hostgraph *h, grim_graph_desc *out) {
   if (!h || !out) return -1;
   out->n_nodes = h->n_nodes;
@@ -348,16 +358,22 @@ void put_num(const Num &n, std::string &out) {
 
 }  // namespace
 
-extern "C" int grim_graphgen_csv(const char *hpf_csv, const char *const *pops, const double *cutoff, uint32_t n_pops,
-                                 const char *const *locus_names, const uint32_t *locus_index, uint32_t n_locus_names,
-                                 const char *nodes_csv, const char *edges_csv, const char *top_links_csv, const char *info_csv,
-                                 char *err, uint64_t err_cap) {
+// generator core.  Each of the four CSVs goes to its file when a path is given and stays in keep[k] when keep is not null
+// (k: 0 nodes, 1 edges, 2 top links, 3 info) -- the direct hpf -> arrays route hands the texts to the loader without files.
+static int graphgen_core(const char *hpf_csv, const char *const *pops, const double *cutoff, uint32_t n_pops,
+                         const char *const *locus_names, const uint32_t *locus_index, uint32_t n_locus_names,
+                         const char *nodes_csv, const char *edges_csv, const char *top_links_csv, const char *info_csv,
+                         std::string *keep, char *err, uint64_t err_cap) {
   auto fail = [&](const std::string &m) {
     set_err(err, err_cap, m);
     return -1;
   };
-  if (!hpf_csv || !pops || !cutoff || !locus_names || !locus_index || !nodes_csv || !edges_csv || !top_links_csv || !info_csv)
-    return fail("grim_graphgen_csv: null argument");
+  auto emit = [&](int k, const char *path, std::string &text) -> bool {
+    if (path && !write_file(path, text)) return false;
+    if (keep) keep[k].swap(text);
+    return true;
+  };
+  if (!hpf_csv || !pops || !cutoff || !locus_names || !locus_index) return fail("grim_graphgen_csv: null argument");
   // label characters: the sorted set of str(index) (generate_neo4j_multi_hpf.py:101-110)
   std::vector<std::string> chars;
   for (uint32_t i = 0; i < n_locus_names; ++i) chars.push_back(std::to_string(locus_index[i]));
@@ -564,7 +580,7 @@ extern "C" int grim_graphgen_csv(const char *hpf_csv, const char *const *pops, c
       out += "\r\n";
     }
   }
-  if (!write_file(nodes_csv, out)) return fail(std::string("cannot write ") + nodes_csv);
+  if (!emit(0, nodes_csv, out)) return fail(std::string("cannot write ") + nodes_csv);
   // ---- edges.csv (:82-97, 434-455): per child node, per contributing haplotype, per added locus -----------------
   out.clear();
   out += ":START_ID(HAPLOTYPE),:END_ID(HAPLOTYPE),CP:DOUBLE[],:TYPE\r\n";
@@ -602,7 +618,7 @@ extern "C" int grim_graphgen_csv(const char *hpf_csv, const char *const *pops, c
       }
     }
   }
-  if (!write_file(edges_csv, out)) return fail(std::string("cannot write ") + edges_csv);
+  if (!emit(1, edges_csv, out)) return fail(std::string("cannot write ") + edges_csv);
   // ---- top_links.csv (:305, 392-394, 470): ascending full-haplotype id per node ----------------------------------
   out.clear();
   out += ":START_ID(HAPLOTYPE),:END_ID(HAPLOTYPE),:TYPE\r\n";
@@ -616,7 +632,7 @@ extern "C" int grim_graphgen_csv(const char *hpf_csv, const char *const *pops, c
         out += ",TOP\r\n";
       }
   }
-  if (!write_file(top_links_csv, out)) return fail(std::string("cannot write ") + top_links_csv);
+  if (!emit(2, top_links_csv, out)) return fail(std::string("cannot write ") + top_links_csv);
   // ---- info_node.csv (:476-484) ----------------------------------------------------------------------------------
   out.clear();
   out += "INFO_NODE_ID:ID(INFO_NODE),populations:STRING[],INFO_NODE:LABEL\r\n1,";
@@ -625,6 +641,38 @@ extern "C" int grim_graphgen_csv(const char *hpf_csv, const char *const *pops, c
     out += pops[p];
   }
   out += ",INFO_NODE\r\n";
-  if (!write_file(info_csv, out)) return fail(std::string("cannot write ") + info_csv);
+  if (!emit(3, info_csv, out)) return fail(std::string("cannot write ") + info_csv);
   return 0;
+}
+
+extern "C" int grim_graphgen_csv(const char *hpf_csv, const char *const *pops, const double *cutoff, uint32_t n_pops,
+                                 const char *const *locus_names, const uint32_t *locus_index, uint32_t n_locus_names,
+                                 const char *nodes_csv, const char *edges_csv, const char *top_links_csv, const char *info_csv,
+                                 char *err, uint64_t err_cap) {
+  if (!nodes_csv || !edges_csv || !top_links_csv || !info_csv) {
+    set_err(err, err_cap, "grim_graphgen_csv: null argument");
+    return -1;
+  }
+  return graphgen_core(hpf_csv, pops, cutoff, n_pops, locus_names, locus_index, n_locus_names, nodes_csv, edges_csv, top_links_csv,
+                       info_csv, nullptr, err, err_cap);
+}
+
+// hpf.csv -> the loaded graph in one call: generate_graph (generate_neo4j_multi_hpf.py:209-486) feeding Graph.build_graph
+// (networkx_graph.py:42-213) without the four files in between.  The CSV paths may each be null; one that is given is
+// written as grim_graphgen_csv would (drop-in: other tools read them).
+extern "C" grim_hostgraph *grim_hostgraph_from_hpf(grim_dict *d, const char *full_loci, const char *hpf_csv, const char *const *pops,
+                                                   const double *cutoff, uint32_t n_pops, const char *const *locus_names,
+                                                   const uint32_t *locus_index, uint32_t n_locus_names, const char *nodes_csv,
+                                                   const char *edges_csv, const char *top_links_csv, const char *info_csv,
+                                                   char *err, uint64_t err_cap) {
+  if (!d || !full_loci) {
+    set_err(err, err_cap, "grim_hostgraph_from_hpf: null argument");
+    return nullptr;
+  }
+  std::string text[4];
+  if (graphgen_core(hpf_csv, pops, cutoff, n_pops, locus_names, locus_index, n_locus_names, nodes_csv, edges_csv, top_links_csv,
+                    info_csv, text, err, err_cap) != 0)
+    return nullptr;
+  return load_texts(d, full_loci, text[0], text[2], text[1], "nodes.csv (in memory)", "top_links.csv (in memory)",
+                    "edges.csv (in memory)", err, err_cap);
 }

@@ -46,6 +46,28 @@ def _num(x):
     return str(x)
 
 
+def generator_inputs(config_file, em_pop=None, em=False, use_default_path=False):
+    """-> (hpf file, populations, per-population cut-offs, loci_map) exactly as generate_graph derives them"""
+    base = os.path.dirname(os.path.realpath(__file__)) + "/" if use_default_path else ""
+    with open(config_file) as fh:
+        conf = json.load(fh)
+    if conf.get("Plan_A_Matrix", []):
+        raise NotImplementedError("Plan_A_Matrix (reduced-label graphs) is not supported by this build")
+    pops = em_pop if em_pop else conf.get("populations")
+    trim = conf.get("freq_trim_threshold")
+    counts_file = pathlib.Path(base + conf.get("pops_count_file", ""))
+    cutoff = {}
+    if em or not counts_file.is_file():
+        for p in pops:
+            cutoff[p] = trim
+    else:
+        with open(counts_file) as fh:
+            for line in fh:
+                p, cnt, _ratio = line.strip().split(",")
+                cutoff[p] = trim / float(cnt)
+    return base + conf.get("freq_file"), pops, [cutoff[p] for p in pops], dict(conf.get("loci_map"))
+
+
 def generate_graph(config_file="../conf/minimal-configuration-script.json", em_pop=None, em=False,
                    use_default_path=False, quiet=False, python_twin=False):
     base = ""

@@ -303,7 +303,7 @@ EXPORTS += [
     "grim_dict_count", "grim_tokenize", "grim_parsed_free", "grim_parsed_lines", "grim_parsed_subjects",
     "grim_parsed_subject_array", "grim_parsed_tokens", "grim_parsed_kinds", "grim_parsed_dev_index",
     "grim_parsed_n_races", "grim_parsed_race", "grim_parsed_id", "grim_parsed_set_kind", "grim_parsed_set_flags", "grim_format", "grim_text_get", "grim_text_free",
-    "grim_format_double", "grim_hostgraph_load_csv", "grim_hostgraph_desc", "grim_hostgraph_free", "grim_graphgen_csv",
+    "grim_format_double", "grim_hostgraph_load_csv", "grim_hostgraph_desc", "grim_hostgraph_free", "grim_graphgen_csv", "grim_hostgraph_from_hpf",
     "grim_parsed_allele", "grim_prior_matrix", "grim_stream_open", "grim_stream_write", "grim_stream_write_file", "grim_stream_finish",
     "grim_stream_error", "grim_stream_text", "grim_stream_get_stats", "grim_stream_n_unsupported", "grim_stream_unsupported",
     "grim_stream_next_records", "grim_stream_release_records", "grim_stream_free",
@@ -394,6 +394,10 @@ def host_lib():
     L.grim_graphgen_csv.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.c_uint32, C.POINTER(C.c_char_p),
                                     C.POINTER(C.c_uint32), C.c_uint32, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p,
                                     C.c_char_p, C.c_uint64]
+    L.grim_hostgraph_from_hpf.restype = C.c_void_p
+    L.grim_hostgraph_from_hpf.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.c_uint32,
+                                          C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.c_uint32, C.c_char_p, C.c_char_p, C.c_char_p,
+                                          C.c_char_p, C.c_char_p, C.c_uint64]
     L.grim_parsed_allele.restype = C.c_void_p
     L.grim_parsed_allele.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
     L.grim_prior_matrix.restype = C.c_int
@@ -574,6 +578,12 @@ def load_graph_csv(adict, full_loci, nodes_csv, top_links_csv, edges_csv):
     err = C.create_string_buffer(512)
     h = L.grim_hostgraph_load_csv(adict.h, full_loci.encode(), os.fsencode(nodes_csv), os.fsencode(top_links_csv),
                                   os.fsencode(edges_csv), err, len(err))
+    return _hostgraph_arrays(h, err)
+
+
+def _hostgraph_arrays(h, err):
+    """a grim_hostgraph handle -> dict of numpy arrays (copies); frees the handle"""
+    L = host_lib()
     if not h:
         msg = err.value.decode()
         if msg.startswith("graph: the highest-numbered vertex"):
@@ -617,6 +627,22 @@ def graphgen_csv(hpf_csv, pops, cutoffs, loci_map, nodes_csv, edges_csv, top_lin
                              err, len(err))
     if rc != 0:
         raise ValueError(err.value.decode())
+
+
+def graph_from_hpf(adict, full_loci, hpf_csv, pops, cutoffs, loci_map, csv_paths=None):
+    """grim_hostgraph_from_hpf: hpf.csv -> the loader's arrays, generator and loader back to back in memory.
+    csv_paths: optional (nodes, edges, top_links, info_node) paths to ALSO write the four CSVs (None entries are skipped)."""
+    L = host_lib()
+    err = C.create_string_buffer(512)
+    pop_arr = (C.c_char_p * len(pops))(*[p.encode() for p in pops])
+    cut_arr = (C.c_double * len(pops))(*[float(c) for c in cutoffs])
+    names = list(loci_map.keys())
+    name_arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+    idx_arr = (C.c_uint32 * len(names))(*[int(loci_map[n]) for n in names])
+    paths = [os.fsencode(p) if p else None for p in (csv_paths or (None, None, None, None))]
+    h = L.grim_hostgraph_from_hpf(adict.h, full_loci.encode(), os.fsencode(hpf_csv), pop_arr, cut_arr, len(pops), name_arr, idx_arr,
+                                  len(names), paths[0], paths[1], paths[2], paths[3], err, len(err))
+    return _hostgraph_arrays(h, err)
 
 
 def prior_spec(priority, unk_priors, count_by_prob=None):

@@ -47,6 +47,35 @@ def impute(conf_file="", hap_pop_pair=False, graph=None):
     return run_impute(conf_file, project_dir_graph, project_dir_in_file, hap_pop_pair, graph)
 
 
+def graph_from_freqs(conf_file="", for_em=False, em_pop=None, write_csv=False):
+    """graph_freqs() + the graph-loading half of impute() in one step: hpf.csv -> a Graph resident in memory, ready
+    for impute(conf, graph=g), without writing and re-reading nodes.csv / edges.csv / top_links.csv (not in the
+    reference: there the CSVs are the only interchange).  write_csv=True also leaves the four files as graph_freqs does."""
+    from .run_impute_def import load_config
+
+    use_default_path = conf_file == ""
+    if use_default_path:
+        conf_file = _packaged_conf()
+    hpf, pops, cutoffs, loci_map = generate_neo4j_multi_hpf.generator_inputs(conf_file, em_pop, for_em, use_default_path)
+    project_dir_graph = os.path.join(_PKG_ROOT, "graph_generation") + "/" if use_default_path else ""
+    config, _ = load_config(conf_file, project_dir_graph, _PKG_ROOT + "/" if use_default_path else "")
+    paths = None
+    if write_csv:
+        import json
+        import pathlib
+
+        with open(conf_file) as fh:
+            raw = json.load(fh)
+        csvdir = (os.path.dirname(os.path.realpath(generate_neo4j_multi_hpf.__file__)) + "/" if use_default_path else "") \
+            + raw.get("graph_files_path")
+        pathlib.Path(csvdir).mkdir(parents=True, exist_ok=True)
+        if csvdir[-1] != "/":
+            csvdir += "/"
+        paths = (csvdir + raw.get("node_csv_file"), csvdir + raw.get("edges_csv_file"), csvdir + raw.get("top_links_csv_file"),
+                 csvdir + raw.get("info_node_csv_file"))
+    return Graph(config).build_graph_from_hpf(hpf, pops, cutoffs, loci_map, paths)
+
+
 def impute_instance(config, graph, count_by_prob=None):
     return Imputation(graph, config, count_by_prob)
 

@@ -98,6 +98,15 @@ class Graph(object):
         self._dev = {}
         return self
 
+    def build_graph_from_hpf(self, hpf_file, populations, cutoffs, loci_map, csv_paths=None):
+        """hpf.csv -> this graph, generator and loader back to back inside the library (grim_hostgraph_from_hpf):
+        what graph_freqs() + build_graph() produce, without the four CSVs in between.  csv_paths = optional
+        (nodes, edges, top_links, info_node) to write them as well."""
+        self.arrays = nat.graph_from_hpf(self.adict, self.full_loci, hpf_file, populations, cutoffs, loci_map, csv_paths)
+        self.n_graph_alleles = [self.adict.count(s) for s in range(len(self.full_loci))]
+        self._dev = {}
+        return self
+
     def _build_graph_python(self, nodesFile, edgesFile, allEdgesFile):
         nl = len(self.full_loci)
         ids, keys, masks, freqs = [], [], [], []

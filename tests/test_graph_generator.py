@@ -203,3 +203,37 @@ def test_loader_arrays_equal_reference_dump(gname):
     filled = np.where(idx >= 0, real_starts[np.maximum(idx, 0)], 0)
     whole = np.concatenate([filled, starts[:-1], [V + n_conn]]).astype("<u4")
     check_arr(whole, ref["Whole_Neighbors_start"])
+
+
+@pytest.mark.parametrize("name", ["cau", "pop4"])
+def test_hpf_to_graph_without_the_csv_files(name, tmp_path, monkeypatch):
+    """grim.graph_from_freqs (grim_hostgraph_from_hpf: generator and loader back to back in memory) builds the arrays
+    graph_freqs() + Graph.build_graph build through the four files; with write_csv the files are the same bytes too"""
+    import numpy as np
+    from grim import grim
+    from grim.imputation.networkx_graph import Graph
+    from grim.run_impute_def import load_config
+
+    work = harness.ensure_graph(name)
+    conf = json.load(open(os.path.join(work, "graph_conf.json")))
+    conf["graph_files_path"] = str(tmp_path / "csv") + "/"
+    cpath = str(tmp_path / "direct.json")
+    json.dump(conf, open(cpath, "w"))
+    monkeypatch.chdir(work)
+    cfg, _ = load_config(os.path.join(work, "graph_conf.json"))
+    ref = Graph(cfg).build_graph(cfg["node_file"], cfg["top_links_file"], cfg["edges_file"])
+    direct = grim.graph_from_freqs(cpath)
+    assert not os.path.exists(tmp_path / "csv")  # nothing written
+    assert set(direct.arrays) == set(ref.arrays)
+    for k, v in ref.arrays.items():
+        if isinstance(v, np.ndarray):
+            assert direct.arrays[k].dtype == v.dtype and np.array_equal(direct.arrays[k], v), k
+        else:
+            assert direct.arrays[k] == v, k
+    assert direct.n_graph_alleles == ref.n_graph_alleles
+    for s in range(len(ref.full_loci)):  # same allele numbering: a subject tokenizes to the same ids on either graph
+        assert [ref.adict.name(s, i) for i in range(ref.n_graph_alleles[s])] == \
+               [direct.adict.name(s, i) for i in range(direct.n_graph_alleles[s])]
+    grim.graph_from_freqs(cpath, write_csv=True)
+    for f in ("nodes.csv", "edges.csv", "top_links.csv", "info_node.csv"):
+        assert open(tmp_path / "csv" / f, "rb").read() == open(os.path.join(work, "output", "csv", f), "rb").read(), f
