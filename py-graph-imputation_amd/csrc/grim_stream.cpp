@@ -229,7 +229,9 @@ static void run_tokenize(grim_stream *s, Chunk *c, uint32_t r) {
 // ---- stage: device ------------------------------------------------------------------------------------------------------
 // runs the subjects of lines [lo, hi) of the chunk; on a row-pool overflow the range is halved and both halves run
 // again (a single subject always fits: the pool is never smaller than one subject's worst case)
+static std::atomic<uint64_t> g_dbg_ns[4];  // GRIM_DEBUG_STREAM: device thread time in staging / load / run / fetch
 static int device_part(grim_stream *s, Chunk *c, uint32_t lo, uint32_t hi, bool whole, std::vector<uint32_t> &og_sorted) {
+  const auto tp0 = Clock::now();
   grim_batch *b = c->batch;
   const EngineHost *H = engine_batch_host(b);
   auto lb = [](const std::vector<uint32_t> &v, uint32_t x) { return (size_t)(std::lower_bound(v.begin(), v.end(), x) - v.begin()); };
@@ -245,6 +247,7 @@ static int device_part(grim_stream *s, Chunk *c, uint32_t lo, uint32_t hi, bool 
   uint64_t tok_used = 0;
   for (uint32_t r = 0; r < c->n_ranges; ++r)
     if (c->tr[r].n_tok && c->range_first_line[r] < hi && c->range_first_line[r + 1] > lo) tok_used = c->slab_off[r] + c->tr[r].n_tok;
+  const auto tp1 = Clock::now();
   int lrc;
   {
     // the race table only grows: a batch that holds fewer matrices than the table has gets all of them again
@@ -258,7 +261,12 @@ static int device_part(grim_stream *s, Chunk *c, uint32_t lo, uint32_t hi, bool 
     lrc = engine_batch_load(b, &ld);
   }
   if (lrc != 0) return -1;
+  const auto tp2 = Clock::now();
   const int rc = grim_batch_run(b);
+  const auto tp3 = Clock::now();
+  g_dbg_ns[0] += (uint64_t)(secs(tp0, tp1) * 1e9);
+  g_dbg_ns[1] += (uint64_t)(secs(tp1, tp2) * 1e9);
+  g_dbg_ns[2] += (uint64_t)(secs(tp2, tp3) * 1e9);
   if (getenv("GRIM_DEBUG_STREAM"))
     fprintf(stderr, "grim stream: chunk %llu lines [%u,%u) small %zu medium %zu general %u -> rc %d, rows %u (pool %llu)\n",
             (unsigned long long)c->index, lo, hi, s1 - s0, m1 - m0, ng, rc, grim_batch_total_rows(b), (unsigned long long)s->rows_per_chunk);
@@ -285,7 +293,9 @@ static int device_part(grim_stream *s, Chunk *c, uint32_t lo, uint32_t hi, bool 
   if (rc != 0) return -1;
   const uint32_t nrows = grim_batch_total_rows(b);
   if (whole) {
+    const auto tp4 = Clock::now();
     if (engine_batch_fetch(b, 0, c->n_lines, nullptr) != 0) return -1;
+    g_dbg_ns[3] += (uint64_t)(secs(tp4, Clock::now()) * 1e9);
     c->rows = engine_batch_host(b)->rows;
   } else {
     // a part of a chunk: its rows are appended to the chunk's own array and the row offsets of its subjects re-based
@@ -795,7 +805,7 @@ extern "C" grim_stream *grim_stream_open(grim_ctx *ctx, const grim_graph *g, con
   uint64_t rows = opts->rows_per_chunk ? opts->rows_per_chunk : 32ull * s->chunk_lines;
   // (one subject: at most four block grabs of the one-wave kernel, each max(rows needed, 64); more subjects than the pool
   //  holds are what the split-and-rerun is for)
-  const uint64_t floor_rows = (uint64_t)engine_small_stride(prm) * s->chunk_lines + 2 * per + 4 * 64 + 1024;
+  const uint64_t floor_rows = 2ull * engine_small_stride(prm) * s->chunk_lines + 2 * per + 4 * 64 + 1024;  // staging + its compacted copy
   if (rows < floor_rows && !(opts->rows_exact && opts->rows_per_chunk)) rows = floor_rows;
   if (rows > 0x7FFFFFF0ull) rows = 0x7FFFFFF0ull;
   s->rows_per_chunk = rows;
@@ -833,6 +843,9 @@ extern "C" grim_stream *grim_stream_open(grim_ctx *ctx, const grim_graph *g, con
 
 extern "C" void grim_stream_free(grim_stream *s) {
   if (!s) return;
+  if (getenv("GRIM_DEBUG_STREAM"))
+    fprintf(stderr, "grim stream: device thread ms: staging %.3f load %.3f run %.3f fetch %.3f over %llu chunks\n", g_dbg_ns[0] / 1e6,
+            g_dbg_ns[1] / 1e6, g_dbg_ns[2] / 1e6, g_dbg_ns[3] / 1e6, (unsigned long long)s->st.chunks);
   {
     std::lock_guard<std::mutex> lk(s->mu);
     s->stop = true;
