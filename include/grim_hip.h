@@ -197,7 +197,8 @@ int grim_batch_run_repeat(grim_batch *b, uint32_t n);
 int grim_batch_set_timing(grim_batch *b, int on);
 /* device time of the last grim_batch_run in timing mode (0 otherwise):
  * which = 0 all kernels, 1 half-wave + one-wave + general kernel, 2 plan-B/C kernel, 3 half-wave kernel, 4 general plan-A
- *         kernel, 5 one-wave kernel, 6 the table kernels (each from the kernels' own start/stop events);
+ *         kernel, 5 one-wave kernel, 6 the table kernels, 7 the half-wave kernel's row compaction (each from the kernels' own
+ *         start/stop events);
  * which | 0x10 = the mean of that figure over all runs since timing was switched on */
 double grim_batch_kernel_ms(const grim_batch *b, int which);
 /* algorithmic byte counters of the last run: [0] probes, [1] CSR neighbour ids,

@@ -174,6 +174,17 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
   return x;
 }
 
+// hash of a full-haplotype key for the half-wave kernel's table: three full-rate 24-bit multiplies over the key's 24-bit
+// pieces (two allele fields each) instead of mix64's two 64-bit ones -- the kernel is instruction-issue bound at scale
+__host__ __device__ __forceinline__ uint32_t fht_hash(uint64_t k) {
+  const uint32_t a = (uint32_t)k & 0xFFFFFFu, b = (uint32_t)(k >> 24) & 0xFFFFFFu, c = (uint32_t)(k >> 48);
+  uint32_t h = (a * 0x9E3779u) ^ (b * 0x85EBCBu) ^ (c * 0xC2B2AFu);
+  h ^= h >> 16;
+  h *= 0x2C1B3Du;
+  h ^= h >> 13;
+  return h;
+}
+
 // order-preserving map double -> uint64 (bigger double <=> bigger integer)
 __device__ __forceinline__ uint64_t f64_ord(double x) {
   uint64_t b = (uint64_t)__double_as_longlong(x);

@@ -148,25 +148,19 @@ __global__ __launch_bounds__(GRIM_WG, GRIM_WG_PER_CU) void grim_plan_a_kernel(De
 // the TOP of the row pool; most of that region stays empty (3 + ~1.3 of 13 rows per subject).  This kernel moves the
 // rows that exist into the bump-allocated part of the pool -- one allocation per wave of 64 subjects -- and re-bases the
 // subjects' row offsets, so that the batch's D2H copy carries 144 instead of 416 bytes of rows per subject.
-__global__ __launch_bounds__(64) void grim_small_compact_kernel(DevArgs A, const uint32_t *order_s, uint32_t n_small, uint32_t stage_base) {
+__global__ __launch_bounds__(64) void grim_small_compact_kernel(DevArgs A, const uint32_t *order_s, uint32_t n_small, uint32_t stage_base,
+                                                                 uint32_t stride) {
   const uint32_t w = blockIdx.x * 64 + threadIdx.x;
   const int lane = lane_id();
+  // a subject's staged rows are one run: [.umug, .umug.pops, .pmug.pops, its .pmug rows] from stage_base + w * stride
   uint32_t si = 0, cnt = 0;
-  uint32_t nr[GRIM_T_COUNT], off[GRIM_T_COUNT];
-#pragma unroll
-  for (int t = 0; t < GRIM_T_COUNT; ++t) nr[t] = off[t] = 0;
+  uint4 ro = make_uint4(0, 0, 0, 0), nr = make_uint4(0, 0, 0, 0);
   if (w < n_small) {
     si = order_s[w];
-    const grim_subject_result *r = A.res + si;
-#pragma unroll
-    for (int t = 0; t < GRIM_T_COUNT; ++t) {
-      const uint32_t n = r->n_rows[t], o = r->row_off[t];
-      if (n && o >= stage_base) {
-        nr[t] = n;
-        off[t] = o;
-        cnt += n;
-      }
-    }
+    const uint32_t *r = (const uint32_t *)(A.res + si);  // dwords 3..6 row_off, 7..10 n_rows
+    ro = make_uint4(r[3], r[4], r[5], r[6]);
+    nr = make_uint4(r[7], r[8], r[9], r[10]);
+    if ((nr.x | nr.y | nr.z | nr.w) != 0 && ro.z >= stage_base) cnt = GRIM_SMALL_ROWS_FIXED + nr.z;  // .z: GRIM_T_PMUG
   }
   uint32_t incl = cnt;  // inclusive prefix over the wave
   for (int d = 1; d < 64; d <<= 1) {
@@ -182,14 +176,29 @@ __global__ __launch_bounds__(64) void grim_small_compact_kernel(DevArgs A, const
     if (lane == 0) atomicExch(&A.counters[4], 1ull);
     return;
   }
-  uint32_t dst = base + incl - cnt;
-#pragma unroll
-  for (int t = 0; t < GRIM_T_COUNT; ++t) {
-    if (!nr[t]) continue;
-    A.res[si].row_off[t] = dst;
-    for (uint32_t k = 0; k < nr[t]; ++k) A.rows[dst + k] = A.rows[off[t] + k];
-    dst += nr[t];
+  if (cnt == 0) return;
+  const uint32_t src = stage_base + w * stride, dst = base + incl - cnt;
+  const uint4 *sp = (const uint4 *)(A.rows + src);
+  uint4 *dp = (uint4 *)(A.rows + dst);
+  uint32_t k = 0;
+  for (; k + 2 <= cnt; k += 2) {  // two rows (four 16-byte loads) in flight
+    const uint4 a0 = sp[2 * k], a1 = sp[2 * k + 1], a2 = sp[2 * k + 2], a3 = sp[2 * k + 3];
+    dp[2 * k] = a0;
+    dp[2 * k + 1] = a1;
+    dp[2 * k + 2] = a2;
+    dp[2 * k + 3] = a3;
   }
+  if (k < cnt) {
+    const uint4 a0 = sp[2 * k], a1 = sp[2 * k + 1];
+    dp[2 * k] = a0;
+    dp[2 * k + 1] = a1;
+  }
+  const uint32_t delta = dst - src;  // modulo 2^32: offsets move down
+  uint32_t *r = (uint32_t *)(A.res + si);
+  r[3] = ro.x + delta;
+  r[4] = ro.y + delta;
+  r[5] = ro.z + delta;
+  r[6] = ro.w + delta;
 }
 
 // zero the counters and work heads of a batch (one launch instead of several memsets)
@@ -204,14 +213,11 @@ __global__ void grim_reset_kernel(unsigned long long *counters, uint32_t *queue,
 __global__ void grim_finish_kernel(unsigned long long *state, unsigned long long *host_state, uint32_t row_head0, int after_plan_b) {
   __shared__ uint32_t pending;
   const uint32_t *queue = (const uint32_t *)(state + GRIM_NCTR);
-  if (threadIdx.x == 0) pending = after_plan_b ? 0u : queue[2] + queue[6];
+  // subjects waiting for Plan B/C, or accepted pairs waiting for the table kernels: a second stage follows
+  if (threadIdx.x == 0) pending = after_plan_b ? 0u : queue[2] + queue[6] + queue[9] + queue[10];
   for (int i = threadIdx.x; i < GRIM_NCTR + GRIM_NQ / 2; i += blockDim.x) host_state[i] = state[i];
   __syncthreads();
-  if (pending) {
-    // Plan B follows: its table kernels continue behind the work units of this stage
-    if (threadIdx.x == 0) ((uint32_t *)(state + GRIM_NCTR))[15] = ((uint32_t *)(state + GRIM_NCTR))[14];
-    return;
-  }
+  if (pending) return;  // the second stage works on this state
   for (int i = threadIdx.x; i < GRIM_NCTR; i += blockDim.x) state[i] = 0;
   if (threadIdx.x < GRIM_NQ) ((uint32_t *)(state + GRIM_NCTR))[threadIdx.x] = threadIdx.x == 1 ? row_head0 : 0u;
 }
@@ -276,8 +282,8 @@ struct grim_batch {
   bool timing;       // GRIM_TIMING=1 or grim_batch_set_timing: direct launches with per-kernel events instead of the graph replay
   hipGraphExec_t gexec;
   int graph_state;  // 0 not tried, 1 captured, -1 direct launches
-  float ms_a, ms_b, ms_s, ms_g, ms_m, ms_t;
-  double acc_ms[7];   // sums over the timed runs since timing was switched on (index = `which`)
+  float ms_a, ms_b, ms_s, ms_g, ms_m, ms_t, ms_c;  // ms_c: the half-wave kernel's row compaction
+  double acc_ms[8];   // sums over the timed runs since timing was switched on (index = `which`)
   uint32_t n_timed;
   uint32_t rows_used;
   unsigned long long counters[8];
@@ -442,7 +448,7 @@ extern "C" grim_graph *grim_graph_upload(grim_ctx *c, const grim_graph_desc *d) 
     for (uint32_t i = 0; i < d->n_nodes; ++i) {
       if (d->node_mask[i] != d->full_mask) continue;
       uint64_t k = d->node_key[i];
-      uint32_t h = (uint32_t)host_mix64(k) & (fcap - 1);
+      uint32_t h = fht_hash(k) & (fcap - 1);
       while (ft[h].key != 0 && ft[h].key != k) h = (h + 1) & (fcap - 1);
       ft[h].key = k;
       ft[h].f0 = d->freq[(size_t)i * d->n_pops];
@@ -954,9 +960,10 @@ static int enqueue_stage1(grim_batch *b, bool timing) {
     const dim3 cgrid((b->n_small + 63) / 64), cblock(64);
     if (timing)
       hipExtLaunchKernelGGL(grim_small_compact_kernel, cgrid, cblock, 0, c->stream, b->ev[12], b->ev[13], 0, A,
-                            (const uint32_t *)b->d_os, b->n_small, stage_base);
+                            (const uint32_t *)b->d_os, b->n_small, stage_base, b->small_stride);
     else
-      hipLaunchKernelGGL(grim_small_compact_kernel, cgrid, cblock, 0, c->stream, A, (const uint32_t *)b->d_os, b->n_small, stage_base);
+      hipLaunchKernelGGL(grim_small_compact_kernel, cgrid, cblock, 0, c->stream, A, (const uint32_t *)b->d_os, b->n_small, stage_base,
+                         b->small_stride);
   }
   if (b->n_medium) {
     static const int waves_per_cu = env_int("GRIM_MEDIUM_WAVES", GRIM_MEDIUM_WAVES_PER_CU);
@@ -977,7 +984,6 @@ static int enqueue_stage1(grim_batch *b, bool timing) {
     else
       hipLaunchKernelGGL(grim_plan_a_kernel, grid, block, 0, c->stream, A);
   }
-  if (b->n_general + b->n_medium) enqueue_tables(b, timing ? b->ev[8] : nullptr, timing ? b->ev[9] : nullptr);
   hipLaunchKernelGGL(grim_finish_kernel, dim3(1), dim3(GRIM_WG), 0, c->stream, A.counters, b->hstate, 0u, 0);
   return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -1002,7 +1008,7 @@ extern "C" int grim_batch_run(grim_batch *b) {
     c->err = "grim_batch_run: output row pool smaller than the half-wave kernel's fixed region";
     return -2;
   }
-  b->ms_s = b->ms_a = b->ms_g = b->ms_m = b->ms_t = 0;
+  b->ms_s = b->ms_a = b->ms_g = b->ms_m = b->ms_t = b->ms_c = 0;
   if (b->timing) {
     if (enqueue_stage1(b, true) != 0) {
       c->err = "grim_batch_run: kernel launch failed";
@@ -1012,12 +1018,7 @@ extern "C" int grim_batch_run(grim_batch *b) {
     if (b->n_small) HIPCHK(hipEventElapsedTime(&b->ms_s, b->ev[3], b->ev[5]), c, -1);
     if (b->n_medium) HIPCHK(hipEventElapsedTime(&b->ms_m, b->ev[0], b->ev[1]), c, -1);
     if (b->n_general + b->n_medium) HIPCHK(hipEventElapsedTime(&b->ms_g, b->ev[6], b->ev[7]), c, -1);
-    if (b->n_general + b->n_medium) HIPCHK(hipEventElapsedTime(&b->ms_t, b->ev[8], b->ev[9]), c, -1);
-    if (b->n_small) {  // the row compaction counts with the table kernels: work that exists to shape the output
-      float tc = 0;
-      HIPCHK(hipEventElapsedTime(&tc, b->ev[12], b->ev[13]), c, -1);
-      b->ms_t += tc;
-    }
+    if (b->n_small) HIPCHK(hipEventElapsedTime(&b->ms_c, b->ev[12], b->ev[13]), c, -1);
     b->ms_a = b->ms_s + b->ms_m + b->ms_g;
   } else {
     if (b->graph_state == 0) {
@@ -1046,12 +1047,16 @@ extern "C" int grim_batch_run(grim_batch *b) {
   b->ms_b = 0;
   uint32_t head[GRIM_NQ];
   memcpy(head, b->hstate + GRIM_NCTR, 4 * GRIM_NQ);
-  // ---- stage 2: Plan B / C only when the first stage left subjects for it ------------------------
-  if (A.prm.planb && head[2] + head[6] > 0) {
-    uint32_t grid = b->n_slots < head[2] + head[6] ? b->n_slots : head[2] + head[6];
-    if (grim_launch_plan_b(A, grid, c->stream, b->timing ? b->ev[4] : nullptr, b->timing ? b->ev[2] : nullptr) != 0) {
-      c->err = "grim_batch_run: plan-B launch failed";
-      return -1;
+  // ---- stage 2: Plan B / C when the first stage left subjects for it, then the table kernels ONCE over the accepted
+  // pairs both stages queued (a round after each stage cost their tails twice) -------------------------------------
+  const bool run_b = A.prm.planb && head[2] + head[6] > 0;
+  if (run_b || head[2] + head[6] + head[9] + head[10] > 0) {
+    if (run_b) {
+      uint32_t grid = b->n_slots < head[2] + head[6] ? b->n_slots : head[2] + head[6];
+      if (grim_launch_plan_b(A, grid, c->stream, b->timing ? b->ev[4] : nullptr, b->timing ? b->ev[2] : nullptr) != 0) {
+        c->err = "grim_batch_run: plan-B launch failed";
+        return -1;
+      }
     }
     enqueue_tables(b, b->timing ? b->ev[10] : nullptr, b->timing ? b->ev[11] : nullptr);
     hipLaunchKernelGGL(grim_finish_kernel, dim3(1), dim3(GRIM_WG), 0, c->stream, A.counters, b->hstate, 0u, 1);
@@ -1059,15 +1064,15 @@ extern "C" int grim_batch_run(grim_batch *b) {
     HIPCHK(hipStreamSynchronize(c->stream), c, -1);
     if (b->timing) {
       float t2 = 0;
-      HIPCHK(hipEventElapsedTime(&b->ms_b, b->ev[4], b->ev[2]), c, -1);
+      if (run_b) HIPCHK(hipEventElapsedTime(&b->ms_b, b->ev[4], b->ev[2]), c, -1);
       HIPCHK(hipEventElapsedTime(&t2, b->ev[10], b->ev[11]), c, -1);
       b->ms_t += t2;
     }
     memcpy(head, b->hstate + GRIM_NCTR, 4 * GRIM_NQ);
   }
   if (b->timing) {
-    const double v[7] = {(double)b->ms_a + b->ms_b + b->ms_t, b->ms_a, b->ms_b, b->ms_s, b->ms_g, b->ms_m, b->ms_t};
-    for (int k = 0; k < 7; ++k) b->acc_ms[k] += v[k];
+    const double v[8] = {(double)b->ms_a + b->ms_b + b->ms_t + b->ms_c, b->ms_a, b->ms_b, b->ms_s, b->ms_g, b->ms_m, b->ms_t, b->ms_c};
+    for (int k = 0; k < 8; ++k) b->acc_ms[k] += v[k];
     b->n_timed++;
   }
   static const int dbg_classes = env_int("GRIM_DEBUG_CLASSES", 0);
@@ -1111,7 +1116,7 @@ extern "C" double grim_batch_kernel_ms(const grim_batch *b, int which) {
   if (!b) return 0.0;
   if (which & 0x10) {  // mean over the timed runs since grim_batch_set_timing(b, 1)
     const int k = which & 0xF;
-    return (k < 7 && b->n_timed) ? b->acc_ms[k] / b->n_timed : 0.0;
+    return (k < 8 && b->n_timed) ? b->acc_ms[k] / b->n_timed : 0.0;
   }
   if (which == 1) return b->ms_a;
   if (which == 2) return b->ms_b;
@@ -1119,7 +1124,8 @@ extern "C" double grim_batch_kernel_ms(const grim_batch *b, int which) {
   if (which == 4) return b->ms_g;
   if (which == 5) return b->ms_m;
   if (which == 6) return b->ms_t;
-  return (double)b->ms_a + (double)b->ms_b + (double)b->ms_t;
+  if (which == 7) return b->ms_c;
+  return (double)b->ms_a + (double)b->ms_b + (double)b->ms_t + (double)b->ms_c;
 }
 
 extern "C" int grim_batch_counters(const grim_batch *cb, uint64_t out[4]) {

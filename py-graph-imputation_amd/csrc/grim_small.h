@@ -74,7 +74,7 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_a_small_kernel(DevArgs A, c
       const uint32_t slot = (l < 4 ? (words[5] >> (8 * l)) : words[6]) & 0xFFu;
       mykey |= (uint64_t)(t + 1u) << (GRIM_ABITS * slot);
     }
-    uint32_t h = (uint32_t)mix64(mykey) & g.fht_mask;
+    uint32_t h = fht_hash(mykey) & g.fht_mask;
     for (;;) {
       const FullEnt e = g.fht[h];
       if (e.key == mykey) { hit = true; f = e.f0; break; }
@@ -100,15 +100,19 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_a_small_kernel(DevArgs A, c
   const bool hi_half = (threadIdx.x & 32) != 0;
   double eps = 0.0;
   bool found = false;
+  bool acc = false;  // this lane's verdict at the step that decided its half
   {
     const uint64_t okb = __ballot(pair_ok);
     bool need_lo = (okb & 0xFFFFull) != 0, need_hi = ((okb >> 32) & 0xFFFFull) != 0;
     bool got_lo = false, got_hi = false;
     double eps_lo = 0.0, eps_hi = 0.0;
     auto step = [&](double e) {
-      const uint64_t b = __ballot(pair_ok && pair_accept(e, pr, w_prior));
-      if (need_lo && (b & 0xFFFFull)) { need_lo = false; got_lo = true; eps_lo = e; }
-      if (need_hi && ((b >> 32) & 0xFFFFull)) { need_hi = false; got_hi = true; eps_hi = e; }
+      const bool a = pair_ok && pair_accept(e, pr, w_prior);
+      const uint64_t b = __ballot(a);
+      const bool take_lo = need_lo && (b & 0xFFFFull), take_hi = need_hi && ((b >> 32) & 0xFFFFull);
+      if (take_lo) { need_lo = false; got_lo = true; eps_lo = e; }
+      if (take_hi) { need_hi = false; got_hi = true; eps_hi = e; }
+      if (hi_half ? take_hi : take_lo) acc = a;
     };
     // the first eight steps sit in scalar registers (loaded at kernel start, under the probe's latency)
 #pragma unroll
@@ -118,7 +122,6 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_a_small_kernel(DevArgs A, c
     eps = hi_half ? eps_hi : eps_lo;
     found = hi_half ? got_hi : got_lo;
   }
-  bool acc = pair_ok && found && pair_accept(eps, pr, w_prior);
   double prob = acc ? pair_prob(pr, w_prior) : 0.0;
   double mx = row16_max(prob);  // the 16 phase lanes of a half are one DPP row
   if (found && eps > 0.0) {
@@ -158,52 +161,51 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_a_small_kernel(DevArgs A, c
     }
   }
   if (!live) return;
-  // ---- output ----------------------------------------------------------------------------------
+  // ---- output, by lane role: one row store and one header store serve the whole half ------------------------------
+  //   hl  0..15  phase lanes       -> their .pmug row (rank-th of the subject's block)
+  //   hl 16..18                    -> the fixed rows: .umug, .umug.pops, .pmug.pops
+  //   hl 19..25                    -> the seven 8-byte pieces of the 56-byte result header
   const uint32_t off = row_base + w * row_stride;
-  const int first_lane = nU ? (__ffs(accmask) - 1) : 0;
-  if (nU > 0) {
-    const uint32_t n_pm = A.prm.out_haps ? (nU < A.prm.n_results ? nU : A.prm.n_results) : 0;
-    if (acc && A.prm.out_haps && rank < n_pm) {
+  const bool ok = nU > 0;
+  const int first_lane = ok ? (__ffs(accmask) - 1) : 0;
+  const uint32_t n_pm = (ok && A.prm.out_haps) ? (nU < A.prm.n_results ? nU : A.prm.n_results) : 0;
+  // the first accepted pair names the (one) genotype
+  const uint64_t ka = ((uint64_t)half_shfl_u((uint32_t)(mykey >> 32), first_lane) << 32) | half_shfl_u((uint32_t)mykey, first_lane);
+  const uint64_t kb = ((uint64_t)half_shfl_u((uint32_t)(key2 >> 32), first_lane) << 32) | half_shfl_u((uint32_t)key2, first_lane);
+  {
+    const int f = hl - 16;
+    const bool phase = hl < 16;
+    const bool wr = ok && (phase ? (acc && rank < n_pm) : (f < 3 && (f < 2 ? A.prm.out_muug != 0 : A.prm.out_haps != 0)));
+    if (wr) {
       grim_row r;
-      r.a = mykey;  // a found node's key is the key that found it
-      r.b = key2;
-      r.prob = prob;
-      r.popa = 0; r.popb = 0;
-      A.rows[off + GRIM_SMALL_ROWS_FIXED + rank] = r;
+      r.a = phase ? mykey : (f == 0 ? ka : 0ull);  // a found node's key is the key that found it
+      r.b = phase ? key2 : (f == 0 ? kb : 0ull);
+      r.prob = phase ? prob : total;
+      r.popa = 0;
+      r.popb = 0;
+      A.rows[off + (phase ? GRIM_SMALL_ROWS_FIXED + rank : (uint32_t)f)] = r;
     }
-    if (hl == first_lane) {
-      grim_row r;
-      r.a = mykey;
-      r.b = key2;
-      r.prob = total;
-      r.popa = 0; r.popb = 0;
-      if (A.prm.out_muug) A.rows[off + 0] = r;
-      r.a = 0; r.b = 0;
-      if (A.prm.out_muug) A.rows[off + 1] = r;
-      if (A.prm.out_haps) A.rows[off + 2] = r;
-      grim_subject_result out;
-      out.status = GRIM_ST_OK; out.plan = 'a'; out.reason = 0; out.plan_phased = 0;
-      out.n_pairs = nU;
-      out.n_genotypes = 1;
-      out.row_off[GRIM_T_UMUG] = off + 0;       out.n_rows[GRIM_T_UMUG] = A.prm.out_muug ? 1 : 0;
-      out.row_off[GRIM_T_UMUG_POPS] = off + 1;  out.n_rows[GRIM_T_UMUG_POPS] = (A.prm.out_muug && A.prm.n_pop_results) ? 1 : 0;
-      out.row_off[GRIM_T_PMUG] = off + GRIM_SMALL_ROWS_FIXED; out.n_rows[GRIM_T_PMUG] = n_pm;
-      out.row_off[GRIM_T_PMUG_POPS] = off + 2;  out.n_rows[GRIM_T_PMUG_POPS] = (A.prm.out_haps && A.prm.n_pop_results) ? 1 : 0;
-      if (!A.prm.n_results) out.n_rows[GRIM_T_UMUG] = 0;
-      out.max_prob = mx;
-      A.res[si] = out;
-    }
-  } else if (hl == 0) {
-    grim_subject_result out;
-    memset(&out, 0, sizeof(out));
-    out.plan = 'a';
-    if (A.prm.planb) {
-      out.status = GRIM_ST_UNSUPPORTED;  // overwritten by the plan-B kernel
-      out.reason = 2;
-      push_next(A, si, false);  // every locus typed: never a heavy one
-    } else {
-      out.status = GRIM_ST_MISS;
-    }
-    A.res[si] = out;
   }
+  if (hl >= 19 && hl < 26) {
+    const int j = hl - 19;
+    const uint8_t status = ok ? GRIM_ST_OK : (A.prm.planb ? GRIM_ST_UNSUPPORTED : GRIM_ST_MISS);  // UNSUPPORTED: the plan-B kernel overwrites it
+    const uint32_t head = (uint32_t)status | ((uint32_t)'a' << 8) | ((!ok && A.prm.planb) ? (2u << 16) : 0u);
+    const uint32_t n_um = (ok && A.prm.out_muug && A.prm.n_results) ? 1u : 0u;
+    const uint32_t n_up = (ok && A.prm.out_muug && A.prm.n_pop_results) ? 1u : 0u;
+    const uint32_t n_pp = (ok && A.prm.out_haps && A.prm.n_pop_results) ? 1u : 0u;
+    const uint64_t mxb = ok ? (uint64_t)__double_as_longlong(mx) : 0ull;
+    uint32_t lo, hi;
+    // dwords: 0 status/plan/reason/plan_phased  1 n_pairs  2 n_genotypes  3-6 row_off  7-10 n_rows  11 pad  12-13 max_prob
+    switch (j) {
+      case 0: lo = head; hi = ok ? nU : 0u; break;
+      case 1: lo = ok ? 1u : 0u; hi = ok ? off + 0 : 0u; break;
+      case 2: lo = ok ? off + 1 : 0u; hi = ok ? off + GRIM_SMALL_ROWS_FIXED : 0u; break;
+      case 3: lo = ok ? off + 2 : 0u; hi = n_um; break;
+      case 4: lo = n_up; hi = n_pm; break;
+      case 5: lo = n_pp; hi = 0u; break;
+      default: lo = (uint32_t)mxb; hi = (uint32_t)(mxb >> 32); break;
+    }
+    ((uint2 *)(A.res + si))[j] = make_uint2(lo, hi);
+  }
+  if (!ok && hl == 0 && A.prm.planb) push_next(A, si, false);  // every locus typed: never a heavy one
 }
