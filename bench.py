@@ -41,7 +41,7 @@ WORKLOADS = {
     "config2": ("cau", "BASELINE configs[1]: CAU 5-locus graph, 10k synthetic fully-typed subjects", 10000, "weak"),
     "config3": ("cau", "BASELINE configs[2]: CAU 5-locus graph, 1M synthetic fully-typed subjects (seed 1) split over the GPUs", 1000000, "strong"),
     "config4": ("pop4", "BASELINE configs[3]: 4-population 5-locus graph, 100k subjects with missing loci / ambiguity / recombinants (seed 3), MR priors", 100000, "strong"),
-    "config5": ("wmda", "BASELINE configs[4] (synthetic stand-in): WMDA-scale multi-population graph, high-ambiguity subjects, options threshold 1e6, 100 haplotypes in phase", 256, "strong"),
+    "config5": ("wmda", "BASELINE configs[4] (synthetic stand-in): WMDA-scale multi-population graph, high-ambiguity subjects, options threshold 1e6, 100 haplotypes in phase", 2048, "strong"),
     "mixed": ("cau", "CAU 5-locus graph, mixed subjects (ambiguity, missing loci, recombinants); not a BASELINE config", 10000, "weak"),
 }
 

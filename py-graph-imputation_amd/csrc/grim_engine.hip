@@ -263,6 +263,8 @@ struct grim_batch {
   uint64_t pool_cap, pool_bytes; // bucket starts, cells, work units, bucket order, groups, probabilities in cell order
   uint64_t pool_want;            // records the last run asked for when it ran out (the next load sizes the pool for it)
   uint64_t pool_asked;           // pair records the last run asked for
+  EngineLoad last_load;          // what the last engine_batch_load was given (priors not kept): a run that outgrew the pair pool loads again
+  bool in_retry;
   uint32_t priors_cap, priors_up;
   uint64_t row_limit;   // rows a run may use
   EnginePlan plan;      // what the arenas are laid out for
@@ -765,6 +767,8 @@ int engine_batch_load(grim_batch *b, const EngineLoad *ld) {
   b->n_small = ld->n_small;
   b->n_medium = ld->n_medium;
   b->n_general = ld->n_general;
+  b->last_load = *ld;
+  b->last_load.priors = nullptr;
   A.n_medium = ld->n_medium;
   A.n_work = ld->n_general;
   // the run state travels with the input: clean counters and work heads, rows of the half-wave kernel's fixed region taken
@@ -1097,6 +1101,16 @@ extern "C" int grim_batch_run(grim_batch *b) {
   }
 #endif
   if (b->counters[4] != 0 || head[1] > A.row_cap) {
+    if (!b->in_retry && engine_batch_grow_pool(b, 256ull << 20)) {
+      // the accepted pairs outgrew the table kernels' pool: size it for what this run asked for and run again (the
+      // inputs are still in the pinned arena; the prior matrices stay where they are)
+      b->in_retry = true;
+      EngineLoad ld = b->last_load;
+      int rc = engine_batch_load(b, &ld);
+      if (rc == 0) rc = grim_batch_run(b);
+      b->in_retry = false;
+      return rc;
+    }
     if (b->rows_used > A.row_cap) b->rows_used = A.row_cap;
     c->err = "grim_batch_run: output row pool exhausted (raise GRIM_ROW_CAP or lower the batch size)";
     return -2;
