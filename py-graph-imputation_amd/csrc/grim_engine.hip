@@ -787,8 +787,9 @@ int engine_batch_load(grim_batch *b, const EngineLoad *ld) {
     // subjects the host classified as heavy (high ambiguity) can accept tens of thousands of pairs each: half a subject's
     // worst case for the first 256 of them, so that a small batch of heavy subjects does not need a second run
     R += (uint64_t)(ld->n_general < 256u ? ld->n_general : 256u) * (A.pair_cap / 2);
+    const char *env_pool = getenv("GRIM_PAIR_POOL");  // tests: start small so that the grow-and-run-again path is taken
+    if (env_pool && atol(env_pool) > 0) R = (uint64_t)atol(env_pool);
     if (b->pool_want > R) R = b->pool_want;  // an earlier run of this batch ran out: it said how much it needed
-    static const long env_pool = getenv("GRIM_PAIR_POOL") ? atol(getenv("GRIM_PAIR_POOL")) : 0;
     if (R > 0x7FFFFFF0ull) R = 0x7FFFFFF0ull;
     const uint64_t items = 2ull * ld->n_subj < R / 256 + 1 ? 2ull * ld->n_subj : R / 256 + 1;  // bigger work items at most
     uint64_t cap_b = R / 8 + (items + 1) * ((uint64_t)P * P + 4), cap_u = R / 8 + items * 64 + 1024;  // buckets hold >= 24 pairs on average, two tables
@@ -812,7 +813,7 @@ int engine_batch_load(grim_batch *b, const EngineLoad *ld) {
     }
     b->pool_cap = R;
     A.ppool = (PairRec *)(b->d_pool + o_pool);
-    A.ppool_cap = (uint32_t)(env_pool > 0 && (uint64_t)env_pool < R ? (uint64_t)env_pool : R);
+    A.ppool_cap = (uint32_t)R;
     A.taux = (TabAux *)(b->d_pool + o_aux);
     A.tboff = (uint32_t *)(b->d_pool + o_boff);
     A.tcell = (CellRec *)(b->d_pool + o_cell);

@@ -95,6 +95,24 @@ def test_block_entry_points_equal_stream():
         assert a[k] == b[k], k
 
 
+def test_pair_pool_grows_and_the_run_repeats(monkeypatch):
+    """a pair pool far too small for the batch (GRIM_PAIR_POOL): the stream and the block entry points (grim_batch_run's
+    own retry) size it for what the run asked for, run again, and produce what a roomy pool produces"""
+    rows = synth.read_freqs(synth.CAU_FREQS)
+    conf = harness.base_conf(harness.POPS["pop4"])
+    conf["UNK_priors"] = "MR"
+    lines = synth.SubjectGen(rows, 77, pops=harness.POPS["pop4"]).mixed(3000)
+    imp, cfg = _imp("pop4", conf)
+    monkeypatch.delenv("GRIM_PAIR_POOL", raising=False)
+    roomy = imp.impute_lines(lines, cfg)
+    monkeypatch.setenv("GRIM_PAIR_POOL", "20000")
+    tight = imp.impute_lines(lines, cfg)
+    block = imp.impute_lines_block(lines, cfg)
+    for k in roomy:
+        assert roomy[k] == tight[k], k
+        assert roomy[k] == block[k], k
+
+
 def test_records_mode_matches_texts():
     """want_records: the raw result records of every chunk, in input order, while the texts are built as well"""
     import threading
