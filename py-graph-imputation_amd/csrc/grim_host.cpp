@@ -319,6 +319,125 @@ irregular:
   return K_PROBLEM_RAW;
 }
 
+// The regular line -- "L*x+L*y^..." with '/' lists, every locus and allele known, parts already in sorted order, no 'g' /
+// 'L' / 'U' clean-up needed -- in ONE pass over the bytes (the general path below costs ~50 memchr calls on 10-byte
+// ranges per line).  false: not that kind of line, nothing was changed, tokenise_gl decides.  Same outputs as
+// tokenise_gl on every line it accepts (tests/test_host_cpp.py holds both against the Python twin).
+struct GlClass {
+  uint8_t c[256];
+  GlClass() {
+    memset(c, 0, sizeof(c));
+    c[(uint8_t)'/'] = c[(uint8_t)'+'] = c[(uint8_t)'^'] = 1;
+    c[(uint8_t)'g'] = c[(uint8_t)'L'] = 2;
+    c[(uint8_t)'*'] = 3;
+  }
+};
+static const GlClass kGlClass;
+static bool tokenise_gl_fast(const DictSnap &D, sv gl, grim_subject &sj, uint16_t *tok, uint64_t tok_room, uint64_t &n_tok) {
+  const char *p = gl.data();
+  const size_t n = gl.size();
+  if (n == 0 || n > 60000) return false;
+  struct Al {
+    uint16_t off, len, star;
+  };
+  struct Side {
+    uint16_t off, len, a0, na;
+  };
+  Al al[96];
+  Side side[2 * GRIM_MAXL];
+  uint32_t n_al = 0, nparts = 0;
+  size_t i = 0;
+  for (;;) {
+    if (nparts >= GRIM_MAXL || nparts >= D.n_loci) return false;
+    const size_t ps = i;
+    for (int sd = 0; sd < 2; ++sd) {
+      Side &S = side[2 * nparts + sd];
+      S.off = (uint16_t)i;
+      S.a0 = (uint16_t)n_al;
+      S.na = 0;
+      for (;;) {
+        const size_t as = i;
+        size_t star = (size_t)-1;
+        while (i < n) {
+          const uint8_t k = kGlClass.c[(uint8_t)p[i]];  // 0: part of a name
+          if (k) {
+            if (k == 1) break;          // '/', '+', '^'
+            if (k == 2) return false;   // 'g', 'L': clean_up_gl has work to do
+            if (star == (size_t)-1) star = i - as;  // '*'
+          }
+          ++i;
+        }
+        if (i == as || n_al >= 96) return false;
+        al[n_al].off = (uint16_t)as;
+        al[n_al].len = (uint16_t)(i - as);
+        al[n_al].star = (uint16_t)(star == (size_t)-1 ? i - as : star);
+        ++n_al;
+        ++S.na;
+        if (i < n && p[i] == '/') {
+          ++i;
+          continue;
+        }
+        break;
+      }
+      S.len = (uint16_t)(i - S.off);
+      if (sd == 0) {
+        if (i >= n || p[i] != '+') return false;
+        ++i;
+      } else if (i < n && p[i] == '+') {
+        return false;
+      }
+    }
+    if (p[ps] == 'U' || p[i - 1] == 'U') return false;
+    ++nparts;
+    if (i >= n) break;
+    ++i;  // '^'
+    if (i >= n) return false;
+  }
+  // sorted(): the parts must already be in the order sorting each side's strings gives
+  for (uint32_t k = 0; k + 1 < nparts; ++k)
+    for (int sd = 0; sd < 2; ++sd) {
+      const Side &a = side[2 * k + sd], &b = side[2 * (k + 1) + sd];
+      if (p[a.off] < p[b.off]) continue;  // (the usual case: another locus, another first letter)
+      if (p[a.off] > p[b.off] || !(sv(p + a.off, a.len) < sv(p + b.off, b.len))) return false;
+    }
+  memset(&sj, 0, sizeof(sj));
+  const uint64_t tok_mark = n_tok;
+  uint32_t used = 0;
+  for (uint32_t k = 0; k < nparts; ++k) {
+    const Side &s1 = side[2 * k], &s2 = side[2 * k + 1];
+    const Al &f = al[s1.a0];
+    const sv locus(p + f.off, f.star);
+    for (uint32_t q = s1.a0; q < (uint32_t)s2.a0 + s2.na; ++q)
+      if (al[q].star != f.star || !DictSnap::same_bytes(p + al[q].off, locus.data(), f.star)) return n_tok = tok_mark, false;
+    const int32_t slot_i = D.find_locus(locus);
+    if (slot_i < 0 || ((used >> slot_i) & 1u)) return n_tok = tok_mark, false;
+    const uint32_t slot = (uint32_t)slot_i;
+    used |= 1u << slot;
+    sj.slot[k] = (uint8_t)slot;
+    if (s1.len == s2.len && DictSnap::same_bytes(p + s1.off, p + s2.off, s1.len)) sj.pad[0] |= (uint8_t)(1u << k);
+    for (int sd = 0; sd < 2; ++sd) {
+      const Side &S = sd ? s2 : s1;
+      const uint64_t start = n_tok;
+      uint32_t cnt = 0;
+      for (uint32_t q = S.a0; q < (uint32_t)S.a0 + S.na; ++q) {
+        const int32_t id = D.find(slot, sv(p + al[q].off, al[q].len));
+        if (id < 0) return n_tok = tok_mark, false;  // an allele the graph does not know: the general path numbers it
+        bool dup = false;
+        for (uint64_t t = start; t < n_tok && !dup; ++t) dup = tok[t] == (uint16_t)id;
+        if (!dup) {
+          if (n_tok >= tok_room) return n_tok = tok_mark, false;
+          tok[n_tok++] = (uint16_t)id;
+          ++cnt;
+        }
+      }
+      sj.cnt[k][sd] = (uint16_t)cnt;
+      sj.wid[k][sd] = S.na;
+    }
+  }
+  sj.n_loci = (uint8_t)nparts;
+  return true;
+}
+
 void tokenize_range(const TokParams &prm, const char *text, uint64_t lo, uint64_t hi, TokRange &R) {
   const DictSnap &D = *prm.snap;
   Scratch sc;
@@ -387,14 +506,20 @@ void tokenize_range(const TokParams &prm, const char *text, uint64_t lo, uint64_
         // worst case one token per two bytes
         if (tmp_tok.size() < gl.size() / 2 + 8) tmp_tok.resize(gl.size() / 2 + 8);
         uint64_t nt = 0;
-        kind = tokenise_gl(D, gl, prm.planb, sc, sj, tmp_tok.data(), tmp_tok.size(), nt, R.ov, R.ov_pool, line_no, tok_overflow);
+        if (tokenise_gl_fast(D, gl, sj, tmp_tok.data(), tmp_tok.size(), nt))
+          kind = K_DEV;
+        else
+          kind = tokenise_gl(D, gl, prm.planb, sc, sj, tmp_tok.data(), tmp_tok.size(), nt, R.ov, R.ov_pool, line_no, tok_overflow);
         if (kind == K_DEV) {
           sj.tok_off = (uint32_t)(R.tok_base + R.tok.size());
           R.tok.insert(R.tok.end(), tmp_tok.begin(), tmp_tok.begin() + nt);
           R.n_tok = R.tok.size();
         }
       } else {
-        kind = tokenise_gl(D, gl, prm.planb, sc, sj, R.tok_dst, R.tok_cap, R.n_tok, R.ov, R.ov_pool, line_no, tok_overflow);
+        if (tokenise_gl_fast(D, gl, sj, R.tok_dst, R.tok_cap, R.n_tok))
+          kind = K_DEV;
+        else
+          kind = tokenise_gl(D, gl, prm.planb, sc, sj, R.tok_dst, R.tok_cap, R.n_tok, R.ov, R.ov_pool, line_no, tok_overflow);
         if (kind == K_DEV) sj.tok_off = (uint32_t)(R.tok_base + tok_before);
       }
     }
