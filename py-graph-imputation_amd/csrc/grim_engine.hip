@@ -729,6 +729,13 @@ int engine_batch_grow_pool(grim_batch *b, uint64_t max_records) {
   return 1;
 }
 
+// what a batch learnt about its pair pool (0: the default sizing was enough) / the same lesson for a sibling batch of the
+// same stream, which will see the same kind of chunks: its next load sizes the pool accordingly instead of finding out
+uint64_t engine_batch_pool_want(const grim_batch *b) { return b ? b->pool_want : 0; }
+void engine_batch_hint_pool(grim_batch *b, uint64_t records) {
+  if (b && records > b->pool_want) b->pool_want = records;
+}
+
 int engine_batch_load(grim_batch *b, const EngineLoad *ld) {
   if (!b || !ld) return -1;
   grim_ctx *c = b->ctx;

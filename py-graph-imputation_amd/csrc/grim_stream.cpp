@@ -118,6 +118,7 @@ struct grim_stream {
   uint32_t n_pops = 0;
   uint32_t chunk_lines = 0, granule = 1024, n_threads = 1, depth = 0;
   uint64_t rows_per_chunk = 0;
+  uint64_t pool_hint = 0;  // pair-pool records a chunk of this stream needed (device thread only)
 
   std::vector<std::unique_ptr<Chunk>> chunks;  // the `depth` slots
   Chunk *filling = nullptr;
@@ -291,6 +292,10 @@ static int device_part(grim_stream *s, Chunk *c, uint32_t lo, uint32_t hi, bool 
     return device_part(s, c, mid, hi, false, og_sorted);
   }
   if (rc != 0) return -1;
+  if (engine_batch_pool_want(b) > s->pool_hint) {  // this batch had to grow its pair pool: the other slots will meet the same chunks
+    s->pool_hint = engine_batch_pool_want(b);
+    for (auto &o : s->chunks) engine_batch_hint_pool(o->batch, s->pool_hint);
+  }
   const uint32_t nrows = grim_batch_total_rows(b);
   if (whole) {
     const auto tp4 = Clock::now();

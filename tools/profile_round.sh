@@ -21,7 +21,7 @@ run config3        "--kernel-trace --stats" "--workload config3 --steps 3 --warm
 run config4        "--kernel-trace --stats" "--workload config4 --steps 3 --warmup 1 --kernel-steps 5 $B"
 run config4_fetch  "--pmc FETCH_SIZE --kernel-trace" "--workload config4 --steps 2 --warmup 1 --kernel-steps 3 $B"
 run config4_write  "--pmc WRITE_SIZE --kernel-trace" "--workload config4 --steps 2 --warmup 1 --kernel-steps 3 $B"
-run config5        "--kernel-trace --stats" "--workload config5 --steps 3 --warmup 1 --kernel-steps 5 $B"
+run config5        "--kernel-trace --stats" "--workload config5 --steps 3 --warmup 2 --kernel-steps 5 $B"
 run config5_fetch  "--pmc FETCH_SIZE --kernel-trace" "--workload config5 --steps 2 --warmup 1 --kernel-steps 3 $B"
 run config5_write  "--pmc WRITE_SIZE --kernel-trace" "--workload config5 --steps 2 --warmup 1 --kernel-steps 3 $B"
 cd $R
