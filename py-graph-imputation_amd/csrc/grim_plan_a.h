@@ -280,7 +280,22 @@ __device__ inline bool shared_scan_wanted(const DevArgs &A, WgShared &sh) {
 
 // All sides of the subject by one scan.  Returns false when a side found more nodes than the slot holds (the caller opens
 // the sides one by one then).  All threads call.
+#ifdef GRIM_STAMPS  // (diagnostic build) workgroup time of the two phases, added to the stage timers 13 / 14
+#define SCAN_STAMP(k)                                                                         \
+  do {                                                                                        \
+    if (threadIdx.x == 0) {                                                                   \
+      const unsigned long long _n = wall_clock64();                                            \
+      atomicAdd(&A.counters[GRIM_STAMP_BASE + (k)], _n - _scan_t0);                           \
+      _scan_t0 = _n;                                                                          \
+    }                                                                                         \
+  } while (0)
+#else
+#define SCAN_STAMP(k)
+#endif
 __device__ inline bool build_sides_shared_scan(const DevArgs &A, WgShared &sh, const Slot &S, const double *prior, WaveTop *wt) {
+#ifdef GRIM_STAMPS
+  unsigned long long _scan_t0 = wall_clock64();
+#endif
   const DevGraph &g = A.g;
   const grim_subject &sj = sh.subj;
   const int tid = threadIdx.x, lane = lane_id();
@@ -307,6 +322,31 @@ __device__ inline bool build_sides_shared_scan(const DevArgs &A, WgShared &sh, c
     sh.hitreq[tid] = r;
   }
   __syncthreads();
+  // Two LDS tables for the scan, in the arena the top-K work areas use afterwards:
+  //   comb[l][a >> 4]: two bits per allele id a -- is it in column 0 / column 1 of position l (one read per position);
+  //   smatch[bits]   : which sides a node with these ten membership bits belongs to (a side asks for one column per
+  //                    position), so a node that passes costs one read plus a step per side that takes it (0-2 as a
+  //                    rule) instead of a compare against every side.
+  uint32_t *comb = sh.hist;                    // [GRIM_MAXL][256]
+  uint32_t *smatch = sh.hist + GRIM_MAXL * 256;  // [1 << 2n] <= 1024
+  for (int k = tid; k < GRIM_MAXL * 256; k += GRIM_WG) {
+    const int l = k >> 8, w16 = k & 255;  // alleles 16 * w16 .. 16 * w16 + 15
+    uint32_t v = 0;
+    if (l < n) {
+      const uint32_t h0 = (sh.abits[l][0][w16 >> 1] >> (16 * (w16 & 1))) & 0xFFFFu, h1 = (sh.abits[l][1][w16 >> 1] >> (16 * (w16 & 1))) & 0xFFFFu;
+      for (int a = 0; a < 16; ++a) v |= (((h0 >> a) & 1u) | (((h1 >> a) & 1u) << 1)) << (2 * a);
+    }
+    comb[k] = v;
+  }
+  for (uint32_t bits = tid; bits < (1u << (2 * n)); bits += GRIM_WG) {
+    uint32_t m = 0;
+    for (int s = 0; s < nsides; ++s) {
+      const uint32_t r = sh.hitreq[s];
+      m |= ((bits & r) == r ? 1u : 0u) << s;
+    }
+    smatch[bits] = m;
+  }
+  __syncthreads();
   constexpr int NK = 8;
   for (uint32_t i0 = la; i0 < lb; i0 += GRIM_WG * NK) {
     uint64_t key[NK];
@@ -325,25 +365,24 @@ __device__ inline bool build_sides_shared_scan(const DevArgs &A, WgShared &sh, c
       for (int l = 0; l < GRIM_MAXL; ++l)
         if (l < n) {
           const uint32_t al = ((uint32_t)(key[q] >> (GRIM_ABITS * sl[l])) & 0xFFFu) - 1u;
-          const uint32_t b0 = (sh.abits[l][0][(al >> 5) & 127u] >> (al & 31u)) & 1u, b1 = (sh.abits[l][1][(al >> 5) & 127u] >> (al & 31u)) & 1u;
-          bits |= (b0 << (2 * l)) | (b1 << (2 * l + 1));
-          possible = possible && (b0 | b1);
+          const uint32_t two = (comb[l * 256 + ((al >> 4) & 255u)] >> (2 * (al & 15u))) & 3u;
+          bits |= two << (2 * l);
+          possible = possible && two != 0;
         }
       if (!possible) continue;  // some position matches neither column: no side takes the node (nearly every node)
-      for (int s = 0; s < nsides; ++s) {
-        const uint32_t r = sh.hitreq[s];
-        if ((bits & r) == r) {
-          const uint32_t pos = atomicAdd(&sh.hitn[s], 1u);
-          if (pos < HCAP)
-            hits[(uint32_t)s * HCAP + pos] = i;
-          else
-            sh.bc[7] = 1;
-        }
+      for (uint32_t m = smatch[bits]; m; m &= m - 1) {
+        const uint32_t s = (uint32_t)__builtin_ctz(m);
+        const uint32_t pos = atomicAdd(&sh.hitn[s], 1u);
+        if (pos < HCAP)
+          hits[s * HCAP + pos] = i;
+        else
+          sh.bc[7] = 1;
       }
     }
   }
   __syncthreads();
   if (sh.bc[7]) return false;
+  SCAN_STAMP(13);
   if (tid == 0) sh.wctr[0][0] += ((uint64_t)(lb - la) * 3) / 4;  // a scanned node costs 12 bytes (key + id), a probe 16
   // ---- phase 2: a wave per side pushes the side's nodes through the ranked top-K ----------------------------------------
   const bool full_nodes = (mask == g.full_mask);
@@ -409,6 +448,7 @@ __device__ inline bool build_sides_shared_scan(const DevArgs &A, WgShared &sh, c
     }
   }
   __syncthreads();
+  SCAN_STAMP(14);
   return true;
 }
 
