@@ -198,20 +198,80 @@ __device__ inline uint32_t pair_offsets(WgShared &sh) {
   return sh.poff[GRIM_MAXPH];
 }
 
+// ---- the two top lists of ONE phase in LDS (over the radix-histogram area, free during the pair stage) -----------------
+// The pair loops below go phase by phase: 2 x <=128 entries are staged once and the phase's <=16 384 pairs read them from
+// LDS -- five gathers per pair from per-workgroup HBM scratch were the cost of the pair stage.
+#define GRIM_TILE_MIN 8192u  // scored pairs from which the pair stage goes phase by phase through LDS tiles
+struct PairTile {
+  double p1[GRIM_TOPCAP], p2[GRIM_TOPCAP], m2[GRIM_TOPCAP];
+  uint32_t e1[GRIM_TOPCAP], e2[GRIM_TOPCAP];
+  uint64_t bm[GRIM_TOPCAP * GRIM_TOPCAP / 64];  // accepted pairs of the phase, one bit each
+  double lp[64];                                 // the prior matrix when it has at most 64 cells
+};
+static_assert(sizeof(PairTile) <= 16 * GRIM_WG * 4, "the phase tile lives in the histogram area");
+
+// all threads; the caller synchronises before reading the tile and again before the next tile_load
+__device__ __forceinline__ void tile_load(PairTile &T, const WgShared &sh, const Slot &S, int i) {
+  const uint32_t n1 = sh.Tn[2 * i], n2 = sh.Tn[2 * i + 1];
+  for (uint32_t t = threadIdx.x; t < n1; t += GRIM_WG) {
+    T.p1[t] = S.Tp[(2 * i) * GRIM_TOPCAP + t];
+    T.e1[t] = S.Te[(2 * i) * GRIM_TOPCAP + t];
+  }
+  for (uint32_t t = threadIdx.x; t < n2; t += GRIM_WG) {
+    T.p2[t] = S.Tp[(2 * i + 1) * GRIM_TOPCAP + t];
+    T.m2[t] = S.Tm[(2 * i + 1) * GRIM_TOPCAP + t];
+    T.e2[t] = S.Te[(2 * i + 1) * GRIM_TOPCAP + t];
+  }
+}
+__device__ __forceinline__ PairRef tile_pair(const PairTile &T, uint32_t r, uint32_t n2, uint32_t magic) {
+  const uint32_t h = n2 > 1 ? __umulhi(r, magic) : r, k = r - h * n2;  // exact for r < 2^14, n2 <= 128 (magic = 2^32 / n2 + 1)
+  PairRef pr;
+  pr.p1 = T.p1[h];
+  pr.e1 = T.e1[h];
+  pr.p2 = T.p2[k];
+  pr.m2 = T.m2[k];
+  pr.e2 = T.e2[k];
+  return pr;
+}
+__device__ __forceinline__ uint32_t tile_magic(uint32_t n2) { return n2 > 1 ? (uint32_t)(0x100000000ull / n2) + 1u : 0u; }
+
 // first ladder index at which ANY pair is accepted (n_ladder if none).  Equals the reference's
 // "decrease epsilon until the pass returns something" loop (impute.py:1665-1687).
 __device__ inline int ladder_first(const DevArgs &A, WgShared &sh, const Slot &S, const double *prior, uint32_t np) {
   const int P = A.g.P;
   int best = A.prm.n_ladder;
-  for (uint32_t f = threadIdx.x; f < np && best > 0; f += GRIM_WG) {
-    PairRef pr = pair_ref(sh, S, f);
-    double w = prior[ENT_POP(pr.e1) * P + ENT_POP(pr.e2)];
-    for (int idx = 0; idx < best; ++idx) {
-      if (pair_accept(A.prm.ladder[idx], pr, w)) {
-        best = idx;
-        break;
+  if (np < GRIM_TILE_MIN) {  // few pairs: straight from the slot
+    for (uint32_t f = threadIdx.x; f < np && best > 0; f += GRIM_WG) {
+      PairRef pr = pair_ref(sh, S, f);
+      double w = prior[ENT_POP(pr.e1) * P + ENT_POP(pr.e2)];
+      for (int idx = 0; idx < best; ++idx) {
+        if (pair_accept(A.prm.ladder[idx], pr, w)) {
+          best = idx;
+          break;
+        }
       }
     }
+  } else {
+    PairTile &T = *(PairTile *)sh.hist;
+    for (int i = 0; i < sh.nph; ++i) {
+      const uint32_t n2 = sh.Tn[2 * i + 1], npi = sh.Tn[2 * i] * n2;
+      if (!npi) continue;
+      __syncthreads();
+      tile_load(T, sh, S, i);
+      __syncthreads();
+      const uint32_t magic = tile_magic(n2);
+      for (uint32_t r = threadIdx.x; r < npi && best > 0; r += GRIM_WG) {
+        const PairRef q = tile_pair(T, r, n2, magic);
+        const double w = prior[ENT_POP(q.e1) * P + ENT_POP(q.e2)];
+        for (int idx = 0; idx < best; ++idx) {
+          if (pair_accept(A.prm.ladder[idx], q, w)) {
+            best = idx;
+            break;
+          }
+        }
+      }
+    }
+    __syncthreads();
   }
   if (threadIdx.x == 0) sh.bc[0] = (uint32_t)A.prm.n_ladder;
   __syncthreads();
@@ -284,51 +344,109 @@ __device__ inline uint32_t pair_pass(const DevArgs &A, WgShared &sh, const Slot 
   uint64_t *Akey = S.ska;
   double *Aprob = (double *)S.skb;
   uint32_t nA = 0;
-  for (uint32_t f0 = 0; f0 < np; f0 += 4 * GRIM_WG) {
-    bool on[4];
-    uint64_t key[4];
-    double prob[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const uint32_t f = f0 + q * GRIM_WG + tid;
-      on[q] = false;
-      key[q] = 0;
-      prob[q] = 0.0;
-      if (f < np) {
-        const PairRef pr = pair_ref(sh, S, f);
-        const double w = prior[ENT_POP(pr.e1) * P + ENT_POP(pr.e2)];
-        if (pair_accept(eps, pr, w)) {
-          on[q] = true;
+  if (np >= GRIM_TILE_MIN) {
+    PairTile &T = *(PairTile *)sh.hist;
+    const int lane = lane_id(), wv = wave_id();
+    const uint64_t lt = (1ull << lane) - 1ull;
+    const bool lds_prior = P * P <= 64;
+    __syncthreads();
+    if (lds_prior)
+      for (int c = tid; c < P * P; c += GRIM_WG) T.lp[c] = prior[c];
+    for (int i = 0; i < sh.nph; ++i) {
+      const uint32_t n2 = sh.Tn[2 * i + 1], npi = sh.Tn[2 * i] * n2;
+      if (!npi) continue;
+      __syncthreads();  // the previous tile is spent
+      tile_load(T, sh, S, i);
+      __syncthreads();
+      const uint32_t magic = tile_magic(n2);
+      // wave w owns the w-th stretch of the phase's pairs (whole chunks of 64): pass 1 marks and counts the accepted ones,
+      // pass 2 writes them behind the waves before it -- two barriers per phase instead of two per 1024 pairs
+      const uint32_t q = ((npi + GRIM_NWAVE * 64 - 1) / (GRIM_NWAVE * 64)) * 64, r0 = wv * q, r1 = r0 + q < npi ? r0 + q : npi;
+      uint32_t cnt = 0;
+      for (uint32_t c0 = r0; c0 < r1; c0 += 64) {
+        const uint32_t r = c0 + lane;
+        bool on = false;
+        if (r < r1) {
+          const PairRef pr = tile_pair(T, r, n2, magic);
+          const uint32_t cell = ENT_POP(pr.e1) * P + ENT_POP(pr.e2);
+          on = pair_accept(eps, pr, lds_prior ? T.lp[cell] : prior[cell]);
+        }
+        const uint64_t m = __ballot(on);
+        if (lane == 0) T.bm[c0 >> 6] = m;
+        cnt += (uint32_t)__popcll(m);
+      }
+      if (lane == 0) sh.tmp[wv] = cnt;
+      __syncthreads();
+      uint32_t base = nA, total = 0;
+      for (int w2 = 0; w2 < GRIM_NWAVE; ++w2) {
+        if (w2 < wv) base += sh.tmp[w2];
+        total += sh.tmp[w2];
+      }
+      for (uint32_t c0 = r0; c0 < r1; c0 += 64) {
+        const uint64_t m = T.bm[c0 >> 6];
+        if ((m >> lane) & 1ull) {
+          const uint32_t r = c0 + lane;
+          const PairRef pr = tile_pair(T, r, n2, magic);
+          const uint32_t cell = ENT_POP(pr.e1) * P + ENT_POP(pr.e2);
+          const uint32_t pos = base + (uint32_t)__popcll(m & lt);
           const uint32_t lo = pr.e1 < pr.e2 ? pr.e1 : pr.e2, hi = pr.e1 < pr.e2 ? pr.e2 : pr.e1;
-          key[q] = ((uint64_t)lo << 32) | hi | GRIM_VALID;
-          prob[q] = pair_prob(pr, w);
+          Af[pos] = sh.poff[i] + r;
+          Akey[pos] = ((uint64_t)lo << 32) | hi | GRIM_VALID;
+          Aprob[pos] = pair_prob(pr, lds_prior ? T.lp[cell] : prior[cell]);
+        }
+        base += (uint32_t)__popcll(m);
+      }
+      nA += total;
+    }
+    __syncthreads();
+  } else {
+    // few pairs: 4 x 256 per barrier round straight from the slot (a tile per phase would cost more barriers than it saves)
+    for (uint32_t f0 = 0; f0 < np; f0 += 4 * GRIM_WG) {
+      bool on[4];
+      uint64_t key[4];
+      double prob[4];
+  #pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t f = f0 + q * GRIM_WG + tid;
+        on[q] = false;
+        key[q] = 0;
+        prob[q] = 0.0;
+        if (f < np) {
+          const PairRef pr = pair_ref(sh, S, f);
+          const double w = prior[ENT_POP(pr.e1) * P + ENT_POP(pr.e2)];
+          if (pair_accept(eps, pr, w)) {
+            on[q] = true;
+            const uint32_t lo = pr.e1 < pr.e2 ? pr.e1 : pr.e2, hi = pr.e1 < pr.e2 ? pr.e2 : pr.e1;
+            key[q] = ((uint64_t)lo << 32) | hi | GRIM_VALID;
+            prob[q] = pair_prob(pr, w);
+          }
         }
       }
-    }
-    uint64_t m[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      m[q] = __ballot(on[q]);
-      if (lane_id() == 0) sh.tmp[q * GRIM_NWAVE + wave_id()] = (uint32_t)__popcll(m[q]);
-    }
-    __syncthreads();
-    uint32_t run = nA, base[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      for (int w2 = 0; w2 < GRIM_NWAVE; ++w2) {
-        if (w2 == wave_id()) base[q] = run;
-        run += sh.tmp[q * GRIM_NWAVE + w2];
+      uint64_t m[4];
+  #pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        m[q] = __ballot(on[q]);
+        if (lane_id() == 0) sh.tmp[q * GRIM_NWAVE + wave_id()] = (uint32_t)__popcll(m[q]);
       }
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (on[q]) {
-        const uint32_t pos = base[q] + (uint32_t)__popcll(m[q] & ((1ull << lane_id()) - 1ull));
-        Af[pos] = f0 + q * GRIM_WG + tid;
-        Akey[pos] = key[q];
-        Aprob[pos] = prob[q];
-      }
-    nA = run;
-    __syncthreads();
+      __syncthreads();
+      uint32_t run = nA, base[4];
+  #pragma unroll
+      for (int q = 0; q < 4; ++q)
+        for (int w2 = 0; w2 < GRIM_NWAVE; ++w2) {
+          if (w2 == wave_id()) base[q] = run;
+          run += sh.tmp[q * GRIM_NWAVE + w2];
+        }
+  #pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (on[q]) {
+          const uint32_t pos = base[q] + (uint32_t)__popcll(m[q] & ((1ull << lane_id()) - 1ull));
+          Af[pos] = f0 + q * GRIM_WG + tid;
+          Akey[pos] = key[q];
+          Aprob[pos] = prob[q];
+        }
+      nA = run;
+      __syncthreads();
+    }
   }
   // Stage B: one slot per unordered entity pair; the smallest position in the accepted list wins it
   const bool in_lds = nA <= GRIM_PASS_LDS_MAX;
@@ -392,56 +510,59 @@ __device__ inline uint32_t pair_pass(const DevArgs &A, WgShared &sh, const Slot 
     }
   }
   __syncthreads();
-  // Stage C: winners in pair order
+  // Stage C: winners in pair order.  Wave w owns the w-th stretch of the accepted list: it counts its winners, and
+  // (final pass) writes them behind the waves before it -- one barrier in between instead of two per 1024 pairs.
   uint32_t nU = 0;
   double mx = 0.0;
-  for (uint32_t u0 = 0; u0 < nA; u0 += 4 * GRIM_WG) {
-    bool win[4];
-    double prob[4];
-    uint32_t slot[4];
+  {
+    const int lane = lane_id(), wv = wave_id();
+    const uint64_t lt = (1ull << lane) - 1ull;
+    const uint32_t q = ((nA + GRIM_NWAVE * 64 - 1) / (GRIM_NWAVE * 64)) * 64, u0 = wv * q, u1 = u0 + q < nA ? u0 + q : nA;
+    auto is_winner = [&](uint32_t u) -> bool {
+      const uint32_t slot = Aslot[u];
+      return (in_lds ? (uint32_t)lm[slot] : ALOAD(&S.tmin[slot])) == u;
+    };
+    // the winners' ballot masks stay in LDS for the writing pass when they fit (the dedup table occupies the histogram
+    // area exactly when the list is short enough for the other one)
+    uint64_t *wb = in_lds ? (uint64_t *)sh.qcell : (uint64_t *)sh.hist;
+    const bool keep = in_lds || nA <= 64u * (16u * GRIM_WG * 4u / 8u);
+    uint32_t cnt = 0;
+    for (uint32_t c0 = u0; c0 < u1; c0 += 4 * 64) {  // four chunks in flight
+      bool w[4];
+      double pp[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const uint32_t u = u0 + q * GRIM_WG + tid;
-      slot[q] = u < nA ? Aslot[u] : GRIM_NONE;
-      prob[q] = u < nA ? Aprob[u] : 0.0;
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t u = c0 + k * 64 + lane;
+        w[k] = u < u1 && is_winner(u);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) pp[k] = w[k] ? Aprob[c0 + k * 64 + lane] : 0.0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (pp[k] > mx) mx = pp[k];
+        const uint64_t m = __ballot(w[k]);
+        if (keep && lane == 0 && c0 + k * 64 < u1) wb[(c0 >> 6) + k] = m;
+        cnt += (uint32_t)__popcll(m);
+      }
     }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const uint32_t u = u0 + q * GRIM_WG + tid;
-      win[q] = false;
-      if (slot[q] != GRIM_NONE) win[q] = (in_lds ? (uint32_t)lm[slot[q]] : ALOAD(&S.tmin[slot[q]])) == u;
-      if (win[q] && prob[q] > mx) mx = prob[q];
+    if (lane == 0) sh.tmp[wv] = cnt;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w2 = 0; w2 < GRIM_NWAVE; ++w2) {
+      if (w2 < wv) base += sh.tmp[w2];
+      nU += sh.tmp[w2];
     }
     if (emit) {
-      uint32_t fq[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) fq[q] = win[q] ? Af[u0 + q * GRIM_WG + tid] : 0;
-      uint64_t m[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        m[q] = __ballot(win[q]);
-        if (lane_id() == 0) sh.tmp[q * GRIM_NWAVE + wave_id()] = (uint32_t)__popcll(m[q]);
+      for (uint32_t c0 = u0; c0 < u1; c0 += 64) {
+        const uint32_t u = c0 + lane;
+        const uint64_t m = keep ? wb[c0 >> 6] : __ballot(u < u1 && is_winner(u));
+        if ((m >> lane) & 1ull) {
+          const uint32_t pos = base + (uint32_t)__popcll(m & lt);
+          S.Useq[pos] = Af[u];
+          S.Uprob[pos] = Aprob[u];
+        }
+        base += (uint32_t)__popcll(m);
       }
-      __syncthreads();
-      uint32_t run = nU, base[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        for (int w2 = 0; w2 < GRIM_NWAVE; ++w2) {
-          if (w2 == wave_id()) base[q] = run;
-          run += sh.tmp[q * GRIM_NWAVE + w2];
-        }
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (win[q]) {
-          const uint32_t pos = base[q] + (uint32_t)__popcll(m[q] & ((1ull << lane_id()) - 1ull));
-          S.Useq[pos] = fq[q];
-          S.Uprob[pos] = prob[q];
-        }
-      nU = run;
-      __syncthreads();
-    } else {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) nU += win[q] ? 1u : 0u;
     }
   }
   // MaxProb
@@ -450,20 +571,10 @@ __device__ inline uint32_t pair_pass(const DevArgs &A, WgShared &sh, const Slot 
     if (o > mx) mx = o;
   }
   if (lane_id() == 0) sh.dtmp[wave_id()] = mx;
-  if (!emit) {
-    // count winners across the workgroup
-    uint32_t c = nU;
-    for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d);
-    if (lane_id() == 0) sh.tmp[wave_id()] = c;
-  }
   __syncthreads();
   mx = sh.dtmp[0];
   for (int w2 = 1; w2 < GRIM_NWAVE; ++w2)
     if (sh.dtmp[w2] > mx) mx = sh.dtmp[w2];
-  if (!emit) {
-    nU = 0;
-    for (int w2 = 0; w2 < GRIM_NWAVE; ++w2) nU += sh.tmp[w2];
-  }
   __syncthreads();
   *maxp = mx;
   return nU;
