@@ -343,6 +343,20 @@ __device__ inline uint32_t pair_pass(const DevArgs &A, WgShared &sh, const Slot 
   uint32_t *Af = S.sva, *Aslot = S.svb;
   uint64_t *Akey = S.ska;
   double *Aprob = (double *)S.skb;
+#ifdef GRIM_STAMPS
+  unsigned long long _pp_t0 = wall_clock64();
+#define PP_STAMP(k)                                                                          \
+  do {                                                                                       \
+    __syncthreads();                                                                         \
+    if (threadIdx.x == 0 && emit) {                                                          \
+      const unsigned long long _n = wall_clock64();                                           \
+      atomicAdd(&A.counters[GRIM_STAMP_BASE + (k)], _n - _pp_t0);                            \
+      _pp_t0 = _n;                                                                           \
+    }                                                                                        \
+  } while (0)
+#else
+#define PP_STAMP(k)
+#endif
   uint32_t nA = 0;
   if (np >= GRIM_TILE_MIN) {
     PairTile &T = *(PairTile *)sh.hist;
@@ -448,6 +462,7 @@ __device__ inline uint32_t pair_pass(const DevArgs &A, WgShared &sh, const Slot 
       __syncthreads();
     }
   }
+  PP_STAMP(0);
   // Stage B: one slot per unordered entity pair; the smallest position in the accepted list wins it
   const bool in_lds = nA <= GRIM_PASS_LDS_MAX;
   lds_u64 *lk = (lds_u64 *)sh.hist;
@@ -510,6 +525,7 @@ __device__ inline uint32_t pair_pass(const DevArgs &A, WgShared &sh, const Slot 
     }
   }
   __syncthreads();
+  PP_STAMP(1);
   // Stage C: winners in pair order.  Wave w owns the w-th stretch of the accepted list: it counts its winners, and
   // (final pass) writes them behind the waves before it -- one barrier in between instead of two per 1024 pairs.
   uint32_t nU = 0;
@@ -565,6 +581,7 @@ __device__ inline uint32_t pair_pass(const DevArgs &A, WgShared &sh, const Slot 
       }
     }
   }
+  PP_STAMP(2);
   // MaxProb
   for (int d = 32; d > 0; d >>= 1) {
     double o = __shfl_xor(mx, d);
