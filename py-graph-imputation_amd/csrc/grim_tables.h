@@ -1122,6 +1122,116 @@ __device__ inline void tab_merge_groups(const DevArgs &A, TabShared &sh, const S
   __syncthreads();
 }
 
+// Ranking straight from the bucket kernel's group records (any order): the first-seen order only ever breaks ties, and the
+// order of the groups' FIRST PAIRS is that order -- so the rows wanted are the `want` smallest of (key of the sum, head),
+// and the renumbering pass (tab_merge_groups) is not needed.  Up to three 12-bit histogram levels narrow the candidates
+// down to what the LDS list holds; false: not resolved this way (the caller renumbers and ranks the old way).
+__device__ inline bool tab_rank_grp(const DevArgs &A, TabShared &sh, const Slot &S, const GrpRec *grp, uint32_t ng, uint32_t want,
+                                    uint32_t **order_out) {
+  const int tid = threadIdx.x;
+  if (ng <= 512) {
+    double *ls = (double *)sh.hist;            // [512]
+    uint32_t *lh = (uint32_t *)(ls + 512);     // [512]
+    for (uint32_t g = tid; g < ng; g += GRIM_WG) {
+      const GrpRec r = grp[g];
+      ls[g] = r.sum;
+      lh[g] = r.head;
+    }
+    __syncthreads();
+    for (uint32_t g = tid; g < ng; g += GRIM_WG) {
+      const double s = ls[g];
+      const uint32_t h = lh[g];
+      uint32_t rank = 0;
+      for (uint32_t g2 = 0; g2 < ng; ++g2) {
+        const double s2 = ls[g2];
+        rank += (s2 > s || (s2 == s && lh[g2] < h)) ? 1u : 0u;
+      }
+      if (rank < want) S.sva[rank] = g;
+    }
+    __syncthreads();
+    *order_out = S.sva;
+    return true;
+  }
+  if (!(want > 0 && want <= 512 && want * 4 <= ng)) return false;
+  uint32_t *h12 = sh.hist;
+  uint64_t prefix = 0, himask = 0, limit = 0;
+  uint32_t need = want, below = 0;
+  bool resolved = false;
+  for (int shift = 52; shift >= 28 && !resolved; shift -= 12) {
+    for (int i = tid; i < 4096; i += GRIM_WG) h12[i] = 0;
+    __syncthreads();
+    for (uint32_t g = tid; g < ng; g += GRIM_WG) {
+      const uint64_t k = ~f64_ord(grp[g].sum);
+      if ((k & himask) == prefix) atomicAdd(&h12[(uint32_t)(k >> shift) & 4095u], 1u);
+    }
+    __syncthreads();
+    uint32_t part = 0;
+    for (int e = 0; e < 16; ++e) part += h12[tid * 16 + e];
+    uint32_t total;
+    const uint32_t before = wg_excl_scan(part, sh.tmp, total);
+    if (before < need && need <= before + part) {
+      uint32_t cum = before;
+#pragma nounroll
+      for (int e = 0; e < 16; ++e) {
+        const uint32_t c = h12[tid * 16 + e];
+        if (cum + c >= need) {
+          sh.bc[4] = (uint32_t)(tid * 16 + e);
+          sh.bc[5] = cum;      // groups of this level in the bins before B
+          sh.bc[6] = c;        // groups in bin B
+          break;
+        }
+        cum += c;
+      }
+    }
+    __syncthreads();
+    const uint32_t B = sh.bc[4], cum_before = sh.bc[5], in_b = sh.bc[6];
+    __syncthreads();
+    if (below + cum_before + in_b <= 1024) {
+      limit = prefix | ((uint64_t)B << shift) | ((1ull << shift) - 1ull);
+      resolved = true;
+    } else {
+      below += cum_before;
+      need -= cum_before;
+      prefix |= (uint64_t)B << shift;
+      himask |= 4095ull << shift;
+    }
+  }
+  if (!resolved) return false;
+  // every group whose key is at most `limit`: at most 1024, any order (the head decides ties, not the position)
+  uint64_t *lk = (uint64_t *)sh.hist;      // [1024]
+  uint32_t *lh = (uint32_t *)(lk + 1024);  // [1024]
+  uint32_t *lg = lh + 1024;                // [1024]
+  if (tid == 0) sh.bc[4] = 0;
+  __syncthreads();
+  for (uint32_t g = tid; g < ng; g += GRIM_WG) {
+    const GrpRec r = grp[g];
+    const uint64_t k = ~f64_ord(r.sum);
+    if (k <= limit) {
+      const uint32_t pos = atomicAdd(&sh.bc[4], 1u);
+      if (pos < 1024) {
+        lk[pos] = k;
+        lh[pos] = r.head;
+        lg[pos] = g;
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t taken = sh.bc[4] < 1024u ? sh.bc[4] : 1024u;
+  for (uint32_t i = tid; i < taken; i += GRIM_WG) {
+    const uint64_t k = lk[i];
+    const uint32_t h = lh[i];
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < taken; ++j) {
+      const uint64_t k2 = lk[j];
+      rank += (k2 < k || (k2 == k && lh[j] < h)) ? 1u : 0u;
+    }
+    if (rank < want) S.svb[rank] = lg[i];
+  }
+  __syncthreads();
+  *order_out = S.svb;
+  return true;
+}
+
 // third kernel, population pairs: rank the non-empty cells (bigger sum first, earlier first pair on ties), write the rows
 __device__ inline void tab_merge_pops(const DevArgs &A, TabShared &sh, const TabWork &w, const TabAux &x, grim_subject_result *out) {
   const int tid = threadIdx.x;
@@ -1213,16 +1323,23 @@ __global__ __launch_bounds__(GRIM_WG, GRIM_TAB_WG_PER_CU) void grim_tables_merge
       const bool on = t == 0 ? A.prm.out_muug : A.prm.out_haps;
       uint32_t ng = 0, want = 0;
       uint32_t *order = nullptr;
+      const GrpRec *grp = nullptr;  // not null: `order` indexes the bucket kernel's group records
       if (t == 0 || on) {
         const int kind = t == 0 ? 0 : (A.prm.em_mr ? 2 : 1);
         if (x.nb[t] == 0 || x.overflow[t]) {
           ng = tab_group_hbm(A, sh, S, rec, nU, kind);  // own groups, a bucket that overflowed, or GRIM_TABLES_HBM=1
+          want = on ? (ng < A.prm.n_results ? ng : A.prm.n_results) : 0;
+          if (want) tab_rank(A, sh, S, S.gsum, ng, want, &order);
         } else {
           ng = x.ng[t];
-          tab_merge_groups(A, sh, S, A.pgrp + (uint64_t)t * A.tstride + w.off, ng, nU);
+          grp = A.pgrp + (uint64_t)t * A.tstride + w.off;
+          want = on ? (ng < A.prm.n_results ? ng : A.prm.n_results) : 0;
+          if (want && !tab_rank_grp(A, sh, S, grp, ng, want, &order)) {
+            tab_merge_groups(A, sh, S, grp, ng, nU);  // many rows wanted, or too many groups near the cut: first-seen ids, full ranking
+            tab_rank(A, sh, S, S.gsum, ng, want, &order);
+            grp = nullptr;
+          }
         }
-        want = on ? (ng < A.prm.n_results ? ng : A.prm.n_results) : 0;
-        if (want) tab_rank(A, sh, S, S.gsum, ng, want, &order);
       }
       const uint32_t off = tab_alloc_rows(A, sh, want);
       if (tid == 0) {
@@ -1233,11 +1350,11 @@ __global__ __launch_bounds__(GRIM_WG, GRIM_TAB_WG_PER_CU) void grim_tables_merge
       if (off != GRIM_NONE)
         for (uint32_t r = tid; r < want; r += GRIM_WG) {
           const uint32_t g = order[r];
-          const PairRec pr = rec[S.ghead[g]];
+          const PairRec pr = rec[grp ? grp[g].head : S.ghead[g]];
           grim_row row;
           row.a = pr.k1;
           row.b = pr.k2;
-          row.prob = S.gsum[g];
+          row.prob = grp ? grp[g].sum : S.gsum[g];
           row.popa = ENT_POP(pr.e1);
           row.popb = ENT_POP(pr.e2);
           A.rows[off + r] = row;
