@@ -922,7 +922,90 @@ __device__ inline void tab_split_pops(const DevArgs &A, TabShared &sh, const Slo
   if (base == GRIM_NONE) return;
   uint32_t *order = A.psort + 2ull * A.tstride + w.off;
   double *pp = A.pprob + w.off;
-  if (ncell > 1) {
+  if (ncell > 1 && ncell <= 1024 && sh.wcnt && nU <= GRIM_NWAVE * 65472u) {
+    // stable partition by cell with wave-owned stretches and per-wave cursors, as tab_split_table deals buckets: no
+    // radix passes through HBM, two sweeps over the pairs
+    const int wv = wave_id(), lane = lane_id();
+    const uint64_t lt = (1ull << lane) - 1ull;
+    const uint32_t q = ((nU + GRIM_NWAVE * 64 - 1) / (GRIM_NWAVE * 64)) * 64;
+    const uint32_t nc = (uint32_t)ncell;
+    uint16_t *wc = sh.wcnt;
+    {
+      uint32_t *wz = (uint32_t *)wc;
+      for (uint32_t k = tid; k < (GRIM_NWAVE * nc + 1) / 2; k += GRIM_WG) wz[k] = 0;
+    }
+    __syncthreads();
+    const uint32_t u0 = wv * q, u1 = u0 + q < nU ? u0 + q : nU;
+    for (uint32_t u = u0 + lane; u < u1; u += 64) {
+      const PairRec r = rec[u];
+      const uint32_t a = ENT_POP(r.e1), b = ENT_POP(r.e2);
+      const uint32_t cell = (a < b ? a : b) * (uint32_t)P + (a < b ? b : a);
+      S.svb[u] = cell;
+      const uint32_t k = wv * nc + cell;
+      atomicAdd((uint32_t *)wc + (k >> 1), 1u << (16 * (k & 1)));
+    }
+    __syncthreads();
+    // (a cell holds most of an item's pairs as a rule: the cursors need 32 bits, unlike a bucket's)
+    uint32_t *cur32 = (uint32_t *)(wc + GRIM_NWAVE * 1024);  // [GRIM_NWAVE][nc], behind the 16-bit counts
+    for (uint32_t c = tid; c < nc; c += GRIM_WG) {
+      uint32_t run = 0;
+      for (int w2 = 0; w2 < GRIM_NWAVE; ++w2) {
+        const uint32_t n = wc[w2 * nc + c];
+        cur32[w2 * nc + c] = run;
+        run += n;
+      }
+      cnt[c + 1] = run;
+    }
+    __syncthreads();
+    if (tid == 0) {  // cell starts (the cells are few next to the pairs: a serial scan by one thread is noise)
+      uint32_t acc = 0;
+      for (int c = 0; c <= ncell; ++c) {
+        acc += cnt[c];
+        cnt[c] = acc;
+      }
+    }
+    __syncthreads();
+    int nbits = 0;
+    while ((1u << nbits) < nc) ++nbits;
+    for (uint32_t c0 = u0; c0 < u1; c0 += 4 * 64) {
+      uint32_t ck[4];
+      bool act[4];
+      uint64_t same[4];
+      double pr[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t u = c0 + k * 64 + lane;
+        act[k] = u < u1;
+        ck[k] = act[k] ? S.svb[u] : 0u;
+        pr[k] = act[k] ? rec[u].prob : 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) same[k] = __ballot(act[k]);
+      for (int bit = 0; bit < nbits; ++bit) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const bool sbit = (ck[k] >> bit) & 1u;
+          const uint64_t m = __ballot(act[k] && sbit);
+          same[k] &= sbit ? m : ~m;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (act[k]) {
+          const uint32_t rank = (uint32_t)__popcll(same[k] & lt), n = (uint32_t)__popcll(same[k]);
+          const uint32_t cur = cur32[wv * nc + ck[k]];
+          const uint32_t pos = cnt[ck[k]] + cur + rank;
+          if (pos < nU) {
+            order[pos] = c0 + k * 64 + lane;
+            pp[pos] = pr[k];
+          }
+          if (rank + 1 == n) cur32[wv * nc + ck[k]] = cur + n;
+        }
+        WAVE_SYNC();
+      }
+    }
+    __syncthreads();
+  } else if (ncell > 1) {
     for (uint32_t u = tid; u < nU; u += GRIM_WG) {
       const PairRec r = rec[u];
       const uint32_t a = ENT_POP(r.e1), b = ENT_POP(r.e2);
