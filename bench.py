@@ -79,6 +79,10 @@ def main():
     args = ap.parse_args()
     if args.workload == "full":
         args.workload = "config2"
+    if args.workload == "config5":
+        # a step is ONE device batch here and each of the stream's four batch slots sizes its (multi-GB) pair pool on first
+        # use: the untimed steps must touch every slot
+        args.warmup = max(args.warmup, 4)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -205,22 +205,64 @@ __device__ inline uint32_t pair_offsets(WgShared &sh) {
 struct PairTile {
   double p1[GRIM_TOPCAP], p2[GRIM_TOPCAP], m2[GRIM_TOPCAP];
   uint32_t e1[GRIM_TOPCAP], e2[GRIM_TOPCAP];
+  uint16_t d1[GRIM_TOPCAP], d2[GRIM_TOPCAP];    // dense numbers of the entities (pair_dense_ids), when the pass asked for them
   uint64_t bm[GRIM_TOPCAP * GRIM_TOPCAP / 64];  // accepted pairs of the phase, one bit each
   double lp[64];                                 // the prior matrix when it has at most 64 cells
 };
 static_assert(sizeof(PairTile) <= 16 * GRIM_WG * 4, "the phase tile lives in the histogram area");
 
 // all threads; the caller synchronises before reading the tile and again before the next tile_load
-__device__ __forceinline__ void tile_load(PairTile &T, const WgShared &sh, const Slot &S, int i) {
+__device__ __forceinline__ void tile_load(PairTile &T, const WgShared &sh, const Slot &S, int i, const uint16_t *dense = nullptr) {
   const uint32_t n1 = sh.Tn[2 * i], n2 = sh.Tn[2 * i + 1];
   for (uint32_t t = threadIdx.x; t < n1; t += GRIM_WG) {
     T.p1[t] = S.Tp[(2 * i) * GRIM_TOPCAP + t];
     T.e1[t] = S.Te[(2 * i) * GRIM_TOPCAP + t];
+    if (dense) T.d1[t] = dense[(2 * i) * GRIM_TOPCAP + t];
   }
   for (uint32_t t = threadIdx.x; t < n2; t += GRIM_WG) {
     T.p2[t] = S.Tp[(2 * i + 1) * GRIM_TOPCAP + t];
     T.m2[t] = S.Tm[(2 * i + 1) * GRIM_TOPCAP + t];
     T.e2[t] = S.Te[(2 * i + 1) * GRIM_TOPCAP + t];
+    if (dense) T.d2[t] = dense[(2 * i + 1) * GRIM_TOPCAP + t];
+  }
+}
+
+// Dense numbers 0..D-1 (D <= 4096) for the distinct entities of all top lists: a pair's dedup key then fits 24 bits, and
+// key and smallest pair number share ONE 64-bit table word -- a dedup insert touches one cache line instead of two (the
+// table of a heavy subject does not fit the L2: every line touched is a DRAM round trip).  All threads call; dense[side *
+// GRIM_TOPCAP + idx] is valid afterwards.  Uses the group-sum arrays of the slot (free during the pair stage).
+#define GRIM_DENSE_SLOTS 8192u
+__device__ inline void pair_dense_ids(const DevArgs &A, WgShared &sh, const Slot &S, uint16_t *dense) {
+  const int tid = threadIdx.x;
+  uint64_t *ek = (uint64_t *)S.gsum;
+  uint32_t *ei = S.ghead;
+  const uint32_t n_ent = 2u * (uint32_t)sh.nph * GRIM_TOPCAP;
+  for (uint32_t s = tid; s < GRIM_DENSE_SLOTS; s += GRIM_WG) ek[s] = 0;
+  if (tid == 0) sh.bc[6] = 0;
+  __syncthreads();
+  for (int pass = 0; pass < 2; ++pass) {
+    for (uint32_t q = tid; q < n_ent; q += GRIM_WG) {
+      const uint32_t side = q / GRIM_TOPCAP, idx = q % GRIM_TOPCAP;
+      if (idx >= sh.Tn[side]) continue;
+      const uint64_t key = (uint64_t)S.Te[q] | GRIM_VALID;
+      uint32_t s = (uint32_t)mix64(key) & (GRIM_DENSE_SLOTS - 1);
+      for (;;) {
+        uint64_t c = ALOAD(&ek[s]);
+        if (c == 0 && pass == 0) {
+          const uint64_t old = atomicCAS((unsigned long long *)&ek[s], 0ull, (unsigned long long)key);
+          if (old == 0) {  // first sight of this entity: it gets the next number
+            ASTORE(&ei[s], atomicAdd(&sh.bc[6], 1u));
+            c = key;
+          } else {
+            c = old;
+          }
+        }
+        if (c == key) break;
+        s = (s + 1) & (GRIM_DENSE_SLOTS - 1);
+      }
+      if (pass == 1) dense[q] = (uint16_t)ALOAD(&ei[s]);
+    }
+    __syncthreads();
   }
 }
 __device__ __forceinline__ PairRef tile_pair(const PairTile &T, uint32_t r, uint32_t n2, uint32_t magic) {
@@ -358,7 +400,11 @@ __device__ inline uint32_t pair_pass(const DevArgs &A, WgShared &sh, const Slot 
 #define PP_STAMP(k)
 #endif
   uint32_t nA = 0;
-  if (np >= GRIM_TILE_MIN) {
+  const bool tiled = np >= GRIM_TILE_MIN;
+  uint32_t *Akey32 = (uint32_t *)S.ska;       // tiled passes: 24-bit keys over dense entity numbers
+  uint16_t *dense = (uint16_t *)S.gstart;
+  if (tiled) {
+    pair_dense_ids(A, sh, S, dense);
     PairTile &T = *(PairTile *)sh.hist;
     const int lane = lane_id(), wv = wave_id();
     const uint64_t lt = (1ull << lane) - 1ull;
@@ -370,7 +416,7 @@ __device__ inline uint32_t pair_pass(const DevArgs &A, WgShared &sh, const Slot 
       const uint32_t n2 = sh.Tn[2 * i + 1], npi = sh.Tn[2 * i] * n2;
       if (!npi) continue;
       __syncthreads();  // the previous tile is spent
-      tile_load(T, sh, S, i);
+      tile_load(T, sh, S, i, dense);
       __syncthreads();
       const uint32_t magic = tile_magic(n2);
       // wave w owns the w-th stretch of the phase's pairs (whole chunks of 64): pass 1 marks and counts the accepted ones,
@@ -403,9 +449,10 @@ __device__ inline uint32_t pair_pass(const DevArgs &A, WgShared &sh, const Slot 
           const PairRef pr = tile_pair(T, r, n2, magic);
           const uint32_t cell = ENT_POP(pr.e1) * P + ENT_POP(pr.e2);
           const uint32_t pos = base + (uint32_t)__popcll(m & lt);
-          const uint32_t lo = pr.e1 < pr.e2 ? pr.e1 : pr.e2, hi = pr.e1 < pr.e2 ? pr.e2 : pr.e1;
+          const uint32_t h = n2 > 1 ? __umulhi(r, magic) : r, k = r - h * n2;
+          const uint32_t da = T.d1[h], db = T.d2[k];
           Af[pos] = sh.poff[i] + r;
-          Akey[pos] = ((uint64_t)lo << 32) | hi | GRIM_VALID;
+          Akey32[pos] = ((da < db ? da : db) << 12) | (da < db ? db : da);
           Aprob[pos] = pair_prob(pr, lds_prior ? T.lp[cell] : prior[cell]);
         }
         base += (uint32_t)__popcll(m);
@@ -465,8 +512,10 @@ __device__ inline uint32_t pair_pass(const DevArgs &A, WgShared &sh, const Slot 
   PP_STAMP(0);
   // Stage B: one slot per unordered entity pair; the smallest position in the accepted list wins it
   const bool in_lds = nA <= GRIM_PASS_LDS_MAX;
+  const bool words = tiled && !in_lds;  // one 64-bit word per slot: key << 32 | smallest position (all ones: empty)
   lds_u64 *lk = (lds_u64 *)sh.hist;
   lds_u32 *lm = (lds_u32 *)sh.qprob;
+  uint64_t *tw = S.k0;
   uint32_t cap = 64;
   if (in_lds) {
     cap = GRIM_PASS_LDS_SLOTS;
@@ -477,16 +526,20 @@ __device__ inline uint32_t pair_pass(const DevArgs &A, WgShared &sh, const Slot 
   } else {
     while (cap < 2 * nA) cap <<= 1;
     if (cap > A.tab_cap) cap = A.tab_cap;
-    for (uint32_t s = tid; s < cap; s += GRIM_WG) {
-      S.k0[s] = 0;
-      S.tmin[s] = GRIM_NONE;
+    if (words) {
+      for (uint32_t s = tid; s < cap; s += GRIM_WG) tw[s] = ~0ull;
+    } else {
+      for (uint32_t s = tid; s < cap; s += GRIM_WG) {
+        S.k0[s] = 0;
+        S.tmin[s] = GRIM_NONE;
+      }
     }
   }
   const uint32_t mask = cap - 1;
   __syncthreads();
   if (in_lds) {
     for (uint32_t u = tid; u < nA; u += GRIM_WG) {
-      const uint64_t a = Akey[u];
+      const uint64_t a = tiled ? ((uint64_t)Akey32[u] | GRIM_VALID) : Akey[u];
       uint32_t s = (uint32_t)mix64(a) & mask;
       for (;;) {
         uint64_t c = __hip_atomic_load(&lk[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -500,6 +553,47 @@ __device__ inline uint32_t pair_pass(const DevArgs &A, WgShared &sh, const Slot 
       }
       __hip_atomic_fetch_min(&lm[s], u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       Aslot[u] = s;
+    }
+  } else if (words) {
+    constexpr int NW = 4;  // inserts a thread keeps in flight
+    for (uint32_t u0 = tid; u0 < nA; u0 += NW * GRIM_WG) {
+      uint32_t key[NW], s[NW];
+      uint64_t word[NW];
+      bool done[NW];
+#pragma unroll
+      for (int q = 0; q < NW; ++q) {
+        const uint32_t u = u0 + q * GRIM_WG;
+        done[q] = u >= nA;
+        key[q] = done[q] ? 0u : Akey32[u];
+        word[q] = ((uint64_t)key[q] << 32) | u;
+        s[q] = (key[q] * 0x9E3779B1u ^ (key[q] >> 11) * 0x85EBCA6Bu) & mask;
+      }
+      for (;;) {
+        bool all = true;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) all = all && done[q];
+        if (all) break;
+        uint64_t w[NW];
+#pragma unroll
+        for (int q = 0; q < NW; ++q) w[q] = done[q] ? 0ull : ALOAD(&tw[s[q]]);
+#pragma unroll
+        for (int q = 0; q < NW; ++q)
+          if (!done[q] && w[q] == ~0ull) {
+            const uint64_t old = atomicCAS((unsigned long long *)&tw[s[q]], ~0ull, (unsigned long long)word[q]);
+            w[q] = old == ~0ull ? word[q] : old;  // claimed: my position is in the word already
+          }
+#pragma unroll
+        for (int q = 0; q < NW; ++q)
+          if (!done[q]) {
+            if ((uint32_t)(w[q] >> 32) == key[q]) {
+              if (w[q] != word[q]) atomicMin((unsigned long long *)&tw[s[q]], (unsigned long long)word[q]);
+              Aslot[u0 + q * GRIM_WG] = s[q];
+              done[q] = true;
+            } else {
+              s[q] = (s[q] + 1) & mask;
+            }
+          }
+      }
     }
   } else {
     for (uint32_t u0 = tid; u0 < nA; u0 += GRIM_PAIR_NB * GRIM_WG) {
@@ -536,6 +630,7 @@ __device__ inline uint32_t pair_pass(const DevArgs &A, WgShared &sh, const Slot 
     const uint32_t q = ((nA + GRIM_NWAVE * 64 - 1) / (GRIM_NWAVE * 64)) * 64, u0 = wv * q, u1 = u0 + q < nA ? u0 + q : nA;
     auto is_winner = [&](uint32_t u) -> bool {
       const uint32_t slot = Aslot[u];
+      if (words) return (uint32_t)ALOAD(&tw[slot]) == u;
       return (in_lds ? (uint32_t)lm[slot] : ALOAD(&S.tmin[slot])) == u;
     };
     // the winners' ballot masks stay in LDS for the writing pass when they fit (the dedup table occupies the histogram
