@@ -224,6 +224,46 @@ def test_config4_style_20k_properties_and_oracle_sample():
         assert got[k].splitlines()[:n] == exp[k].splitlines(), k
 
 
+def test_config4_full_size_100k():
+    """BASELINE config 4 at FULL size (bench.py --workload config4: 100 000 subjects, seed 3): properties over all of it,
+    the oracle on a slice from the end, and the first 20 000 subjects equal to what the 20k test's input gives (subjects are
+    independent: a bigger batch -- other kernel mix per chunk, table kernels over 27 M pair records -- must not change a row)"""
+    rows = synth.read_freqs(synth.CAU_FREQS)
+    pops = harness.POPS["pop4"]
+    lines = synth.SubjectGen(rows, 3, pops=pops).mixed(100000)
+    assert lines[:20000] == synth.SubjectGen(rows, 3, pops=pops).mixed(20000)
+    conf = harness.base_conf(pops)
+    conf["UNK_priors"] = "MR"
+    got, glog, imp = _run("pop4", conf, lines, "c4full")
+    assert got["problem"] == "" and not imp.unsupported
+    ids = [l.split(",")[0] for l in lines]
+    order = {sid: i for i, sid in enumerate(ids)}
+    heads = [l.split(",", 1)[0] for l in got["umug"].splitlines() if l.rsplit(",", 1)[1] == "0"]
+    assert [order[s] for s in heads] == sorted(order[s] for s in heads) and len(set(heads)) == len(heads)
+    assert set(ids) - set(heads) == {l.split(",")[1] for l in got["miss"].splitlines()}
+    for name in ("umug", "pmug", "umug_pops", "pmug_pops"):
+        last_id, last_rank, last_p = None, -1, None
+        for line in got[name].splitlines():
+            f = line.rsplit(",", 2)
+            sid = line.split(",", 1)[0]
+            rank, pr = int(f[2]), float(f[1])
+            assert (rank == 0) if sid != last_id else (rank == last_rank + 1 and pr <= last_p)
+            last_id, last_rank, last_p = sid, rank, pr
+    small, _, _ = _run("pop4", conf, lines[:20000], "c4full20k")
+    last20k = ids[19999]
+    for k in ("umug", "pmug", "umug_pops", "pmug_pops"):
+        big = got[k].splitlines()
+        n = len(small[k].splitlines())
+        assert big[:n] == small[k].splitlines(), k
+        assert n == len(big) or order[big[n].split(",", 1)[0]] > order[last20k], k
+    tail = lines[-300:]
+    exp, _ = harness.run_oracle("pop4", conf, tail, tag="c4full_orc")
+    first_tail = order[tail[0].split(",")[0]]
+    for k in ("umug", "pmug", "umug_pops", "pmug_pops"):
+        mine = [l for l in got[k].splitlines() if order[l.split(",", 1)[0]] >= first_tail]
+        assert mine == exp[k].splitlines(), k
+
+
 def test_config5_style_high_ambiguity_threshold_1e6():
     """BASELINE config 5 style subjects (8 alternatives per locus and side, number_of_options_threshold
     1e6 -> 32768 candidates per side through the cartesian branch) on the CAU graph."""
