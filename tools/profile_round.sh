@@ -18,6 +18,8 @@ run config2_fetch  "--pmc FETCH_SIZE --kernel-trace" "--steps 10 --warmup 2 --ke
 run config2_write  "--pmc WRITE_SIZE --kernel-trace" "--steps 10 --warmup 2 --kernel-steps 10 $B"
 run config2_sq     "--pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --kernel-trace" "--steps 10 --warmup 2 --kernel-steps 10 $B"
 run config3        "--kernel-trace --stats" "--workload config3 --steps 3 --warmup 1 --kernel-steps 10 $B"
+run config3_fetch  "--pmc FETCH_SIZE --kernel-trace" "--workload config3 --steps 1 --warmup 1 --kernel-steps 3 $B"
+run config3_write  "--pmc WRITE_SIZE --kernel-trace" "--workload config3 --steps 1 --warmup 1 --kernel-steps 3 $B"
 run config4        "--kernel-trace --stats" "--workload config4 --steps 3 --warmup 1 --kernel-steps 5 $B"
 run config4_fetch  "--pmc FETCH_SIZE --kernel-trace" "--workload config4 --steps 2 --warmup 1 --kernel-steps 3 $B"
 run config4_write  "--pmc WRITE_SIZE --kernel-trace" "--workload config4 --steps 2 --warmup 1 --kernel-steps 3 $B"
