@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--file-subjects", type=int, default=1000000, help="lines of the file -> file leg (config 2/3: 1M = config 3's file)")
     ap.add_argument("--cpu-workers", type=int, default=8, help="processes of the CPU baseline (cpu_baseline.cores)")
     ap.add_argument("--kernel-steps", type=int, default=50, help="runs of the resident-batch kernel loop (roofline)")
+    ap.add_argument("--chunk-lines", type=int, default=0, help="lines per device batch of the stream (default: the whole step, at most %d)" % MAX_CHUNK)
     args = ap.parse_args()
     if args.workload == "full":
         args.workload = "config2"
@@ -117,7 +118,8 @@ def main():
     gname, desc, dflt_n, scaling = WORKLOADS[args.workload]
     n_step = args.subjects or (dflt_n if scaling == "weak" else max(1, dflt_n // world))
     # chunk size of the stream: a divisor of the step so that every step is a whole number of device batches
-    m = (n_step + MAX_CHUNK - 1) // MAX_CHUNK
+    max_chunk = args.chunk_lines if args.chunk_lines > 0 else MAX_CHUNK
+    m = (n_step + max_chunk - 1) // max_chunk
     while n_step % m:
         m += 1
     chunk_lines = n_step // m
