@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -228,6 +229,7 @@ __global__ void grim_finish_kernel(unsigned long long *state, unsigned long long
 struct grim_ctx {
   int device;
   hipStream_t stream;
+  hipStream_t copy_stream;  // D2H of a finished batch while the next batch's kernels run (engine_batch_fetch_async)
   std::string err;
   int n_cu;
   // per-workgroup scratch slots, kept across batches (13 GB at the default sizes: allocating them
@@ -322,7 +324,9 @@ extern "C" grim_ctx *grim_create(int device_id) {
   }
   grim_ctx *c = new grim_ctx();
   c->device = device_id;
-  if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) {
+  c->copy_stream = nullptr;
+  if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) {
     g_err = "grim_create: cannot initialise device";
     delete c;
     return nullptr;
@@ -344,6 +348,7 @@ extern "C" void grim_destroy(grim_ctx *c) {
   c->spare.clear();
   if (c->scratch) hipFree(c->scratch);
   hipStreamDestroy(c->stream);
+  if (c->copy_stream) hipStreamDestroy(c->copy_stream);
   delete c;
 }
 
@@ -510,7 +515,7 @@ static bool pin_realloc(uint8_t *&ptr, uint64_t bytes) {
   return hipHostMalloc((void **)&ptr, bytes ? bytes : 256, hipHostMallocDefault) == hipSuccess;
 }
 
-static uint64_t g_moved[2];
+static std::atomic<uint64_t> g_moved[2];
 
 // lay the arenas out for a batch of at most pl.n_subj subjects and pl.tok_cap tokens; grows them when needed (what
 // they held is lost then) and points the device arguments and the host-side pointers at the new places
@@ -1173,7 +1178,14 @@ extern "C" int grim_batch_counters(const grim_batch *cb, uint64_t out[4]) {
 
 extern "C" uint32_t grim_batch_total_rows(const grim_batch *b) { return b ? b->rows_used : 0; }
 
+static int batch_fetch_on(grim_batch *b, uint32_t res_lo, uint32_t res_hi, grim_row *rows_dst, hipStream_t st);
 int engine_batch_fetch(grim_batch *b, uint32_t res_lo, uint32_t res_hi, grim_row *rows_dst) {
+  return b ? batch_fetch_on(b, res_lo, res_hi, rows_dst, b->ctx->stream) : -1;
+}
+// the whole batch's results over the context's copy stream: the caller has synchronised the kernels (grim_batch_run
+// returned) and may run the NEXT batch's kernels while this copy is in flight; any thread
+int engine_batch_fetch_async(grim_batch *b) { return b ? batch_fetch_on(b, 0, b->n_subj, nullptr, b->ctx->copy_stream) : -1; }
+static int batch_fetch_on(grim_batch *b, uint32_t res_lo, uint32_t res_hi, grim_row *rows_dst, hipStream_t st) {
   if (!b) return -1;
   grim_ctx *c = b->ctx;
   use_device(c->device);
@@ -1198,21 +1210,21 @@ int engine_batch_fetch(grim_batch *b, uint32_t res_lo, uint32_t res_hi, grim_row
   if (whole && b->off_rows - sizeof(grim_subject_result) * (uint64_t)b->n_subj < 4096) {
     // headers and rows are (nearly) back to back: one copy
     const uint64_t bytes = b->rows_used ? b->off_rows + sizeof(grim_row) * (uint64_t)b->rows_used : sizeof(grim_subject_result) * (uint64_t)b->n_subj;
-    if (bytes) HIPCHK(hipMemcpyAsync(b->h_out, b->d_out, bytes, hipMemcpyDeviceToHost, c->stream), c, -1);
+    if (bytes) HIPCHK(hipMemcpyAsync(b->h_out, b->d_out, bytes, hipMemcpyDeviceToHost, st), c, -1);
     g_moved[1] += bytes;
   } else {
     if (res_hi > res_lo) {
       const uint64_t o = sizeof(grim_subject_result) * (uint64_t)res_lo, n = sizeof(grim_subject_result) * (uint64_t)(res_hi - res_lo);
-      HIPCHK(hipMemcpyAsync(b->h_out + o, b->d_out + o, n, hipMemcpyDeviceToHost, c->stream), c, -1);
+      HIPCHK(hipMemcpyAsync(b->h_out + o, b->d_out + o, n, hipMemcpyDeviceToHost, st), c, -1);
       g_moved[1] += n;
     }
     if (b->rows_used) {
       void *dst = rows_dst ? (void *)rows_dst : (void *)(b->h_out + b->off_rows);
-      HIPCHK(hipMemcpyAsync(dst, b->d_out + b->off_rows, sizeof(grim_row) * (uint64_t)b->rows_used, hipMemcpyDeviceToHost, c->stream), c, -1);
+      HIPCHK(hipMemcpyAsync(dst, b->d_out + b->off_rows, sizeof(grim_row) * (uint64_t)b->rows_used, hipMemcpyDeviceToHost, st), c, -1);
       g_moved[1] += sizeof(grim_row) * (uint64_t)b->rows_used;
     }
   }
-  HIPCHK(hipStreamSynchronize(c->stream), c, -1);
+  HIPCHK(hipStreamSynchronize(st), c, -1);
   return 0;
 }
 

@@ -48,6 +48,7 @@ void engine_set_error(grim_ctx *ctx, const char *msg);
 void engine_batch_recycle(grim_batch *b);
 // after a run that returned -2: 1 = the pair pool ran out and the next load will make it big enough (run the same subjects
 // again), 0 = split the batch
+int engine_batch_fetch_async(grim_batch *b);
 uint64_t engine_batch_pool_want(const grim_batch *b);
 void engine_batch_hint_pool(grim_batch *b, uint64_t records);
 int engine_batch_grow_pool(grim_batch *b, uint64_t max_records);

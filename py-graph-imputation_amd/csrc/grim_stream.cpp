@@ -66,9 +66,10 @@ struct StreamRaces : RaceResolver {  // race pair -> prior matrix, shared by eve
   }
 };
 
-enum { CH_FREE = 0, CH_FILLING, CH_TOKENIZING, CH_TOKENIZED, CH_DEVICE_DONE, CH_FORMATTED, CH_COMMITTED, CH_WRITTEN };
+enum { CH_FREE = 0, CH_FILLING, CH_TOKENIZING, CH_TOKENIZED, CH_RUN_DONE, CH_DEVICE_DONE, CH_FORMATTED, CH_COMMITTED, CH_WRITTEN };
 
 struct Chunk {
+  bool fetch_pending = false;  // the kernels are done, the results are still on the device
   int slot_no = 0;
   grim_batch *batch = nullptr;
   uint64_t index = 0, first_line = 0;
@@ -133,7 +134,9 @@ struct grim_stream {
   bool stop = false, failed = false, input_closed = false;
   std::string err;
   std::vector<std::thread> workers;
-  std::thread dev_thread;
+  std::thread dev_thread, copy_thread;
+  std::deque<Chunk *> copy_q;
+  std::condition_variable cv_copy;
   uint64_t next_device = 0, next_commit = 0, next_record = 0, n_done = 0;
 
   int fd[6] = {-1, -1, -1, -1, -1, -1};
@@ -160,6 +163,7 @@ struct grim_stream {
     }
     cv_work.notify_all();
     cv_dev.notify_all();
+    cv_copy.notify_all();
     cv_slot.notify_all();
     cv_rec.notify_all();
     cv_done.notify_all();
@@ -300,10 +304,7 @@ static int device_part(grim_stream *s, Chunk *c, uint32_t lo, uint32_t hi, bool 
   }
   const uint32_t nrows = grim_batch_total_rows(b);
   if (whole) {
-    const auto tp4 = Clock::now();
-    if (engine_batch_fetch(b, 0, c->n_lines, nullptr) != 0) return -1;
-    g_dbg_ns[3] += (uint64_t)(secs(tp4, Clock::now()) * 1e9);
-    c->rows = engine_batch_host(b)->rows;
+    c->fetch_pending = true;  // the copy thread brings the results over while this thread runs the next chunk's kernels
   } else {
     // a part of a chunk: its rows are appended to the chunk's own array and the row offsets of its subjects re-based
     const size_t base = c->extra_rows.size();
@@ -350,11 +351,12 @@ static void device_loop(grim_stream *s) {
       std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
       std::vector<uint32_t> sorted(og.size());
       for (size_t k = 0; k < perm.size(); ++k) sorted[k] = og[perm[k]];
+      c->fetch_pending = false;
       rc = device_part(s, c, 0, c->n_lines, true, sorted);
       if (rc == 0 && !c->extra_rows.empty()) c->rows = c->extra_rows.data();
-      if (rc == 0 && !c->rows) c->rows = engine_batch_host(c->batch)->rows;
     }
     c->device_s = secs(t0, Clock::now());
+    bool to_copy = false;
     {
       std::lock_guard<std::mutex> lk(s->mu);
       s->st.device_s += c->device_s;
@@ -365,6 +367,45 @@ static void device_loop(grim_stream *s) {
         s->fail(std::string("device stage failed: ") + (e ? e : ""));
         return;
       }
+      if (c->n_dev_subjects && c->fetch_pending && c->extra_rows.empty()) {
+        c->state = CH_RUN_DONE;
+        s->copy_q.push_back(c);
+        s->cv_copy.notify_all();
+        to_copy = true;
+      } else {
+        c->state = CH_DEVICE_DONE;
+      }
+    }
+    if (!to_copy) enqueue_format(s, c);
+  }
+}
+
+// the copy thread: D2H of a chunk whose kernels are done, over the context's copy stream
+static void copy_loop(grim_stream *s) {
+  for (;;) {
+    Chunk *c = nullptr;
+    {
+      std::unique_lock<std::mutex> lk(s->mu);
+      for (;;) {
+        if (s->stop || s->failed) return;
+        if (!s->copy_q.empty()) {
+          c = s->copy_q.front();
+          s->copy_q.pop_front();
+          break;
+        }
+        s->cv_copy.wait(lk);
+      }
+    }
+    const auto t0 = Clock::now();
+    const int rc = engine_batch_fetch_async(c->batch);
+    g_dbg_ns[3] += (uint64_t)(secs(t0, Clock::now()) * 1e9);
+    {
+      std::lock_guard<std::mutex> lk(s->mu);
+      if (rc != 0) {
+        s->fail("device stage failed: copying the results to the host");
+        return;
+      }
+      c->rows = engine_batch_host(c->batch)->rows;
       c->state = CH_DEVICE_DONE;
     }
     enqueue_format(s, c);
@@ -858,6 +899,7 @@ extern "C" grim_stream *grim_stream_open(grim_ctx *ctx, const grim_graph *g, con
   s->t_open = Clock::now();
   for (uint32_t i = 0; i < s->n_threads; ++i) s->workers.emplace_back(worker_loop, s);
   s->dev_thread = std::thread(device_loop, s);
+  s->copy_thread = std::thread(copy_loop, s);
   return s;
 }
 
@@ -871,10 +913,12 @@ extern "C" void grim_stream_free(grim_stream *s) {
     s->stop = true;
     s->cv_work.notify_all();
     s->cv_dev.notify_all();
+    s->cv_copy.notify_all();
     s->cv_slot.notify_all();
   }
   for (auto &t : s->workers) t.join();
   if (s->dev_thread.joinable()) s->dev_thread.join();
+  if (s->copy_thread.joinable()) s->copy_thread.join();
   if (s->unlinker.joinable()) s->unlinker.join();
   for (auto &c : s->chunks) engine_batch_recycle(c->batch);
   for (int k = 0; k < 6; ++k)
