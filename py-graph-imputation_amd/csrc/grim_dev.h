@@ -20,7 +20,7 @@
 #define GRIM_NONE 0xFFFFFFFFu
 #define GRIM_VALID 0x8000000000000000ull
 #define GRIM_SIDES (2 * GRIM_MAXPH)
-#define GRIM_COMP_CAP 8192  // >= 2 * GRIM_SIDES * GRIM_TOPCAP
+#define GRIM_COMP_CAP 8192  // >= 2 * GRIM_SIDES * GRIM_TOPCAP (64 KB: stays in the L2; a 512 KB table per workgroup did not)
 #define GRIM_RTOK_CAP 12288 // u16 tokens per slot: 3 versions of up to 4096 alleles per subject
 
 // ---- graph as the kernels see it --------------------------------------------------------------

@@ -41,6 +41,7 @@ struct WgShared {
   // (0xFFFF: none of the list is known to the graph, the list stays); active while `reduced` is set
   uint16_t bestc[GRIM_SIDES][GRIM_MAXL];
   uint8_t reduced;
+  uint32_t comp_mask;  // slots - 1 of the composite-haplotype table as cleared for the current pass (plan B / C)
   // abits[l][c]: bit a set = allele id a is in the subject's list of position l, column c (version 0).
   // The intersection opening tests a graph node against a side with one bit per position.
   uint32_t abits[GRIM_MAXL][2][128];
@@ -385,7 +386,7 @@ __device__ inline uint32_t pair_pass(const DevArgs &A, WgShared &sh, const Slot 
   uint32_t *Af = S.sva, *Aslot = S.svb;
   uint64_t *Akey = S.ska;
   double *Aprob = (double *)S.skb;
-#ifdef GRIM_STAMPS
+#if defined(GRIM_STAMPS) && !defined(GRIM_NO_PP_STAMPS)
   unsigned long long _pp_t0 = wall_clock64();
 #define PP_STAMP(k)                                                                          \
   do {                                                                                       \

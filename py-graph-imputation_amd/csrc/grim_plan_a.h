@@ -216,7 +216,7 @@ __device__ __forceinline__ void store_top(const Slot &S, WgShared &sh, WaveTop &
     if (carry < v) v = carry;
     if (r < n) {
       uint32_t hap = L.hap[r];
-      if (COMP) hap = HAP_COMPOSITE | tab_insert(S.comp, GRIM_COMP_CAP - 1, L.aux[r] | GRIM_VALID);
+      if (COMP) hap = HAP_COMPOSITE | tab_insert(S.comp, sh.comp_mask, L.aux[r] | GRIM_VALID);
       S.Tp[row * GRIM_TOPCAP + r] = L.p[r];
       S.Tm[row * GRIM_TOPCAP + r] = v;
       S.Te[row * GRIM_TOPCAP + r] = hap | ((uint32_t)(L.tie[r] & 0xFF) << 24);

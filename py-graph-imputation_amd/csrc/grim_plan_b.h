@@ -500,8 +500,18 @@ __device__ inline bool side_plan_c(const DevArgs &A, WgShared &sh, const Slot &S
 }
 
 // ---- the fallback passes; each leaves its accepted pairs in the slot (U) and returns their count --------
+// empties the composite-haplotype table for a pass that will hold at most `slots / 2` of them.  All threads call.
+__device__ inline void comp_reset(WgShared &sh, const Slot &S, uint32_t slots) {
+  __syncthreads();
+  if (threadIdx.x == 0) sh.comp_mask = slots - 1;
+  for (uint32_t s = threadIdx.x; s < slots; s += GRIM_WG) S.comp[s] = 0;
+  __syncthreads();
+}
+#define GRIM_COMP_SMALL 8192u  // >= 2 * GRIM_SIDES * GRIM_TOPCAP: one set of top lists
+
 struct PbState {
   uint8_t memo[GRIM_SIDES];
+  uint8_t have[GRIM_SIDES];  // pb_levels: the matrix row whose top list the slot holds for this side (0xFF none, 0xFE the unseen-allele variant)
   uint8_t side_scan[GRIM_SIDES], side_any[GRIM_SIDES];
   uint32_t absent_side[2];
   uint32_t flag;
@@ -567,23 +577,47 @@ __device__ inline uint32_t pb_levels(const DevArgs &A, WgShared &sh, const Slot 
   const int nph = sh.nph;
   for (int level = 0; level < 2; ++level) {
     const double *prior = A.priors + (uint64_t)(level == 0 ? sh.subj.prior_idx : A.ones_prior) * P * P;
-    if (tid < GRIM_SIDES) st.memo[tid] = 10;
+    if (tid < GRIM_SIDES) {
+      st.memo[tid] = 10;
+      st.have[tid] = 0xFF;
+      sh.Tn[tid] = 0;
+    }
+    // the composite-haplotype table serves the rows of the level as long as it has room: a side whose best row is known
+    // keeps its list from one row to the next (the reference recomputes it for every later row: same arguments, same list)
+    comp_reset(sh, S, GRIM_COMP_CAP);
+    if (tid == 0) sh.bc[7] = 0;  // entries the table may hold
     __syncthreads();
     for (int m = 0; m < (int)A.prm.planb_rows; ++m) {
       STAMP_BEGIN();
-      for (int s = tid; s < GRIM_COMP_CAP; s += GRIM_WG) S.comp[s] = 0;
-      if (tid < GRIM_SIDES) sh.Tn[tid] = 0;
-      __syncthreads();
+      if (sh.bc[7] > GRIM_COMP_CAP / 4) {  // the next row's lists might not fit: start over with an empty table
+        comp_reset(sh, S, GRIM_COMP_CAP);
+        if (tid < GRIM_SIDES) {
+          st.have[tid] = 0xFF;
+          sh.Tn[tid] = 0;
+        }
+        if (tid == 0) sh.bc[7] = 0;
+        __syncthreads();
+      }
       for (int s = wave_id(); s < 2 * nph; s += GRIM_NWAVE) {
         if (!(st.side_any[s] && st.side_any[s ^ 1])) continue;  // phase dropped by open_phases
         SideSpec sp = side_spec(A, sh, s >> 1, s & 1);
         const uint32_t ab = st.absent_side[s & 1];
         if (ab == 0) {
           int idx = m < (int)st.memo[s] ? m : (int)st.memo[s];
+          if ((int)st.have[s] == idx) continue;  // the list of this row is in place
           bool nonempty = side_row(A, sh, S, prior, wt[wave_id()], sp, tok, idx, s);
-          if (nonempty && lane_id() == 0) st.memo[s] = (uint8_t)idx;
+          if (lane_id() == 0) {
+            st.have[s] = (uint8_t)idx;
+            if (nonempty) st.memo[s] = (uint8_t)idx;
+            atomicAdd(&sh.bc[7], sh.Tn[s]);
+          }
         } else {
+          if (st.have[s] == 0xFE) continue;
           side_absent(A, sh, S, prior, wt[wave_id()], sp, tok, ab, s);
+          if (lane_id() == 0) {
+            st.have[s] = 0xFE;
+            atomicAdd(&sh.bc[7], sh.Tn[s]);
+          }
         }
       }
       __syncthreads();
@@ -593,7 +627,7 @@ __device__ inline uint32_t pb_levels(const DevArgs &A, WgShared &sh, const Slot 
       if (nU) return nU;
     }
     // rescue loop (impute.py:1490-1558): its six iterations are identical, one suffices
-    for (int s = tid; s < GRIM_COMP_CAP; s += GRIM_WG) S.comp[s] = 0;
+    comp_reset(sh, S, GRIM_COMP_SMALL);
     if (tid < GRIM_SIDES) sh.Tn[tid] = 0;
     __syncthreads();
     for (int s = wave_id(); s < 2 * nph; s += GRIM_NWAVE) {
@@ -623,7 +657,7 @@ __device__ inline uint32_t pb_plan_a(const DevArgs &A, WgShared &sh, const Slot 
   const int P = A.g.P;
   const int nph = sh.nph;
   const double *prior = A.priors + (uint64_t)sh.subj.prior_idx * P * P;
-  for (int s = tid; s < GRIM_COMP_CAP; s += GRIM_WG) S.comp[s] = 0;
+  comp_reset(sh, S, GRIM_COMP_SMALL);
   if (tid < GRIM_SIDES) sh.Tn[tid] = 0;
   __syncthreads();
   for (int s = wave_id(); s < 2 * nph; s += GRIM_NWAVE) {
@@ -680,7 +714,7 @@ __device__ inline uint32_t pb_plan_c(const DevArgs &A, WgShared &sh, const Slot 
   const int P = A.g.P;
   const int nph = sh.nph;
   const double *prior = A.priors + (uint64_t)A.ones_prior * P * P;
-  for (int s = tid; s < GRIM_COMP_CAP; s += GRIM_WG) S.comp[s] = 0;
+  comp_reset(sh, S, GRIM_COMP_SMALL);
   if (tid < GRIM_SIDES) sh.Tn[tid] = 0;
   __syncthreads();
   for (int s = wave_id(); s < 2 * nph; s += GRIM_NWAVE) {
