@@ -441,6 +441,7 @@ static bool tokenise_gl_fast(const DictSnap &D, sv gl, grim_subject &sj, uint16_
 void tokenize_range(const TokParams &prm, const char *text, uint64_t lo, uint64_t hi, TokRange &R) {
   const DictSnap &D = *prm.snap;
   Scratch sc;
+  const bool fast = !getenv("GRIM_NO_FAST_TOKENIZER");  // tests: every line through the general path
   std::vector<uint16_t> tmp_tok;  // dense mode: the current subject's tokens
   uint32_t line_no = 0;
   uint64_t a = lo;
@@ -506,7 +507,7 @@ void tokenize_range(const TokParams &prm, const char *text, uint64_t lo, uint64_
         // worst case one token per two bytes
         if (tmp_tok.size() < gl.size() / 2 + 8) tmp_tok.resize(gl.size() / 2 + 8);
         uint64_t nt = 0;
-        if (tokenise_gl_fast(D, gl, sj, tmp_tok.data(), tmp_tok.size(), nt))
+        if (fast && tokenise_gl_fast(D, gl, sj, tmp_tok.data(), tmp_tok.size(), nt))
           kind = K_DEV;
         else
           kind = tokenise_gl(D, gl, prm.planb, sc, sj, tmp_tok.data(), tmp_tok.size(), nt, R.ov, R.ov_pool, line_no, tok_overflow);
@@ -516,7 +517,7 @@ void tokenize_range(const TokParams &prm, const char *text, uint64_t lo, uint64_
           R.n_tok = R.tok.size();
         }
       } else {
-        if (tokenise_gl_fast(D, gl, sj, R.tok_dst, R.tok_cap, R.n_tok))
+        if (fast && tokenise_gl_fast(D, gl, sj, R.tok_dst, R.tok_cap, R.n_tok))
           kind = K_DEV;
         else
           kind = tokenise_gl(D, gl, prm.planb, sc, sj, R.tok_dst, R.tok_cap, R.n_tok, R.ov, R.ov_pool, line_no, tok_overflow);

@@ -135,3 +135,46 @@ def test_cpp_prior_matrix_bit_identical_to_python():
                 a = imp._prior_matrix(r1, r2, pri)
             b = nat.prior_matrix(ps, pp, r1, r2)
             assert np.array_equal(np.asarray(a, dtype=np.float64).view(np.uint64), b.view(np.uint64)), (pp, r1, r2)
+
+
+def test_fast_tokenizer_path_equals_general_path(monkeypatch):
+    """the single-pass fast path for regular GL strings against the general path (GRIM_NO_FAST_TOKENIZER) on seeded
+    subjects with the fuzzer's mutations: same kinds, same subject records, same tokens, byte for byte"""
+    import sys
+
+    from grim import _native as nat
+    from grim.imputation.networkx_graph import Graph
+    from grim.run_impute_def import load_config
+
+    sys.path.insert(0, os.path.join(harness.ROOT, "tools"))
+    import fuzz
+
+    work = harness.ensure_graph("pop4")
+    cwd = os.getcwd()
+    os.chdir(work)
+    try:
+        cfg, _ = load_config("graph_conf.json")
+        g = Graph(cfg).build_graph(cfg["node_file"], cfg["top_links_file"], cfg["edges_file"])
+    finally:
+        os.chdir(cwd)
+    rows = synth.read_freqs(synth.CAU_FREQS)
+    pops = harness.POPS["pop4"]
+    rng = np.random.default_rng(12)
+    gen = synth.SubjectGen(rows, 99, pops=pops)
+    lines = gen.full(3000) + gen.mixed(6000, amb=0.5, miss=0.3, recomb=0.3)
+    lines = [fuzz.mutate(l, rng, gen.by_locus) if rng.random() < 0.3 else l for l in lines]
+    text = ("\n".join(lines) + "\n").encode()
+    out = []
+    for no_fast in (False, True):
+        if no_fast:
+            monkeypatch.setenv("GRIM_NO_FAST_TOKENIZER", "1")
+        else:
+            monkeypatch.delenv("GRIM_NO_FAST_TOKENIZER", raising=False)
+        parsed = nat.Parsed(g.adict, text, True)
+        out.append((bytes(parsed.kinds()), parsed.subjects().tobytes(), parsed.tokens().tobytes(), list(parsed.dev_index())))
+        parsed.close()
+    assert out[0][0] == out[1][0]
+    assert out[0][3] == out[1][3]
+    assert out[0][1] == out[1][1]
+    assert out[0][2] == out[1][2]
+    assert out[0][0].count(bytes([nat.K_DEVICE])) > 8000  # most lines are device subjects (the fast path's clientele)
