@@ -135,3 +135,29 @@ def test_two_live_batches_on_one_context():
     big.run()
     small.close()
     big.close()
+
+
+def test_graph_from_freqs_serves_impute(tmp_path, monkeypatch):
+    """grim.graph_from_freqs (hpf.csv -> arrays, no graph CSVs) gives impute(conf, graph=g) the graph that graph_freqs +
+    Graph.build_graph give it: the reference's sample run comes out byte for byte"""
+    from graph_generation.generate_hpf import produce_hpf
+    from grim import grim
+
+    work = tmp_path
+    os.makedirs(work / "data" / "freqs")
+    os.makedirs(work / "data" / "subjects")
+    shutil.copy(os.path.join(harness.GOLD, "data", "freqs", "CAU.freqs.gz"), work / "data" / "freqs")
+    shutil.copy(os.path.join(harness.GOLD, "data", "subjects", "donor.csv"), work / "data" / "subjects")
+    gname, conf, lines, exp, elog, em = harness.golden("cau_min")
+    conf["imputation_in_file"] = "data/subjects/donor.csv"
+    json.dump(conf, open(work / "conf.json", "w"))
+    monkeypatch.chdir(work)
+    with contextlib.redirect_stdout(io.StringIO()):
+        produce_hpf(conf_file="conf.json")
+        g = grim.graph_from_freqs("conf.json")
+        assert not os.path.exists(work / "output" / "csv" / "nodes.csv")  # no graph CSV was written
+        g2 = grim.impute(conf_file="conf.json", graph=g)
+    assert g2 is g
+    got = _texts(work / "output")
+    for k in exp:
+        assert got[k] == exp[k], k
