@@ -1126,11 +1126,34 @@ __global__ __launch_bounds__(64) void grim_tables_bucket_kernel(DevArgs A) {
   // of units: an item's records are then pulled into one L2 instead of eight
   const uint32_t nwg = gridDim.x, q8 = nwg / 8, r8 = nwg % 8, xcd = blockIdx.x % 8;
   const uint32_t vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + blockIdx.x / 8;
-  for (uint32_t k = A.queue[15] + vid; k < n_units; k += nwg) {
-    const TabUnit un = A.tunits[k];
+  // The chain unit header -> pair numbers -> records -> (grouping) -> group counter -> group records is a row of dependent
+  // memory round trips; the NEXT unit's header and pair numbers are fetched while this unit's group counter is on its way.
+  uint32_t k = A.queue[15] + vid;
+  TabUnit un;
+  uint32_t pre[TAB_NB / 64];  // the unit's pair numbers, lane + 64 i
+  auto fetch = [&](uint32_t kk, TabUnit &u, uint32_t (&idx)[TAB_NB / 64]) {
+    u.n = 0;
+    u.tb = 0;
+    if (kk < n_units) {
+      u = A.tunits[kk];
+      if ((u.tb >> 28) < 2 && u.n <= TAB_NB) {
+        const uint32_t *src = A.psort + (uint64_t)(u.tb >> 28) * A.tstride + u.off + u.lo;
+#pragma unroll
+        for (int i = 0; i < TAB_NB / 64; ++i) idx[i] = (uint32_t)(lane + 64 * i) < u.n ? src[lane + 64 * i] : 0u;
+      }
+    }
+  };
+  fetch(k, un, pre);
+  while (k < n_units) {
     TabAux &x = A.taux[un.item];
     const uint32_t t = un.tb >> 28, n = un.n;
-    if (n == 0) continue;
+    TabUnit nxt;
+    uint32_t npre[TAB_NB / 64];
+    if (n == 0) {
+      k += nwg;
+      fetch(k, un, pre);
+      continue;
+    }
     if (t == 2) {  // a population cell: the left-to-right sum of its probabilities
       const double s = wave_chain(A.pprob + un.off + un.lo, n);
       if (lane == 0) {
@@ -1140,18 +1163,24 @@ __global__ __launch_bounds__(64) void grim_tables_bucket_kernel(DevArgs A) {
         cr.pad = 0;
         A.tcell[x.cell_base + (un.tb & 0x0FFFFFFFu)] = cr;
       }
+      k += nwg;
+      fetch(k, un, pre);
       continue;
     }
     if (n > TAB_NB) {  // a bucket the arena cannot hold: the merge kernel takes the HBM path for this table
       if (lane == 0) atomicExch(&x.overflow[t], 1u);
+      k += nwg;
+      fetch(k, un, pre);
       continue;
     }
-    const uint32_t *src = A.psort + (uint64_t)t * A.tstride + un.off + un.lo;
-    for (uint32_t i = lane; i < n; i += 64) W.uidx[i] = src[i];
+#pragma unroll
+    for (int i = 0; i < TAB_NB / 64; ++i)
+      if ((uint32_t)(lane + 64 * i) < n) W.uidx[lane + 64 * i] = pre[i];
     WAVE_SYNC();
     const uint32_t nruns = wave_group_pairs(W, t == 0 ? 0 : 1, P, A.ppool + un.off, n);
     uint32_t g0 = 0;
     if (lane == 0) g0 = atomicAdd(&x.ng[t], nruns);
+    fetch(k + nwg, nxt, npre);  // in flight together with the counter
     g0 = __shfl(g0, 0);
     const double *gs = (const double *)W.tab;
     GrpRec *dst = A.pgrp + (uint64_t)t * A.tstride + un.off + g0;
@@ -1163,6 +1192,10 @@ __global__ __launch_bounds__(64) void grim_tables_bucket_kernel(DevArgs A) {
       dst[j] = gr;
     }
     WAVE_SYNC();
+    k += nwg;
+    un = nxt;
+#pragma unroll
+    for (int i = 0; i < TAB_NB / 64; ++i) pre[i] = npre[i];
   }
 }
 
