@@ -40,8 +40,9 @@ struct WaveTabT1 : WaveTab<TAB_N> {
 #define TAB_NB 256         // pairs per bucket the bucket kernel holds
 #endif
 #ifndef TAB_DIV
-#define TAB_DIV 96u         // a table of n pairs is dealt into the power of two >= n / TAB_DIV buckets (48..96 pairs on average:
-                           // measured 2.1 ms against 2.5 ms per 400 000 buckets with 24..48)
+#define TAB_DIV 128u        // a table of n pairs is dealt into the power of two >= n / TAB_DIV buckets (64..128 pairs on average).
+                           // Measured with the sort-free grouping, table kernels per 100 k config-4 subjects: 7.5 ms at 64, 7.3 at 96,
+                           // 6.7 at 128 (a unit's fixed cost -- header, pair numbers, group counter -- weighs more than its pairs)
 #endif
 
 struct TabShared {
