@@ -202,7 +202,9 @@ __device__ inline uint32_t pair_offsets(WgShared &sh) {
 // ---- the two top lists of ONE phase in LDS (over the radix-histogram area, free during the pair stage) -----------------
 // The pair loops below go phase by phase: 2 x <=128 entries are staged once and the phase's <=16 384 pairs read them from
 // LDS -- five gathers per pair from per-workgroup HBM scratch were the cost of the pair stage.
+#ifndef GRIM_TILE_MIN
 #define GRIM_TILE_MIN 8192u  // scored pairs from which the pair stage goes phase by phase through LDS tiles
+#endif
 struct PairTile {
   double p1[GRIM_TOPCAP], p2[GRIM_TOPCAP], m2[GRIM_TOPCAP];
   uint32_t e1[GRIM_TOPCAP], e2[GRIM_TOPCAP];
