@@ -77,6 +77,11 @@ def main():
     ap.add_argument("--cpu-workers", type=int, default=8, help="processes of the CPU baseline (cpu_baseline.cores)")
     ap.add_argument("--kernel-steps", type=int, default=50, help="runs of the resident-batch kernel loop (roofline)")
     ap.add_argument("--chunk-lines", type=int, default=0, help="lines per device batch of the stream (default: the whole step, at most %d)" % MAX_CHUNK)
+    ap.add_argument("--min-seconds", type=float, default=1.0, help="the timed region of --steps steps is repeated until it has run this long in total; "
+                    "ms_per_step is the MEDIAN region (min / max beside it)")
+    ap.add_argument("--max-repeats", type=int, default=400)
+    ap.add_argument("--sharded", action="store_true", help="time the product's multi-GPU driver instead: grim.shard.impute_sharded, subject file on disk -> "
+                    "the six merged output files on disk, chunks pulled from the job's store (a step = one whole file)")
     args = ap.parse_args()
     if args.workload == "full":
         args.workload = "config2"
@@ -164,24 +169,31 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    if args.sharded:
+        return sharded_leg(args, rank, world, dist, work, conf, cfg, graph, lines, gname, desc, n_step, scaling)
+
     # ---- A. headline: host strings -> host records, K steps through one stream ------------------------
+    # One timed REGION = exactly --steps steps between two barriers.  A region of config 2 lasts a few milliseconds, far too
+    # short to measure on a shared box, so the region is repeated (same stream, pipeline drained in between) until the regions
+    # add up to --min-seconds; the reported step time is the median region's, with the fastest and slowest beside it.
     st = nat.Stream(ctx, dgraph, graph.adict, params, ps, cfg["pops"], want_text=False, want_records=True,
                     chunk_lines=chunk_lines, depth=4)
     chunks_per_step = n_step // chunk_lines
-    go = threading.Event()
+    import queue
+    cmds = queue.Queue()
     feed_err = []
 
     def feed():
         try:
-            for _ in range(args.warmup):
-                st.write(text)
-            go.wait()
-            for _ in range(args.steps):
-                st.write(text)
+            while True:
+                n = cmds.get()
+                if n is None:
+                    break
+                for _ in range(n):
+                    st.write(text)
             st.finish()
         except Exception as e:  # pragma: no cover
             feed_err.append(e)
-            go.set()
 
     th = threading.Thread(target=feed)
     th.start()
@@ -198,26 +210,39 @@ def main():
             seen["rows"] += int(res["n_rows"].sum()) if len(res) else 0
             st.release(handle)
 
+    def agree_max(x):
+        if dist is None:
+            return x
+        import torch
+        t = torch.tensor([x], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def region():
+        sync_barrier()
+        t0 = time.perf_counter()
+        cmds.put(args.steps)
+        drain(args.steps * chunks_per_step)
+        sync_barrier()
+        return agree_max(time.perf_counter() - t0)  # max over ranks
+
+    cmds.put(args.warmup)
     drain(args.warmup * chunks_per_step)
-    sync_barrier()
     seen.update(lines=0, ok=0, rows=0)
-    t0 = time.perf_counter()
-    go.set()
-    drain(args.steps * chunks_per_step)
-    sync_barrier()
-    elapsed = time.perf_counter() - t0
+    regions = [region()]
+    n_ok_per_step = seen["ok"] // max(1, args.steps)
+    repeats = int(min(args.max_repeats, max(3, -(-args.min_seconds // max(regions[0], 1e-9)))))  # the same on every rank
+    while len(regions) < repeats:
+        regions.append(region())
+    cmds.put(None)
     th.join()
     if feed_err:
         raise feed_err[0]
     assert st.next_records() is None
     sstats = st.stats()
     st.close()
-    n_ok_per_step = seen["ok"] // max(1, args.steps)
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    regions.sort()
+    elapsed = regions[len(regions) // 2]  # the median region: exactly --steps steps
 
     # ---- B. kernels only: the same batch resident in HBM (roofline input) ----------------------------------
     parsed = nat.Parsed(graph.adict, text, cfg["planb"])
@@ -258,17 +283,19 @@ def main():
     # HBM traffic per launch of the dominant kernel: PMC numbers cannot be collected from inside this process; they
     # come from the committed rocprofv3 --pmc passes over this same command (tools/profile_round.sh)
     traffic, traffic_src = None, None
-    pmc_path = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
+    pmc_path = os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")
+    if not os.path.exists(pmc_path):
+        pmc_path = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
     if os.path.exists(pmc_path):
         pmc = json.load(open(pmc_path)).get(args.workload, {}).get(names[dom])
         if pmc and "hbm_bytes_raw" in pmc and n_step == dflt_n:
             traffic = pmc["hbm_bytes_raw"]
-            traffic_src = "profiles/r2_pmc_traffic.json: (FETCH_SIZE + WRITE_SIZE) KB x 1024 per launch, separate --pmc passes; " \
+            traffic_src = "profiles/" + os.path.basename(pmc_path) + ": (FETCH_SIZE + WRITE_SIZE) KB x 1024 per launch, separate --pmc passes; " \
                           "with FETCH_SIZE doubled (gfx950 wide-read correction): %d" % pmc["hbm_bytes_fetch_doubled"]
 
     out = None
     if rank == 0:
-        total_subjects = world * n_step * args.steps
+        total_subjects = world * n_step * args.steps  # per region
         out = {
             "metric": "imputed subjects/sec (whole node), 5-locus CAU graph",
             "value": total_subjects / elapsed,
@@ -277,6 +304,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step_min": 1e3 * regions[0] / args.steps, "ms_per_step_max": 1e3 * regions[-1] / args.steps,
+            "repeats": len(regions), "timed_s": sum(regions),
             "higher_is_better": True,
             "scaling": scaling,
             "vs_baseline": None,
@@ -289,8 +318,9 @@ def main():
                 "graph_nodes": int(graph.arrays["n_nodes"]), "populations": P,
                 "timed_region": "host GL strings in memory -> grim_stream (tokenizer threads, pinned staging, H2D, kernels, D2H) -> "
                                 "result records in pinned host memory, read by the caller; %d device batch(es) of %d lines per step, "
-                                "4 in flight" % (chunks_per_step, chunk_lines),
-                "host_threads": int(os.environ.get("GRIM_HOST_THREADS", "0")) or min(32, os.cpu_count() or 1),
+                                "4 in flight; value = subjects of one region of --steps steps / the MEDIAN region time over `repeats` "
+                                "back-to-back regions (barrier + drained pipeline on both sides of each)" % (chunks_per_step, chunk_lines),
+                "host_threads": int(os.environ.get("GRIM_HOST_THREADS", "0")) or int(nat.host_lib().grim_default_threads()),
                 "stream_cpu_s": {"tokenize": sstats.tokenize_cpu_s, "device_thread_busy": sstats.device_s},
             },
             "kernel_only": {
@@ -315,6 +345,69 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def sharded_leg(args, rank, world, dist, work, conf, cfg, graph, lines, gname, desc, n_step, scaling):
+    """--sharded: the product's multi-GPU driver, file -> files.  Every rank calls grim.shard.impute_sharded on the SAME
+    conf; chunks of --chunk-lines lines (default 65536) are pulled from the job's store, every rank streams its chunks
+    through one long-lived grim_stream into part files, rank 0 assembles the six outputs with copy_file_range.  A step =
+    the whole file (world x n_step subjects); --steps steps timed one by one, median reported."""
+    from grim import shard
+
+    all_lines = lines
+    if dist is not None:  # every rank generated its slice of the strong-scaling workload: the file is the whole of it
+        gathered = [None] * world
+        dist.all_gather_object(gathered, lines)
+        all_lines = [l for part in gathered for l in part]
+    path = os.path.join(work, "data", "subjects", "bench_sharded.csv")
+    out_dir = os.path.join(work, "output_bench_sharded")
+    c2 = dict(conf)
+    c2["imputation_in_file"] = "data/subjects/bench_sharded.csv"
+    c2["imputation_out_path"] = "output_bench_sharded"
+    cpath = os.path.join(work, "conf_bench_sharded.json")
+    if rank == 0:
+        with open(path, "w") as fh:
+            fh.write("\n".join(all_lines) + "\n")
+        json.dump(c2, open(cpath, "w"))
+        os.makedirs(out_dir, exist_ok=True)
+    if dist is not None:
+        dist.barrier()
+    chunk = args.chunk_lines or 65536
+    times = []
+    for k in range(args.warmup + args.steps):
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        shard.impute_sharded(cpath, graph=graph, chunk_lines=chunk)  # ends with the job's barrier
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            import torch
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        if k >= args.warmup:
+            times.append(dt)
+    times.sort()
+    med = times[len(times) // 2]
+    if rank == 0:
+        sizes = {k: os.path.getsize(os.path.join(out_dir, f)) for k, f in (("umug", "don.umug"), ("pmug", "don.pmug")) if os.path.exists(os.path.join(out_dir, f))}
+        print(json.dumps({
+            "metric": "imputed subjects/sec (whole node), 5-locus CAU graph", "value": len(all_lines) / med, "unit": "subjects/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * med,
+            "ms_per_step_min": 1e3 * times[0], "ms_per_step_max": 1e3 * times[-1], "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": desc + "; --sharded: grim.shard.impute_sharded, subject file on disk -> six merged output files on disk "
+                                          "(page cache, no fsync), %d subjects in the file, chunks of %d lines pulled from the job's store" % (len(all_lines), chunk),
+                       "subjects_per_step": len(all_lines), "host_threads_per_rank": int(nat_threads()), "output_bytes": sizes},
+        }))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def nat_threads():
+    from grim import _native as nat
+    return nat.host_lib().grim_default_threads()
 
 
 def file_leg(args, work, conf, cfg, imp, lines, rows, n_step):
@@ -345,7 +438,8 @@ def file_leg(args, work, conf, cfg, imp, lines, rows, n_step):
             best, stats = dt, dict(imp.last_stats)
     return {
         "subjects": n_file, "seconds": best, "subjects_per_s": n_file / best,
-        "what": "Imputation.impute_file: subject file on disk -> .umug/.umug.pops/.pmug/.pmug.pops/.miss/.problem on disk (best of 3)",
+        "what": "Imputation.impute_file: subject file on disk -> .umug/.umug.pops/.pmug/.pmug.pops/.miss/.problem on disk (best of 3; "
+                "page cache, no fsync -- the reference does not sync either)",
         "pipeline_wall_s": stats.get("wall_s"), "device_thread_busy_s": stats.get("device_s"),
         "cpu_s": stats.get("host_s"), "output_bytes": sum(stats.get("text_bytes", [])[:6]), "chunks": stats.get("chunks"),
     }

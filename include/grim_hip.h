@@ -7,8 +7,9 @@
  * reference tree).  Plain pointers and sizes only; the library copies what it is given, owns
  * what it returns, and never calls back into the host language.
  *
- * Threading: one grim_ctx per GPU, used by one host thread at a time.  Independent contexts
- * are independent.
+ * Threading: one grim_ctx per GPU.  The block entry points (grim_batch_*) of a context are used by one host thread at
+ * a time; a grim_stream runs its own threads on its context (one stream per context at a time).  Independent contexts
+ * are independent.  grim_last_error returns a copy private to the calling thread.
  * Errors: functions return 0 on success, <0 on error (grim_last_error gives the text);
  * constructors return NULL on error.  Per-subject outcomes (miss / needs-fallback) are DATA in
  * grim_subject_result.status, never a call failure.
@@ -289,8 +290,8 @@ int grim_prior_matrix(const grim_prior_spec *spec, const char *const *pop_names,
 typedef struct grim_stream grim_stream;
 typedef struct {
   uint32_t chunk_lines;     /* lines per device batch; 0 = 131072 */
-  uint32_t depth;           /* chunks in flight; 0 = 3 */
-  int32_t n_threads;        /* tokenizer / formatter threads; 0 = all cores (at most 32) */
+  uint32_t depth;           /* chunks in flight; 0 = 4 */
+  int32_t n_threads;        /* tokenizer / formatter threads; 0 = grim_default_threads() */
   uint64_t line_offset;     /* global index of the first line (multi-GPU shards keep the reference's line numbers) */
   uint64_t rows_per_chunk;  /* row pool of one chunk; 0 = 32 rows per line (never less than one subject's worst case) */
   uint8_t want_text;        /* format the six output texts */
@@ -323,8 +324,22 @@ grim_stream *grim_stream_open(grim_ctx *ctx, const grim_graph *g, const grim_dic
                               const grim_prior_spec *priors, const char *const *pop_names, uint32_t n_pops,
                               const grim_stream_opts *opts);
 int grim_stream_write(grim_stream *s, const char *text, uint64_t len);
-/* reads the file in blocks and feeds it (universal newlines: "\r\n" and "\r" end a line too, as Python's open()) */
+/* the same with universal newlines, as Python's open(): "\r\n" and "\r" end a line too (a "\r\n" may straddle two calls) */
+int grim_stream_write_text(grim_stream *s, const char *text, uint64_t len);
+/* reads the file in blocks and feeds it through grim_stream_write_text */
 int grim_stream_write_file(grim_stream *s, const char *path);
+/* Input segments -- what a rank of grim/shard.py feeds: byte ranges of ONE file that are not adjacent (the chunks it pulled
+ * from the job's counter; scripts/runfile_mp.py:109-148 gives every worker ONE contiguous range instead).  grim_stream_segment
+ * ends the current segment -- the line being filled is complete, with or without its newline -- and starts the next one at
+ * global line index next_line_offset.  After grim_stream_finish, grim_stream_segment_end(k) gives the cumulative bytes of
+ * the seven texts up to the end of segment k (segment 0 starts at the stream's line_offset), i.e. where segment k's part of
+ * every output file ends. */
+int grim_stream_segment(grim_stream *s, uint64_t next_line_offset);
+uint32_t grim_stream_n_segments(const grim_stream *s);
+int grim_stream_segment_end(const grim_stream *s, uint32_t k, uint64_t out[7]);
+/* worker threads a stream starts when opts.n_threads is 0: cores of this process's affinity mask / ranks on this host
+ * (LOCAL_WORLD_SIZE, else WORLD_SIZE), at most 32 */
+uint32_t grim_default_threads(void);
 /* end of input: processes the last partial chunk and waits until every chunk is written; 0 or <0 (grim_stream_error) */
 int grim_stream_finish(grim_stream *s);
 const char *grim_stream_error(const grim_stream *s);

@@ -113,6 +113,7 @@ struct DevArgs {
   GrpRec *pgrp;
   double *pprob;
 };
+#define GRIM_F_NO_NODUP 2u       // DevArgs.flags (GRIM_NO_NODUP=1): the pair passes always run their dedup (test switch)
 #define GRIM_NQ 24               // u32 words of `queue` (the run state block is counters + queue):
                                  // [13] bucket-start slots used [14] work units [15] their work counter
                                  // [16] / [17] work counters of the split / merge kernel
@@ -132,8 +133,8 @@ __device__ __forceinline__ void push_next(const DevArgs &A, uint32_t si, bool he
 // ---- optional stage timers (diagnostic build only: hipcc -DGRIM_STAMPS; never in the shipped .so) ----
 #define GRIM_STAMP_BASE (8 + 4 * 64)
 #ifdef GRIM_STAMPS
-#define GRIM_HIST_BASE (GRIM_STAMP_BASE + 16)  // diagnostic build: log2 histograms, 4 x 24 buckets
-#define GRIM_NCTR (8 + 4 * 64 + 16 + 96)
+#define GRIM_HIST_BASE (GRIM_STAMP_BASE + 16)  // diagnostic build: log2 histograms, 8 x 24 buckets
+#define GRIM_NCTR (8 + 4 * 64 + 16 + 192)
 #else
 #define GRIM_NCTR (8 + 4 * 64 + 16)
 #endif
@@ -148,7 +149,7 @@ __device__ __forceinline__ void push_next(const DevArgs &A, uint32_t si, bool he
       _t0 = _t1;                                                           \
     }                                                                      \
   } while (0)
-// HIST(h, v, w): bucket floor(log2(v+1)) of histogram h (0..3) += w
+// HIST(h, v, w): bucket floor(log2(v+1)) of histogram h (0..7) += w
 #define HIST(h, v, w)                                                                                  \
   do {                                                                                                 \
     if (threadIdx.x == 0) {                                                                            \

@@ -10,6 +10,7 @@
 #include <string.h>
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -111,6 +112,11 @@ __global__ __launch_bounds__(GRIM_WG, GRIM_WG_PER_CU) void grim_plan_a_kernel(De
       }
       const unsigned long long t_pairs = STAMP_NOW();
       (void)t_pairs;
+      HIST(3, nU, 1);
+      HIST(4, np, 1);
+      HIST(5, sh.poff[0] + [&]() { uint32_t e = 0; for (int s = 0; s < 2 * sh.nph; ++s) e += sh.Tn[s]; return e; }(), 1);
+      HIST(6, nU, nU);
+      HIST(7, nU, (t_pairs - t_subject) / 100);
       if (nU > 0) {
         emit_tables(A, sh, S, nU, sh.out, si);
         STAMP(12);
@@ -230,7 +236,12 @@ struct grim_ctx {
   int device;
   hipStream_t stream;
   hipStream_t copy_stream;  // D2H of a finished batch while the next batch's kernels run (engine_batch_fetch_async)
+  // Two threads of a stream use one context at the same time (device thread: loads and launches; copy thread: waits,
+  // second stages, D2H), so the error text is written and read under its own lock; grim_last_error hands out a
+  // per-thread copy.  Everything else a context owns is either immutable after grim_create or guarded by run_mu.
+  std::mutex err_mu;
   std::string err;
+  std::mutex run_mu;        // binding the scratch block / launching a run's kernels: one thread at a time
   int n_cu;
   // per-workgroup scratch slots, kept across batches (13 GB at the default sizes: allocating them
   // per batch cost more than the kernels)
@@ -281,6 +292,9 @@ struct grim_batch {
   uint32_t n_medium;
   uint32_t n_small, n_general, small_stride;
   uint64_t scratch_need;  // bytes of per-workgroup scratch this batch's runs need (bound at run time)
+  hipEvent_t ev_done;  // recorded behind the last kernel of a stage: what engine_batch_wait waits for (not the whole stream --
+                       // the device thread may have queued the next chunk's kernels behind it already)
+  bool enqueued;       // stage 1 is in flight (engine_batch_enqueue without its engine_batch_wait)
   hipEvent_t ev[14];  // timing mode, kernel start/stop: [3]/[5] half-wave, [0]/[1] one-wave, [6]/[7] general, [4]/[2] Plan B,
                       // [8]/[9] table kernels of stage 1, [10]/[11] table kernels after Plan B
   bool timing;       // GRIM_TIMING=1 or grim_batch_set_timing: direct launches with per-kernel events instead of the graph replay
@@ -295,13 +309,19 @@ struct grim_batch {
 
 static thread_local std::string g_err;
 
+static void set_err(grim_ctx *c, const std::string &m) {
+  g_err = m;
+  if (c) {
+    std::lock_guard<std::mutex> lk(c->err_mu);
+    c->err = m;
+  }
+}
+
 #define HIPCHK(call, ctxp, ret)                                                        \
   do {                                                                                 \
     hipError_t e_ = (call);                                                            \
     if (e_ != hipSuccess) {                                                            \
-      std::string m_ = std::string(#call) + ": " + hipGetErrorString(e_);             \
-      if (ctxp) (ctxp)->err = m_;                                                      \
-      g_err = m_;                                                                      \
+      set_err((ctxp), std::string(#call) + ": " + hipGetErrorString(e_));             \
       return ret;                                                                      \
     }                                                                                  \
   } while (0)
@@ -352,7 +372,13 @@ extern "C" void grim_destroy(grim_ctx *c) {
   delete c;
 }
 
-extern "C" const char *grim_last_error(grim_ctx *c) { return c ? c->err.c_str() : g_err.c_str(); }
+extern "C" const char *grim_last_error(grim_ctx *c) {
+  if (c) {  // a copy private to the calling thread: the context's text may be rewritten by another thread meanwhile
+    std::lock_guard<std::mutex> lk(c->err_mu);
+    g_err = c->err;
+  }
+  return g_err.c_str();
+}
 
 template <typename T>
 static T *upload(grim_ctx *c, std::vector<void *> &bufs, const T *src, size_t n, uint64_t *bytes) {
@@ -377,9 +403,9 @@ static uint64_t host_mix64(uint64_t x) {
 extern "C" grim_graph *grim_graph_upload(grim_ctx *c, const grim_graph_desc *d) {
   if (!c || !d) return nullptr;
   hipSetDevice(c->device);
-  if (d->n_pops == 0 || d->n_pops > GRIM_MAXPOP) { c->err = "grim_graph_upload: population count out of range"; return nullptr; }
-  if (d->n_loci == 0 || d->n_loci > GRIM_MAXL) { c->err = "grim_graph_upload: locus count out of range"; return nullptr; }
-  if (d->n_nodes >= (1u << 23)) { c->err = "grim_graph_upload: more than 2^23 nodes"; return nullptr; }
+  if (d->n_pops == 0 || d->n_pops > GRIM_MAXPOP) { set_err(c, "grim_graph_upload: population count out of range"); return nullptr; }
+  if (d->n_loci == 0 || d->n_loci > GRIM_MAXL) { set_err(c, "grim_graph_upload: locus count out of range"); return nullptr; }
+  if (d->n_nodes >= (1u << 23)) { set_err(c, "grim_graph_upload: more than 2^23 nodes"); return nullptr; }
   grim_graph *g = new grim_graph();
   g->ctx = c;
   g->bytes = 0;
@@ -394,7 +420,7 @@ extern "C" grim_graph *grim_graph_upload(grim_ctx *c, const grim_graph_desc *d) 
   bool unique_names = true;
   for (uint32_t i = 0; i < d->n_nodes; ++i) {
     uint64_t k = d->node_key[i];
-    if (k == 0) { c->err = "grim_graph_upload: node with empty key"; delete g; return nullptr; }
+    if (k == 0) { set_err(c, "grim_graph_upload: node with empty key"); delete g; return nullptr; }
     uint32_t h = (uint32_t)host_mix64(k) & (cap - 1);
     while (hk[h] != 0 && hk[h] != k) h = (h + 1) & (cap - 1);
     if (hk[h] == k) unique_names = false;
@@ -465,7 +491,7 @@ extern "C" grim_graph *grim_graph_upload(grim_ctx *c, const grim_graph_desc *d) 
   }
   if (!D.fht || !D.node_key || !D.node_mask || !D.freq || !D.a_start || !D.a_nbr || !D.b_conn || !D.b_start || !D.b_nbr ||
       !D.lab_start || !D.lab_nodes || !D.lab_key || !D.ht) {
-    c->err = "grim_graph_upload: device allocation or copy failed";
+    set_err(c, "grim_graph_upload: device allocation or copy failed");
     for (void *p : g->bufs) hipFree(p);
     delete g;
     return nullptr;
@@ -639,7 +665,7 @@ static void batch_init_params(grim_batch *b, const grim_graph *g, const grim_par
   L.rtok = take(2ull * GRIM_RTOK_CAP);
   L.stride = align256(o);
   b->timing = env_int("GRIM_TIMING", 0) != 0;
-  A.flags = env_int("GRIM_TABLES_HBM", 0) ? GRIM_F_TABLES_HBM : 0u;
+  A.flags = (env_int("GRIM_TABLES_HBM", 0) ? GRIM_F_TABLES_HBM : 0u) | (env_int("GRIM_NO_NODUP", 0) ? GRIM_F_NO_NODUP : 0u);
   memset(b->acc_ms, 0, sizeof(b->acc_ms));
   b->n_timed = 0;
   b->n_subj = b->n_small = b->n_medium = b->n_general = 0;
@@ -649,8 +675,8 @@ static void batch_init_params(grim_batch *b, const grim_graph *g, const grim_par
 grim_batch *engine_batch_create(grim_ctx *c, const grim_graph *g, const grim_params *p, uint64_t row_limit, const EnginePlan *plan) {
   if (!c || !g || !p || !plan) return nullptr;
   use_device(c->device);
-  if (p->top_n == 0 || p->top_n > GRIM_TOPCAP) { c->err = "grim_batch_upload: max_haplotypes_number_in_phase must be 1..128"; return nullptr; }
-  if (p->n_ladder < 0 || p->n_ladder > GRIM_MAXLADDER) { c->err = "grim_batch_upload: epsilon ladder too long"; return nullptr; }
+  if (p->top_n == 0 || p->top_n > GRIM_TOPCAP) { set_err(c, "grim_batch_upload: max_haplotypes_number_in_phase must be 1..128"); return nullptr; }
+  if (p->n_ladder < 0 || p->n_ladder > GRIM_MAXLADDER) { set_err(c, "grim_batch_upload: epsilon ladder too long"); return nullptr; }
   if (row_limit > 0x7FFFFFF0ull) row_limit = 0x7FFFFFF0ull;
   if (row_limit < 64) row_limit = 64;
   grim_batch *b = nullptr;
@@ -671,8 +697,9 @@ grim_batch *engine_batch_create(grim_ctx *c, const grim_graph *g, const grim_par
       ok = false;
     }
     for (int i = 0; i < 14 && ok; ++i) ok = hipEventCreate(&b->ev[i]) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&b->ev_done, hipEventDisableTiming | hipEventReleaseToSystem) == hipSuccess;
     if (!ok) {
-      c->err = "grim_batch: device or pinned-host allocation failed";
+      set_err(c, "grim_batch: device or pinned-host allocation failed");
       batch_destroy(b);
       return nullptr;
     }
@@ -680,7 +707,7 @@ grim_batch *engine_batch_create(grim_ctx *c, const grim_graph *g, const grim_par
   b->row_limit = row_limit;
   batch_init_params(b, g, p);
   if (!batch_plan(b, *plan)) {
-    c->err = "grim_batch: device or pinned-host allocation failed";
+    set_err(c, "grim_batch: device or pinned-host allocation failed");
     batch_destroy(b);
     return nullptr;
   }
@@ -709,16 +736,13 @@ int engine_batch_plan(grim_batch *b, const EnginePlan *plan) {
   if (!b || !plan) return -1;
   use_device(b->ctx->device);
   if (!batch_plan(b, *plan)) {
-    b->ctx->err = "grim_batch: device or pinned-host allocation failed while growing a batch";
+    set_err(b->ctx, "grim_batch: device or pinned-host allocation failed while growing a batch");
     return -1;
   }
   return 0;
 }
 
-void engine_set_error(grim_ctx *c, const char *msg) {
-  if (c) c->err = msg;
-  g_err = msg;
-}
+void engine_set_error(grim_ctx *c, const char *msg) { set_err(c, msg); }
 const EngineHost *engine_batch_host(grim_batch *b) { return b ? &b->h : nullptr; }
 uint64_t engine_bytes_moved(const grim_batch *, int dir) { return g_moved[dir ? 1 : 0]; }
 
@@ -747,7 +771,7 @@ int engine_batch_load(grim_batch *b, const EngineLoad *ld) {
   use_device(c->device);
   DevArgs &A = b->a;
   if (ld->n_subj > b->plan.n_subj || ld->tok_used > b->plan.tok_cap) {
-    c->err = "engine_batch_load: beyond what the batch was planned for";
+    set_err(c, "engine_batch_load: beyond what the batch was planned for");
     return -1;
   }
   hipStream_t st = c->stream;
@@ -762,7 +786,7 @@ int engine_batch_load(grim_batch *b, const EngineLoad *ld) {
       b->d_priors = b->h_priors = nullptr;
       if (hipMalloc((void **)&b->d_priors, 8 * (uint64_t)want * PP) != hipSuccess ||
           hipHostMalloc((void **)&b->h_priors, 8 * (uint64_t)want * PP, hipHostMallocDefault) != hipSuccess) {
-        c->err = "engine_batch_load: allocation of the prior matrices failed";
+        set_err(c, "engine_batch_load: allocation of the prior matrices failed");
         return -1;
       }
       b->priors_cap = want;
@@ -818,7 +842,7 @@ int engine_batch_load(grim_batch *b, const EngineLoad *ld) {
       b->pool_bytes = 0;
       if (hipMalloc((void **)&b->d_pool, o) != hipSuccess) {
         (void)hipGetLastError();
-        c->err = "engine_batch_load: cannot allocate " + std::to_string((unsigned long long)(o >> 20)) + " MiB for the table kernels";
+        set_err(c, "engine_batch_load: cannot allocate " + std::to_string((unsigned long long)(o >> 20)) + " MiB for the table kernels");
         return -1;
       }
       b->pool_bytes = o;
@@ -904,25 +928,30 @@ extern "C" grim_batch *grim_batch_upload(grim_ctx *c, const grim_graph *g, const
   }
   EngineLoad ld{d->n_subjects, (uint32_t)os.size(), (uint32_t)om.size(), (uint32_t)og.size(), d->n_tokens,
                 d->n_priors ? d->n_priors : 1u, pri};
-  if (engine_batch_load(b, &ld) != 0 || hipStreamSynchronize(c->stream) != hipSuccess) {
-    if (c->err.empty()) c->err = "grim_batch_upload: copy failed";
+  const int lrc = engine_batch_load(b, &ld);  // sets the error text itself
+  if (lrc != 0 || hipStreamSynchronize(c->stream) != hipSuccess) {
+    if (lrc == 0) set_err(c, "grim_batch_upload: copy failed");
     grim_batch_free(b);
     return nullptr;
   }
   return b;
 }
 
-// the context's scratch block: bound when a run starts (never while kernels of this context are in flight: every run
-// of a context is synchronous and a context is used by one thread at a time), so a batch never keeps a stale pointer
+// the context's scratch block: bound when a run's kernels are launched (c->run_mu held).  Kernels use it only while they
+// run -- nothing in it outlives a kernel -- and a context's kernels share one stream, so batches in flight at the same
+// time may share the block; it is only ever replaced by a bigger one, after the stream has drained.
 static int bind_scratch(grim_batch *b) {
   grim_ctx *c = b->ctx;
   if (b->scratch_need > c->scratch_bytes) {
-    if (c->scratch) hipFree(c->scratch);
+    if (c->scratch) {
+      hipStreamSynchronize(c->stream);
+      hipFree(c->scratch);
+    }
     c->scratch = nullptr;
     c->scratch_bytes = 0;
     if (hipMalloc(&c->scratch, b->scratch_need) != hipSuccess) {
       (void)hipGetLastError();
-      c->err = "grim_batch_run: cannot allocate " + std::to_string((unsigned long long)(b->scratch_need >> 20)) + " MiB of scratch";
+      set_err(c, "grim_batch_run: cannot allocate " + std::to_string((unsigned long long)(b->scratch_need >> 20)) + " MiB of scratch");
       return -1;
     }
     c->scratch_bytes = b->scratch_need;
@@ -1013,30 +1042,28 @@ extern "C" int grim_batch_set_timing(grim_batch *b, int on) {
   return 0;
 }
 
-extern "C" int grim_batch_run(grim_batch *b) {
+// A run in two halves, so that a caller can keep the device busy: engine_batch_enqueue launches stage 1 (half-wave, one-wave,
+// general kernel, finish kernel) behind whatever the context's stream holds and returns at once; engine_batch_wait waits for
+// that stage, launches stage 2 (Plan B / C, the table kernels) when the state block says subjects or accepted pairs are
+// waiting, and returns what grim_batch_run returns.  The two may be called from different threads (one after the other).
+int engine_batch_enqueue(grim_batch *b) {
   if (!b) return -1;
   grim_ctx *c = b->ctx;
   use_device(c->device);
-  DevArgs &A = b->a;
-  if (bind_scratch(b) != 0) return -1;
   if ((uint64_t)b->n_small * b->small_stride > b->row_limit) {
     // the half-wave kernel's rows have fixed places in the staging region at the top of the pool: they must all exist
     b->rows_used = 0;
-    c->err = "grim_batch_run: output row pool smaller than the half-wave kernel's fixed region";
+    set_err(c, "grim_batch_run: output row pool smaller than the half-wave kernel's fixed region");
     return -2;
   }
-  b->ms_s = b->ms_a = b->ms_g = b->ms_m = b->ms_t = b->ms_c = 0;
+  b->ms_s = b->ms_a = b->ms_g = b->ms_m = b->ms_t = b->ms_c = b->ms_b = 0;
+  std::lock_guard<std::mutex> lk(c->run_mu);
+  if (bind_scratch(b) != 0) return -1;
   if (b->timing) {
     if (enqueue_stage1(b, true) != 0) {
-      c->err = "grim_batch_run: kernel launch failed";
+      set_err(c, "grim_batch_run: kernel launch failed");
       return -1;
     }
-    HIPCHK(hipStreamSynchronize(c->stream), c, -1);
-    if (b->n_small) HIPCHK(hipEventElapsedTime(&b->ms_s, b->ev[3], b->ev[5]), c, -1);
-    if (b->n_medium) HIPCHK(hipEventElapsedTime(&b->ms_m, b->ev[0], b->ev[1]), c, -1);
-    if (b->n_general + b->n_medium) HIPCHK(hipEventElapsedTime(&b->ms_g, b->ev[6], b->ev[7]), c, -1);
-    if (b->n_small) HIPCHK(hipEventElapsedTime(&b->ms_c, b->ev[12], b->ev[13]), c, -1);
-    b->ms_a = b->ms_s + b->ms_m + b->ms_g;
   } else {
     if (b->graph_state == 0) {
       b->graph_state = -1;
@@ -1056,29 +1083,55 @@ extern "C" int grim_batch_run(grim_batch *b) {
     if (b->graph_state == 1) {
       HIPCHK(hipGraphLaunch(b->gexec, c->stream), c, -1);
     } else if (enqueue_stage1(b, false) != 0) {
-      c->err = "grim_batch_run: kernel launch failed";
+      set_err(c, "grim_batch_run: kernel launch failed");
       return -1;
     }
-    HIPCHK(hipStreamSynchronize(c->stream), c, -1);
   }
-  b->ms_b = 0;
+  HIPCHK(hipEventRecord(b->ev_done, c->stream), c, -1);
+  b->enqueued = true;
+  return 0;
+}
+
+int engine_batch_wait(grim_batch *b) {
+  if (!b) return -1;
+  grim_ctx *c = b->ctx;
+  use_device(c->device);
+  DevArgs &A = b->a;
+  if (!b->enqueued) {
+    set_err(c, "engine_batch_wait: nothing in flight");
+    return -1;
+  }
+  b->enqueued = false;
+  HIPCHK(hipEventSynchronize(b->ev_done), c, -1);
+  if (b->timing) {
+    if (b->n_small) HIPCHK(hipEventElapsedTime(&b->ms_s, b->ev[3], b->ev[5]), c, -1);
+    if (b->n_medium) HIPCHK(hipEventElapsedTime(&b->ms_m, b->ev[0], b->ev[1]), c, -1);
+    if (b->n_general + b->n_medium) HIPCHK(hipEventElapsedTime(&b->ms_g, b->ev[6], b->ev[7]), c, -1);
+    if (b->n_small) HIPCHK(hipEventElapsedTime(&b->ms_c, b->ev[12], b->ev[13]), c, -1);
+    b->ms_a = b->ms_s + b->ms_m + b->ms_g;
+  }
   uint32_t head[GRIM_NQ];
   memcpy(head, b->hstate + GRIM_NCTR, 4 * GRIM_NQ);
   // ---- stage 2: Plan B / C when the first stage left subjects for it, then the table kernels ONCE over the accepted
   // pairs both stages queued (a round after each stage cost their tails twice) -------------------------------------
   const bool run_b = A.prm.planb && head[2] + head[6] > 0;
   if (run_b || head[2] + head[6] + head[9] + head[10] > 0) {
-    if (run_b) {
-      uint32_t grid = b->n_slots < head[2] + head[6] ? b->n_slots : head[2] + head[6];
-      if (grim_launch_plan_b(A, grid, c->stream, b->timing ? b->ev[4] : nullptr, b->timing ? b->ev[2] : nullptr) != 0) {
-        c->err = "grim_batch_run: plan-B launch failed";
-        return -1;
+    {
+      std::lock_guard<std::mutex> lk(c->run_mu);
+      if (bind_scratch(b) != 0) return -1;
+      if (run_b) {
+        uint32_t grid = b->n_slots < head[2] + head[6] ? b->n_slots : head[2] + head[6];
+        if (grim_launch_plan_b(A, grid, c->stream, b->timing ? b->ev[4] : nullptr, b->timing ? b->ev[2] : nullptr) != 0) {
+          set_err(c, "grim_batch_run: plan-B launch failed");
+          return -1;
+        }
       }
+      enqueue_tables(b, b->timing ? b->ev[10] : nullptr, b->timing ? b->ev[11] : nullptr);
+      hipLaunchKernelGGL(grim_finish_kernel, dim3(1), dim3(GRIM_WG), 0, c->stream, A.counters, b->hstate, 0u, 1);
+      HIPCHK(hipGetLastError(), c, -1);
+      HIPCHK(hipEventRecord(b->ev_done, c->stream), c, -1);
     }
-    enqueue_tables(b, b->timing ? b->ev[10] : nullptr, b->timing ? b->ev[11] : nullptr);
-    hipLaunchKernelGGL(grim_finish_kernel, dim3(1), dim3(GRIM_WG), 0, c->stream, A.counters, b->hstate, 0u, 1);
-    HIPCHK(hipGetLastError(), c, -1);
-    HIPCHK(hipStreamSynchronize(c->stream), c, -1);
+    HIPCHK(hipEventSynchronize(b->ev_done), c, -1);
     if (b->timing) {
       float t2 = 0;
       if (run_b) HIPCHK(hipEventElapsedTime(&b->ms_b, b->ev[4], b->ev[2]), c, -1);
@@ -1106,29 +1159,37 @@ extern "C" int grim_batch_run(grim_batch *b) {
   fprintf(stderr, "grim stamps (us):");
   for (int k = 0; k < 16; ++k) fprintf(stderr, " [%d]%.0f", k, b->hstate[GRIM_STAMP_BASE + k] / 100.0);
   fprintf(stderr, "\n");
-  static const char *hname[4] = {"hist 0", "hist 1", "hist 2", "hist 3"};
-  for (int h = 0; h < 4; ++h) {
+  static const char *hname[8] = {"0 opening (0 side by side, 1 shared scan)", "1 us in sides by alleles", "2 subjects by alleles",
+                                 "3 subjects by accepted pairs", "4 subjects by scored pairs", "5 subjects by top-list entries",
+                                 "6 accepted pairs by accepted pairs", "7 us per subject by accepted pairs"};
+  for (int h = 0; h < 8; ++h) {
     fprintf(stderr, "grim hist %s:", hname[h]);
     for (int k = 0; k < 24; ++k) fprintf(stderr, " %llu", b->hstate[GRIM_HIST_BASE + 24 * h + k]);
     fprintf(stderr, "\n");
   }
 #endif
   if (b->counters[4] != 0 || head[1] > A.row_cap) {
-    if (!b->in_retry && engine_batch_grow_pool(b, 256ull << 20)) {
-      // the accepted pairs outgrew the table kernels' pool: size it for what this run asked for and run again (the
-      // inputs are still in the pinned arena; the prior matrices stay where they are)
-      b->in_retry = true;
-      EngineLoad ld = b->last_load;
-      int rc = engine_batch_load(b, &ld);
-      if (rc == 0) rc = grim_batch_run(b);
-      b->in_retry = false;
-      return rc;
-    }
     if (b->rows_used > A.row_cap) b->rows_used = A.row_cap;
-    c->err = "grim_batch_run: output row pool exhausted (raise GRIM_ROW_CAP or lower the batch size)";
+    set_err(c, "grim_batch_run: output row pool exhausted (raise GRIM_ROW_CAP or lower the batch size)");
     return -2;
   }
   return 0;
+}
+
+extern "C" int grim_batch_run(grim_batch *b) {
+  if (!b) return -1;
+  int rc = engine_batch_enqueue(b);
+  if (rc == 0) rc = engine_batch_wait(b);
+  if (rc == -2 && !b->in_retry && engine_batch_grow_pool(b, 256ull << 20)) {
+    // the accepted pairs outgrew the table kernels' pool: size it for what this run asked for and run again (the
+    // inputs are still in the pinned arena; the prior matrices stay where they are)
+    b->in_retry = true;
+    EngineLoad ld = b->last_load;
+    rc = engine_batch_load(b, &ld);
+    if (rc == 0) rc = grim_batch_run(b);
+    b->in_retry = false;
+  }
+  return rc;
 }
 
 extern "C" int grim_batch_run_repeat(grim_batch *b, uint32_t n) {
@@ -1199,7 +1260,7 @@ static int batch_fetch_on(grim_batch *b, uint32_t res_lo, uint32_t res_hi, grim_
     if (n < need) n = need;
     if (!pin_realloc(b->h_out, n)) {
       b->h_out_cap = 0;
-      c->err = "engine_batch_fetch: pinned allocation failed";
+      set_err(c, "engine_batch_fetch: pinned allocation failed");
       return -1;
     }
     b->h_out_cap = n;
@@ -1245,6 +1306,7 @@ static void batch_destroy(grim_batch *b) {
   hipStreamSynchronize(b->ctx->stream);
   for (int i = 0; i < 14; ++i)
     if (b->ev[i]) hipEventDestroy(b->ev[i]);
+  if (b->ev_done) hipEventDestroy(b->ev_done);
   if (b->gexec) hipGraphExecDestroy(b->gexec);
   void *dev[] = {b->d_in, b->d_work, b->d_out, b->d_priors, b->d_pool};
   for (void *p : dev)

@@ -49,6 +49,11 @@ void engine_batch_recycle(grim_batch *b);
 // after a run that returned -2: 1 = the pair pool ran out and the next load will make it big enough (run the same subjects
 // again), 0 = split the batch
 int engine_batch_fetch_async(grim_batch *b);
+// a run in two halves (grim_batch_run = enqueue + wait): stage 1 is launched behind whatever the context's stream holds and
+// the call returns; engine_batch_wait (any thread, after enqueue returned) waits for it, runs stage 2 when the run state
+// asks for it and returns grim_batch_run's code (0, -1, -2 = a pool overflowed)
+int engine_batch_enqueue(grim_batch *b);
+int engine_batch_wait(grim_batch *b);
 uint64_t engine_batch_pool_want(const grim_batch *b);
 void engine_batch_hint_pool(grim_batch *b, uint64_t records);
 int engine_batch_grow_pool(grim_batch *b, uint64_t max_records);

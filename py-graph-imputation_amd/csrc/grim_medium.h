@@ -261,6 +261,20 @@ __device__ inline int medium_subject(const DevArgs &A, WaveMed &M, uint32_t si, 
   WAVE_SYNC();
   const uint32_t np = M.poff[GRIM_MAXPH];
   if (np > MW_NP) return 2;
+  // every scored pair a different unordered entity pair (see prepare_lists, grim_plan_a.h): the two lists of every
+  // position are the same text or disjoint sets, and some position differs -> the dedup below has nothing to find
+  bool nodup = false;
+  {
+    bool het = false, clash = false;
+    if (lane < n && !((sj.pad[0] >> lane) & 1u)) {
+      het = true;
+      const uint16_t *l0 = tok + M.toff[lane][0], *l1 = tok + M.toff[lane][1];
+      const uint32_t c0 = sj.cnt[lane][0], c1 = sj.cnt[lane][1];
+      for (uint32_t a = 0; a < c0 && !clash; ++a)
+        for (uint32_t b = 0; b < c1 && !clash; ++b) clash = l0[a] == l1[b];
+    }
+    nodup = __ballot(het) != 0 && __ballot(clash) == 0 && !(A.flags & GRIM_F_NO_NODUP);
+  }
   // ---- ladder (impute.py:1665-1687) ----------------------------------------------------------------
   int best = A.prm.n_ladder;
   for (uint32_t f = lane; f < np && best > 0; f += 64) {
@@ -304,7 +318,8 @@ __device__ inline int medium_subject(const DevArgs &A, WaveMed &M, uint32_t si, 
         if (f < np) {
           const uint64_t key = M.u.pkeys[f];
           win = key != 0;
-          for (uint32_t f2 = 0; f2 < f && win; ++f2) win = M.u.pkeys[f2] != key;
+          if (!nodup)
+            for (uint32_t f2 = 0; f2 < f && win; ++f2) win = M.u.pkeys[f2] != key;
           if (win) {
             PairRef pr = med_pair(M, f);
             prob = pair_prob(pr, prior[ENT_POP(pr.e1) * P + ENT_POP(pr.e2)]);

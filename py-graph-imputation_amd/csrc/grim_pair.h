@@ -41,6 +41,7 @@ struct WgShared {
   // (0xFFFF: none of the list is known to the graph, the list stays); active while `reduced` is set
   uint16_t bestc[GRIM_SIDES][GRIM_MAXL];
   uint8_t reduced;
+  uint8_t nodup;       // no two scored pairs of this subject can be the same unordered entity pair (prepare_lists)
   uint32_t comp_mask;  // slots - 1 of the composite-haplotype table as cleared for the current pass (plan B / C)
   // abits[l][c]: bit a set = allele id a is in the subject's list of position l, column c (version 0).
   // The intersection opening tests a graph node against a side with one bit per position.
@@ -235,6 +236,8 @@ __device__ __forceinline__ void tile_load(PairTile &T, const WgShared &sh, const
 // table of a heavy subject does not fit the L2: every line touched is a DRAM round trip).  All threads call; dense[side *
 // GRIM_TOPCAP + idx] is valid afterwards.  Uses the group-sum arrays of the slot (free during the pair stage).
 #define GRIM_DENSE_SLOTS 8192u
+// the table lives in the slot's group-sum arrays (8 and 4 bytes per pair_cap): a tiled pass has np >= GRIM_TILE_MIN <= pair_cap
+static_assert(GRIM_TILE_MIN >= GRIM_DENSE_SLOTS, "pair_dense_ids: the dense-id table would overrun gsum / ghead of a small slot");
 __device__ inline void pair_dense_ids(const DevArgs &A, WgShared &sh, const Slot &S, uint16_t *dense) {
   const int tid = threadIdx.x;
   uint64_t *ek = (uint64_t *)S.gsum;
@@ -333,6 +336,9 @@ __device__ inline uint32_t pair_pass(const DevArgs &A, WgShared &sh, const Slot 
                                      double eps, bool emit, double *maxp) {
   const int P = A.g.P;
   const int tid = threadIdx.x;
+  // nodup (prepare_lists): every scored pair is a different unordered entity pair, so every accepted pair wins -- no
+  // keys, no dedup table, no winner pass; the accepted list IS the winner list
+  const bool nodup = sh.nodup && !(A.flags & GRIM_F_NO_NODUP);
   if (np <= GRIM_WG) {
     // few pairs: one thread per pair, first-wins dedup by looking at the earlier pairs' keys in LDS
     uint64_t *pk = (uint64_t *)sh.qprob;  // free outside pop_tables
@@ -352,7 +358,8 @@ __device__ inline uint32_t pair_pass(const DevArgs &A, WgShared &sh, const Slot 
     pk[tid] = key;
     __syncthreads();
     bool win = accd;
-    for (int f2 = 0; f2 < tid && win; ++f2) win = pk[f2] != key;
+    if (!nodup)
+      for (int f2 = 0; f2 < tid && win; ++f2) win = pk[f2] != key;
     uint64_t m = __ballot(win);
     double mx = win ? prob : 0.0;
     for (int d = 32; d > 0; d >>= 1) {
@@ -385,9 +392,11 @@ __device__ inline uint32_t pair_pass(const DevArgs &A, WgShared &sh, const Slot 
   // round).  Everything after this works on the accepted list only: its length, not the number of scored pairs,
   // sizes the dedup table -- which lives in LDS when the list is short, so that the common subject's dedup
   // causes no HBM traffic at all (clearing a 2 x np-slot table per pass was 8.5 GB of writes per 100 k mixed subjects).
-  uint32_t *Af = S.sva, *Aslot = S.svb;
+  uint32_t *Af = nodup ? S.Useq : S.sva, *Aslot = S.svb;  // nodup: stage A writes the winners' list itself
   uint64_t *Akey = S.ska;
-  double *Aprob = (double *)S.skb;
+  double *Aprob = nodup ? S.Uprob : (double *)S.skb;
+  const bool keep_list = !nodup || emit;                   // a nodup pass that only wants MaxProb writes nothing
+  double amx = 0.0;                                        // nodup: the biggest accepted probability this thread saw
 #if defined(GRIM_STAMPS) && !defined(GRIM_NO_PP_STAMPS)
   unsigned long long _pp_t0 = wall_clock64();
 #define PP_STAMP(k)                                                                          \
@@ -407,7 +416,7 @@ __device__ inline uint32_t pair_pass(const DevArgs &A, WgShared &sh, const Slot 
   uint32_t *Akey32 = (uint32_t *)S.ska;       // tiled passes: 24-bit keys over dense entity numbers
   uint16_t *dense = (uint16_t *)S.gstart;
   if (tiled) {
-    pair_dense_ids(A, sh, S, dense);
+    if (!nodup) pair_dense_ids(A, sh, S, dense);
     PairTile &T = *(PairTile *)sh.hist;
     const int lane = lane_id(), wv = wave_id();
     const uint64_t lt = (1ull << lane) - 1ull;
@@ -419,7 +428,7 @@ __device__ inline uint32_t pair_pass(const DevArgs &A, WgShared &sh, const Slot 
       const uint32_t n2 = sh.Tn[2 * i + 1], npi = sh.Tn[2 * i] * n2;
       if (!npi) continue;
       __syncthreads();  // the previous tile is spent
-      tile_load(T, sh, S, i, dense);
+      tile_load(T, sh, S, i, nodup ? nullptr : dense);
       __syncthreads();
       const uint32_t magic = tile_magic(n2);
       // wave w owns the w-th stretch of the phase's pairs (whole chunks of 64): pass 1 marks and counts the accepted ones,
@@ -452,11 +461,18 @@ __device__ inline uint32_t pair_pass(const DevArgs &A, WgShared &sh, const Slot 
           const PairRef pr = tile_pair(T, r, n2, magic);
           const uint32_t cell = ENT_POP(pr.e1) * P + ENT_POP(pr.e2);
           const uint32_t pos = base + (uint32_t)__popcll(m & lt);
-          const uint32_t h = n2 > 1 ? __umulhi(r, magic) : r, k = r - h * n2;
-          const uint32_t da = T.d1[h], db = T.d2[k];
-          Af[pos] = sh.poff[i] + r;
-          Akey32[pos] = ((da < db ? da : db) << 12) | (da < db ? db : da);
-          Aprob[pos] = pair_prob(pr, lds_prior ? T.lp[cell] : prior[cell]);
+          const double prob = pair_prob(pr, lds_prior ? T.lp[cell] : prior[cell]);
+          if (nodup) {
+            amx = prob > amx ? prob : amx;
+          } else {
+            const uint32_t h = n2 > 1 ? __umulhi(r, magic) : r, k = r - h * n2;
+            const uint32_t da = T.d1[h], db = T.d2[k];
+            Akey32[pos] = ((da < db ? da : db) << 12) | (da < db ? db : da);
+          }
+          if (keep_list) {
+            Af[pos] = sh.poff[i] + r;
+            Aprob[pos] = prob;
+          }
         }
         base += (uint32_t)__popcll(m);
       }
@@ -504,15 +520,32 @@ __device__ inline uint32_t pair_pass(const DevArgs &A, WgShared &sh, const Slot 
       for (int q = 0; q < 4; ++q)
         if (on[q]) {
           const uint32_t pos = base[q] + (uint32_t)__popcll(m[q] & ((1ull << lane_id()) - 1ull));
-          Af[pos] = f0 + q * GRIM_WG + tid;
-          Akey[pos] = key[q];
-          Aprob[pos] = prob[q];
+          if (nodup) amx = prob[q] > amx ? prob[q] : amx;
+          else Akey[pos] = key[q];
+          if (keep_list) {
+            Af[pos] = f0 + q * GRIM_WG + tid;
+            Aprob[pos] = prob[q];
+          }
         }
       nA = run;
       __syncthreads();
     }
   }
   PP_STAMP(0);
+  if (nodup) {  // the accepted pairs are the winners, already in pair order where the caller wants them
+    for (int d = 32; d > 0; d >>= 1) {
+      const double o = __shfl_xor(amx, d);
+      if (o > amx) amx = o;
+    }
+    if (lane_id() == 0) sh.dtmp[wave_id()] = amx;
+    __syncthreads();
+    double mxn = sh.dtmp[0];
+    for (int w2 = 1; w2 < GRIM_NWAVE; ++w2)
+      if (sh.dtmp[w2] > mxn) mxn = sh.dtmp[w2];
+    __syncthreads();
+    *maxp = mxn;
+    return nA;
+  }
   // Stage B: one slot per unordered entity pair; the smallest position in the accepted list wins it
   const bool in_lds = nA <= GRIM_PASS_LDS_MAX;
   const bool words = tiled && !in_lds;  // one 64-bit word per slot: key << 32 | smallest position (all ones: empty)

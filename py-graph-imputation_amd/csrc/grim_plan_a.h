@@ -76,6 +76,27 @@ __device__ inline bool prepare_lists(const DevArgs &A, WgShared &sh, const Slot 
     }
   }
   __syncthreads();
+  // Can two of the subject's pairs ever name the same unordered {(haplotype, population), (haplotype, population)}?  A
+  // haplotype of a phase side carries, at every typed position, an allele of that side's list there.  When the two lists of
+  // every position are either the same text or DISJOINT sets, and some position differs, any two different sides differ at a
+  // position with disjoint lists, so no haplotype belongs to two sides: the two sides of a phase never share an entity and
+  // no two kept phases (which are never mirror images) share a side -- every scored pair is unique, and the first-wins
+  // dedup of calc_haps_pairs (impute.py:506-511, 603-611) has nothing to do.  (The reduced list versions are subsets.)
+  if (threadIdx.x < 64) {
+    const int l = threadIdx.x;
+    bool het = false, clash = false;
+    if (l < sj.n_loci && !((sj.pad[0] >> l) & 1u)) {
+      het = true;
+      if (ambiguous) {
+        for (int w = 0; w < 128 && !clash; ++w) clash = (sh.abits[l][0][w] & sh.abits[l][1][w]) != 0;
+      } else {
+        clash = A.tok[sj.tok_off + sh.toff[l][0]] == A.tok[sj.tok_off + sh.toff[l][1]];
+      }
+    }
+    const uint64_t hm = __ballot(het), cm = __ballot(clash);
+    if (threadIdx.x == 0) sh.nodup = (hm != 0 && cm == 0) ? 1 : 0;
+  }
+  __syncthreads();
   return true;
 }
 
@@ -181,14 +202,24 @@ __device__ __forceinline__ void expand_chunk(const DevArgs &A, const double *pri
       if (AUX) aux = g.node_key[hap] | L.caux[lo];
       if (RANKED) rtie = ((L.caux[lo] << 22) | (uint64_t)(t - L.cstart[lo])) << 14;
     }
-    for (int j = 0; j < P; ++j) {
-      double p = valid ? g.freq[(uint64_t)hap * P + j] : 0.0;
-      if (AUX) p = p * scale;
-      bool act = valid && p > 0.0;
-      double key = p * prior[j * P + j];
-      uint64_t tie = (((item_base + t) * (uint64_t)P + (uint64_t)j) << 8) | (uint64_t)j;
-      if (RANKED) tie = rtie | ((uint64_t)j << 8) | (uint64_t)j;
-      top_push(L, st, act, p, key, tie, hap, aux);
+    // four populations' frequencies per step: the loads are issued together (top_push's LDS fences would otherwise put a
+    // memory round trip between one population and the next -- half of a side's dependent chain at P = 4)
+    for (int j0 = 0; j0 < P; j0 += 4) {
+      double pv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pv[q] = (valid && j0 + q < P) ? g.freq[(uint64_t)hap * P + j0 + q] : 0.0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int j = j0 + q;
+        if (j >= P) break;
+        double p = pv[q];
+        if (AUX) p = p * scale;
+        bool act = valid && p > 0.0;
+        double key = p * prior[j * P + j];
+        uint64_t tie = (((item_base + t) * (uint64_t)P + (uint64_t)j) << 8) | (uint64_t)j;
+        if (RANKED) tie = rtie | ((uint64_t)j << 8) | (uint64_t)j;
+        top_push(L, st, act, p, key, tie, hap, aux);
+      }
     }
   }
   item_base += total;

@@ -12,6 +12,7 @@
 // again in halves.  No GPU code here: the device work goes through the engine.
 #include <errno.h>
 #include <fcntl.h>
+#include <sched.h>
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -70,6 +71,10 @@ enum { CH_FREE = 0, CH_FILLING, CH_TOKENIZING, CH_TOKENIZED, CH_RUN_DONE, CH_DEV
 
 struct Chunk {
   bool fetch_pending = false;  // the kernels are done, the results are still on the device
+  bool in_flight = false;      // stage 1 of the whole chunk is enqueued: the copy thread waits for it
+  std::vector<uint32_t> og_sorted;  // general-kernel subjects, heaviest first
+  Clock::time_point t_dev0;
+  uint32_t segment = 0;        // input segment the chunk belongs to (grim_stream_segment)
   int slot_no = 0;
   grim_batch *batch = nullptr;
   uint64_t index = 0, first_line = 0;
@@ -119,7 +124,11 @@ struct grim_stream {
   uint32_t n_pops = 0;
   uint32_t chunk_lines = 0, granule = 1024, n_threads = 1, depth = 0;
   uint64_t rows_per_chunk = 0;
-  uint64_t pool_hint = 0;  // pair-pool records a chunk of this stream needed (device thread only)
+  std::atomic<uint64_t> pool_hint{0};  // pair-pool records a chunk of this stream needed: every later load starts there
+  // input segments (grim_stream_segment): cumulative text bytes at the end of each, known once its chunks are committed
+  uint32_t cur_segment = 0;
+  std::vector<std::array<uint64_t, 7>> seg_end;
+  std::vector<uint8_t> seg_set;
   std::vector<std::string> stale;  // earlier runs' output files, moved aside at open
   std::thread unlinker;
 
@@ -131,7 +140,8 @@ struct grim_stream {
   std::mutex mu;  // guards task queues, chunk states, commit state
   std::condition_variable cv_work, cv_dev, cv_slot, cv_rec, cv_done;
   std::deque<Task> q_hi, q_lo;
-  bool stop = false, failed = false, input_closed = false;
+  bool stop = false, input_closed = false;
+  std::atomic<bool> failed{false};
   std::string err;
   std::vector<std::thread> workers;
   std::thread dev_thread, copy_thread;
@@ -234,27 +244,41 @@ static void run_tokenize(grim_stream *s, Chunk *c, uint32_t r) {
 }
 
 // ---- stage: device ------------------------------------------------------------------------------------------------------
-// runs the subjects of lines [lo, hi) of the chunk; on a row-pool overflow the range is halved and both halves run
-// again (a single subject always fits: the pool is never smaller than one subject's worst case)
-static std::atomic<uint64_t> g_dbg_ns[4];  // GRIM_DEBUG_STREAM: device thread time in staging / load / run / fetch
-static int device_part(grim_stream *s, Chunk *c, uint32_t lo, uint32_t hi, bool whole, std::vector<uint32_t> &og_sorted) {
+// The device thread only STAGES and LAUNCHES: class lists into the pinned arena, one H2D, the kernels of stage 1, and on to
+// the next chunk -- it never waits for the GPU.  The copy thread waits for a chunk's kernels (engine_batch_wait: an event
+// behind its last kernel, not the stream), runs the second stage when subjects or accepted pairs are waiting for it,
+// brings the results over on the copy stream and hands the chunk to the formatter.  A chunk whose results overflow a pool
+// is run again by the copy thread, synchronously: the pair pool grown to what the run asked for, else in halves (a single
+// subject always fits: the row pool is never smaller than one subject's worst case).
+static std::atomic<uint64_t> g_dbg_ns[4];  // GRIM_DEBUG_STREAM: staging / load + launch (device thread), wait + stage 2 / fetch (copy thread)
+
+struct PartStats {  // what a part's run adds to the stream's statistics (applied under the lock by the caller)
+  double kernel_ms[7] = {0, 0, 0, 0, 0, 0, 0};
+  uint64_t counters[4] = {0, 0, 0, 0};
+  uint64_t reruns = 0;
+};
+
+// lays the subjects of lines [lo, hi) out in the chunk's pinned arena and starts the H2D copy
+static int stage_part(grim_stream *s, Chunk *c, uint32_t lo, uint32_t hi, size_t (&rng)[4], uint32_t &ng) {
   const auto tp0 = Clock::now();
   grim_batch *b = c->batch;
   const EngineHost *H = engine_batch_host(b);
   auto lb = [](const std::vector<uint32_t> &v, uint32_t x) { return (size_t)(std::lower_bound(v.begin(), v.end(), x) - v.begin()); };
   const size_t s0 = lb(c->os, lo), s1 = lb(c->os, hi), m0 = lb(c->om, lo), m1 = lb(c->om, hi);
+  rng[0] = s0; rng[1] = s1; rng[2] = m0; rng[3] = m1;
   if (s1 > s0) {
     memcpy(H->small, c->small.data() + s0, sizeof(SmallRec) * (s1 - s0));
     memcpy(H->order_s, c->os.data() + s0, 4 * (s1 - s0));
   }
   if (m1 > m0) memcpy(H->order_m, c->om.data() + m0, 4 * (m1 - m0));
-  uint32_t ng = 0;
-  for (uint32_t si : og_sorted)
+  ng = 0;
+  for (uint32_t si : c->og_sorted)
     if (si >= lo && si < hi) H->order_g[ng++] = si;
   uint64_t tok_used = 0;
   for (uint32_t r = 0; r < c->n_ranges; ++r)
     if (c->tr[r].n_tok && c->range_first_line[r] < hi && c->range_first_line[r + 1] > lo) tok_used = c->slab_off[r] + c->tr[r].n_tok;
   const auto tp1 = Clock::now();
+  engine_batch_hint_pool(b, s->pool_hint.load());  // what an earlier chunk of this stream had to grow its pair pool to
   int lrc;
   {
     // the race table only grows: a batch that holds fewer matrices than the table has gets all of them again
@@ -267,44 +291,51 @@ static int device_part(grim_stream *s, Chunk *c, uint32_t lo, uint32_t hi, bool 
     }
     lrc = engine_batch_load(b, &ld);
   }
-  if (lrc != 0) return -1;
-  const auto tp2 = Clock::now();
-  const int rc = grim_batch_run(b);
-  const auto tp3 = Clock::now();
   g_dbg_ns[0] += (uint64_t)(secs(tp0, tp1) * 1e9);
-  g_dbg_ns[1] += (uint64_t)(secs(tp1, tp2) * 1e9);
-  g_dbg_ns[2] += (uint64_t)(secs(tp2, tp3) * 1e9);
+  g_dbg_ns[1] += (uint64_t)(secs(tp1, Clock::now()) * 1e9);
+  return lrc;
+}
+
+static void part_stats(grim_stream *s, grim_batch *b, PartStats &ps) {
+  if (!s->opt.timing) return;
+  for (int k = 0; k < 7; ++k) ps.kernel_ms[k] += grim_batch_kernel_ms(b, k);
+  uint64_t ctr[4];
+  if (grim_batch_counters(b, ctr) == 0)
+    for (int k = 0; k < 4; ++k) ps.counters[k] += ctr[k];
+}
+
+// synchronous run of the subjects of lines [lo, hi) (copy thread: the second try of a chunk, or a part of it)
+static int device_part_sync(grim_stream *s, Chunk *c, uint32_t lo, uint32_t hi, bool whole, PartStats &ps);
+
+// after a run of [lo, hi) ended with `rc`: results stay on the device (whole chunk) or are fetched as a part; a pool that
+// overflowed sends the range through device_part_sync again
+static int finish_part(grim_stream *s, Chunk *c, uint32_t lo, uint32_t hi, bool whole, int rc, const size_t (&rng)[4], uint32_t ng, PartStats &ps) {
+  grim_batch *b = c->batch;
+  part_stats(s, b, ps);
   if (getenv("GRIM_DEBUG_STREAM"))
     fprintf(stderr, "grim stream: chunk %llu lines [%u,%u) small %zu medium %zu general %u -> rc %d, rows %u (pool %llu)\n",
-            (unsigned long long)c->index, lo, hi, s1 - s0, m1 - m0, ng, rc, grim_batch_total_rows(b), (unsigned long long)s->rows_per_chunk);
-  if (s->opt.timing) {
-    for (int k = 0; k < 7; ++k) s->st.kernel_ms[k] += grim_batch_kernel_ms(b, k);
-    uint64_t ctr[4];
-    if (grim_batch_counters(b, ctr) == 0)
-      for (int k = 0; k < 4; ++k) s->st.counters[k] += ctr[k];
-  }
+            (unsigned long long)c->index, lo, hi, rng[1] - rng[0], rng[3] - rng[2], ng, rc, grim_batch_total_rows(b), (unsigned long long)s->rows_per_chunk);
   if (rc == -2) {
     // subjects with tens of thousands of accepted pairs: give the table kernels' pair pool what the run asked for (up to
     // 256 M records, 21 GB with the arrays sized by it) and run the same subjects again, before halving the batch
-    if (engine_batch_grow_pool(b, 256ull << 20)) {
-      ++s->st.reruns;
-      return device_part(s, c, lo, hi, whole, og_sorted);
-    }
+    ++ps.reruns;
+    if (engine_batch_grow_pool(b, 256ull << 20)) return device_part_sync(s, c, lo, hi, whole, ps);
     if (hi - lo <= 1) return -1;  // cannot happen: see grim_stream_open
-    ++s->st.reruns;
     const uint32_t mid = lo + (hi - lo) / 2;
-    int r1 = device_part(s, c, lo, mid, false, og_sorted);
+    const int r1 = device_part_sync(s, c, lo, mid, false, ps);
     if (r1 != 0) return r1;
-    return device_part(s, c, mid, hi, false, og_sorted);
+    return device_part_sync(s, c, mid, hi, false, ps);
   }
   if (rc != 0) return -1;
-  if (engine_batch_pool_want(b) > s->pool_hint) {  // this batch had to grow its pair pool: the other slots will meet the same chunks
-    s->pool_hint = engine_batch_pool_want(b);
-    for (auto &o : s->chunks) engine_batch_hint_pool(o->batch, s->pool_hint);
+  {  // this batch had to grow its pair pool: the other slots will meet the same kind of chunks
+    const uint64_t want = engine_batch_pool_want(b);
+    uint64_t cur = s->pool_hint.load();
+    while (want > cur && !s->pool_hint.compare_exchange_weak(cur, want)) {
+    }
   }
   const uint32_t nrows = grim_batch_total_rows(b);
   if (whole) {
-    c->fetch_pending = true;  // the copy thread brings the results over while this thread runs the next chunk's kernels
+    c->fetch_pending = true;
   } else {
     // a part of a chunk: its rows are appended to the chunk's own array and the row offsets of its subjects re-based
     const size_t base = c->extra_rows.size();
@@ -314,11 +345,20 @@ static int device_part(grim_stream *s, Chunk *c, uint32_t lo, uint32_t hi, bool 
     auto rebase = [&](uint32_t si) {
       for (int t = 0; t < GRIM_T_COUNT; ++t) res[si].row_off[t] += (uint32_t)base;
     };
-    for (size_t k = s0; k < s1; ++k) rebase(c->os[k]);
-    for (size_t k = m0; k < m1; ++k) rebase(c->om[k]);
+    for (size_t k = rng[0]; k < rng[1]; ++k) rebase(c->os[k]);
+    for (size_t k = rng[2]; k < rng[3]; ++k) rebase(c->om[k]);
     for (uint32_t k = 0; k < ng; ++k) rebase(engine_batch_host(b)->order_g[k]);
   }
   return 0;
+}
+
+static int device_part_sync(grim_stream *s, Chunk *c, uint32_t lo, uint32_t hi, bool whole, PartStats &ps) {
+  size_t rng[4];
+  uint32_t ng = 0;
+  if (stage_part(s, c, lo, hi, rng, ng) != 0) return -1;
+  int rc = engine_batch_enqueue(c->batch);
+  if (rc == 0) rc = engine_batch_wait(c->batch);
+  return finish_part(s, c, lo, hi, whole, rc, rng, ng, ps);
 }
 
 static void enqueue_format(grim_stream *s, Chunk *c);
@@ -337,29 +377,36 @@ static void device_loop(grim_stream *s) {
       }
     }
     const auto t0 = Clock::now();
+    c->t_dev0 = t0;
     int rc = 0;
     c->extra_rows.clear();
     c->rows = nullptr;
+    c->fetch_pending = false;
+    c->in_flight = false;
     if (c->n_dev_subjects) {
       // longest-processing-time-first for the general kernel; stable: equal-cost subjects stay in input order
-      std::vector<uint32_t> og = c->og;
+      const std::vector<uint32_t> &og = c->og;
       const grim_subject *subj = engine_batch_host(c->batch)->subj;
       std::vector<double> cost(og.size());
       for (size_t k = 0; k < og.size(); ++k) cost[k] = grim_cost(subj[og[k]]);
       std::vector<uint32_t> perm(og.size());
       for (size_t k = 0; k < perm.size(); ++k) perm[k] = (uint32_t)k;
       std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
-      std::vector<uint32_t> sorted(og.size());
-      for (size_t k = 0; k < perm.size(); ++k) sorted[k] = og[perm[k]];
-      c->fetch_pending = false;
-      rc = device_part(s, c, 0, c->n_lines, true, sorted);
-      if (rc == 0 && !c->extra_rows.empty()) c->rows = c->extra_rows.data();
+      c->og_sorted.resize(og.size());
+      for (size_t k = 0; k < perm.size(); ++k) c->og_sorted[k] = og[perm[k]];
+      size_t rng[4];
+      uint32_t ng = 0;
+      rc = stage_part(s, c, 0, c->n_lines, rng, ng);
+      if (rc == 0) {
+        rc = engine_batch_enqueue(c->batch);
+        if (rc == 0) c->in_flight = true;
+        else if (rc == -2) rc = 0;  // a pool too small before anything ran: the copy thread sorts it out (in_flight stays false)
+      }
     }
-    c->device_s = secs(t0, Clock::now());
-    bool to_copy = false;
+    const double busy = secs(t0, Clock::now());
     {
       std::lock_guard<std::mutex> lk(s->mu);
-      s->st.device_s += c->device_s;
+      s->st.device_s += busy;
       s->st.subjects += c->n_dev_subjects;
       ++s->next_device;
       if (rc != 0) {
@@ -367,20 +414,14 @@ static void device_loop(grim_stream *s) {
         s->fail(std::string("device stage failed: ") + (e ? e : ""));
         return;
       }
-      if (c->n_dev_subjects && c->fetch_pending && c->extra_rows.empty()) {
-        c->state = CH_RUN_DONE;
-        s->copy_q.push_back(c);
-        s->cv_copy.notify_all();
-        to_copy = true;
-      } else {
-        c->state = CH_DEVICE_DONE;
-      }
+      c->state = CH_RUN_DONE;
+      s->copy_q.push_back(c);
+      s->cv_copy.notify_all();
     }
-    if (!to_copy) enqueue_format(s, c);
   }
 }
 
-// the copy thread: D2H of a chunk whose kernels are done, over the context's copy stream
+// the copy thread: waits for a chunk's kernels, second stage, D2H over the context's copy stream
 static void copy_loop(grim_stream *s) {
   for (;;) {
     Chunk *c = nullptr;
@@ -397,15 +438,39 @@ static void copy_loop(grim_stream *s) {
       }
     }
     const auto t0 = Clock::now();
-    const int rc = engine_batch_fetch_async(c->batch);
-    g_dbg_ns[3] += (uint64_t)(secs(t0, Clock::now()) * 1e9);
+    int rc = 0;
+    PartStats ps;
+    if (c->n_dev_subjects) {
+      if (c->in_flight) {
+        c->in_flight = false;
+        const int wrc = engine_batch_wait(c->batch);
+        auto lb = [](const std::vector<uint32_t> &v, uint32_t x) { return (size_t)(std::lower_bound(v.begin(), v.end(), x) - v.begin()); };
+        const size_t rng[4] = {0, lb(c->os, c->n_lines), 0, lb(c->om, c->n_lines)};
+        rc = finish_part(s, c, 0, c->n_lines, true, wrc, rng, (uint32_t)c->og_sorted.size(), ps);
+      } else {
+        rc = device_part_sync(s, c, 0, c->n_lines, true, ps);
+      }
+      if (rc == 0 && !c->extra_rows.empty()) c->rows = c->extra_rows.data();
+    }
+    const auto t1 = Clock::now();
+    g_dbg_ns[2] += (uint64_t)(secs(t0, t1) * 1e9);
+    bool fetched_ok = true;
+    if (rc == 0 && c->n_dev_subjects && c->fetch_pending && c->extra_rows.empty()) {
+      fetched_ok = engine_batch_fetch_async(c->batch) == 0;
+      if (fetched_ok) c->rows = engine_batch_host(c->batch)->rows;
+      g_dbg_ns[3] += (uint64_t)(secs(t1, Clock::now()) * 1e9);
+    }
+    c->device_s = secs(c->t_dev0, Clock::now());
     {
       std::lock_guard<std::mutex> lk(s->mu);
-      if (rc != 0) {
-        s->fail("device stage failed: copying the results to the host");
+      for (int k = 0; k < 7; ++k) s->st.kernel_ms[k] += ps.kernel_ms[k];
+      for (int k = 0; k < 4; ++k) s->st.counters[k] += ps.counters[k];
+      s->st.reruns += ps.reruns;
+      if (rc != 0 || !fetched_ok) {
+        const char *e = grim_last_error(s->ctx);
+        s->fail(std::string(rc != 0 ? "device stage failed: " : "device stage failed: copying the results to the host: ") + (e ? e : ""));
         return;
       }
-      c->rows = engine_batch_host(c->batch)->rows;
       c->state = CH_DEVICE_DONE;
     }
     enqueue_format(s, c);
@@ -440,6 +505,10 @@ static void commit_ready(grim_stream *s) {  // mu held: commits every chunk that
         s->unsupported.push_back({c->first_line + c->range_first_line[r] + j, reason,
                                   std::string(c->text.data() + T.line[j].off, T.line[j].id_len)});
       }
+    }
+    if (c->segment < s->seg_end.size()) {  // everything of this segment up to here is placed
+      for (int k = 0; k < 7; ++k) s->seg_end[c->segment][k] = s->file_pos[k];
+      s->seg_set[c->segment] = 1;
     }
     ++s->next_commit;
     c->state = CH_COMMITTED;
@@ -597,6 +666,7 @@ static int dispatch(grim_stream *s, Chunk *c) {
   }
   s->next_line += n;
   std::lock_guard<std::mutex> lk(s->mu);
+  c->segment = s->cur_segment;
   s->st.lines += n;
   ++s->st.chunks;
   c->state = CH_TOKENIZING;
@@ -642,6 +712,41 @@ extern "C" int grim_stream_write(grim_stream *s, const char *text, uint64_t len)
   return s->failed ? -1 : 0;
 }
 
+// universal newlines, as Python's open(): "\r\n" and "\r" end a line too.  `p` is rewritten in place; a "\r" that ends a
+// block is remembered (carry_cr) so that the "\n" of a "\r\n" split across two calls is not taken for an empty line.
+static int write_universal(grim_stream *s, char *p, size_t m) {
+  size_t skip = 0;
+  if (m && s->carry_cr && p[0] == '\n') skip = 1;
+  if (m) s->carry_cr = false;
+  if (m && memchr(p, '\r', m)) {
+    size_t w = 0;
+    for (size_t i = skip; i < m; ++i) {
+      if (p[i] == '\r') {
+        p[w++] = '\n';
+        if (i + 1 < m) {
+          if (p[i + 1] == '\n') ++i;
+        } else {
+          s->carry_cr = true;
+        }
+      } else {
+        p[w++] = p[i];
+      }
+    }
+    m = w;
+    skip = 0;
+  }
+  if (m > skip) return grim_stream_write(s, p + skip, m - skip);
+  return s->failed ? -1 : 0;
+}
+
+extern "C" int grim_stream_write_text(grim_stream *s, const char *text, uint64_t len) {
+  if (!s || (!text && len)) return -1;
+  if (!len) return 0;
+  if (!s->carry_cr && !memchr(text, '\r', len)) return grim_stream_write(s, text, len);
+  std::vector<char> buf(text, text + len);
+  return write_universal(s, buf.data(), buf.size());
+}
+
 extern "C" int grim_stream_write_file(grim_stream *s, const char *path) {
   if (!s || !path) return -1;
   const int fd = open(path, O_RDONLY);
@@ -662,29 +767,7 @@ extern "C" int grim_stream_write_file(grim_stream *s, const char *path) {
       break;
     }
     if (n == 0) break;
-    size_t m = (size_t)n;
-    char *p = buf.data();
-    size_t skip = 0;
-    if (s->carry_cr && p[0] == '\n') skip = 1;  // the "\n" of a "\r\n" split across two blocks
-    s->carry_cr = false;
-    if (memchr(p, '\r', m)) {  // universal newlines, as Python's open(): "\r\n" and "\r" end a line
-      size_t w = 0;
-      for (size_t i = skip; i < m; ++i) {
-        if (p[i] == '\r') {
-          p[w++] = '\n';
-          if (i + 1 < m) {
-            if (p[i + 1] == '\n') ++i;
-          } else {
-            s->carry_cr = true;
-          }
-        } else {
-          p[w++] = p[i];
-        }
-      }
-      m = w;
-      skip = 0;
-    }
-    if (m > skip && grim_stream_write(s, p + skip, m - skip) != 0) {
+    if (write_universal(s, buf.data(), (size_t)n) != 0) {
       rc = -1;
       break;
     }
@@ -693,24 +776,50 @@ extern "C" int grim_stream_write_file(grim_stream *s, const char *path) {
   return rc;
 }
 
+// closes the chunk that is being filled (a last line without its newline is a line); returns -1 on failure
+static int close_filling(grim_stream *s) {
+  Chunk *c = s->filling;
+  s->filling = nullptr;
+  if (!c) return 0;
+  if (!c->text.empty() && c->text.back() != '\n') ++c->n_lines;
+  if (c->n_lines == 0) {
+    std::lock_guard<std::mutex> lk(s->mu);
+    c->state = CH_FREE;
+    --s->next_index;
+    s->cv_slot.notify_all();
+    return 0;
+  }
+  return dispatch(s, c);
+}
+
+extern "C" int grim_stream_segment(grim_stream *s, uint64_t next_line_offset) {
+  if (!s || s->input_closed) return -1;
+  if (close_filling(s) != 0) return -1;
+  s->carry_cr = false;
+  s->next_line = next_line_offset;
+  std::lock_guard<std::mutex> lk(s->mu);
+  ++s->cur_segment;
+  s->seg_end.push_back({{0, 0, 0, 0, 0, 0, 0}});
+  s->seg_set.push_back(0);
+  return s->failed ? -1 : 0;
+}
+
+extern "C" uint32_t grim_stream_n_segments(const grim_stream *s) { return s ? (uint32_t)s->seg_end.size() : 0; }
+
+extern "C" int grim_stream_segment_end(const grim_stream *s, uint32_t k, uint64_t out[7]) {
+  if (!s || !out || k >= s->seg_end.size()) return -1;
+  // a segment without a line ends where the one before it ended
+  int j = (int)k;
+  while (j >= 0 && !s->seg_set[j]) --j;
+  for (int t = 0; t < 7; ++t) out[t] = j >= 0 ? s->seg_end[j][t] : 0;
+  return 0;
+}
+
 extern "C" int grim_stream_finish(grim_stream *s) {
   if (!s) return -1;
   if (!s->input_closed) {
     s->input_closed = true;
-    Chunk *c = s->filling;
-    s->filling = nullptr;
-    if (c) {
-      if (!c->text.empty() && c->text.back() != '\n') {  // a last line without its newline is a line
-        ++c->n_lines;
-      }
-      if (c->n_lines == 0) {
-        std::lock_guard<std::mutex> lk(s->mu);
-        c->state = CH_FREE;
-        --s->next_index;
-      } else if (dispatch(s, c) != 0) {
-        return -1;
-      }
-    }
+    if (close_filling(s) != 0) return -1;
   }
   std::unique_lock<std::mutex> lk(s->mu);
   for (;;) {
@@ -744,7 +853,10 @@ extern "C" const char *grim_stream_text(grim_stream *s, int which, uint64_t *len
 
 extern "C" int grim_stream_get_stats(const grim_stream *s, grim_stream_stats *out) {
   if (!s || !out) return -1;
-  *out = s->st;
+  {
+    std::lock_guard<std::mutex> lk(const_cast<grim_stream *>(s)->mu);
+    *out = s->st;
+  }
   out->tokenize_cpu_s = s->tok_ns.load() * 1e-9;
   out->format_cpu_s = s->fmt_ns.load() * 1e-9;
   out->write_cpu_s = s->wr_ns.load() * 1e-9;
@@ -798,6 +910,25 @@ extern "C" int grim_stream_release_records(grim_stream *s, grim_stream_records *
   return 0;
 }
 
+// Worker threads of a stream when the caller does not say: the cores this process may run on (its affinity mask, not the
+// machine's core count) divided by the ranks that share the host (LOCAL_WORLD_SIZE as torchrun exports it, else WORLD_SIZE:
+// one node), at most 32.  Eight ranks on one host are then eight streams of cores / 8 threads each, not eight of 32.
+extern "C" uint32_t grim_default_threads(void) {
+  unsigned cores = 0;
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) cores = (unsigned)CPU_COUNT(&set);
+  if (!cores) cores = std::max(1u, std::thread::hardware_concurrency());
+  unsigned ranks = 1;
+  const char *lw = getenv("LOCAL_WORLD_SIZE");
+  if (!lw || atoi(lw) <= 0) lw = getenv("WORLD_SIZE");
+  if (lw && atoi(lw) > 0) ranks = (unsigned)atoi(lw);
+  unsigned nt = cores / ranks;
+  if (nt < 1) nt = 1;
+  if (nt > 32) nt = 32;
+  return nt;
+}
+
 extern "C" grim_stream *grim_stream_open(grim_ctx *ctx, const grim_graph *g, const grim_dict *dict, const grim_params *prm,
                                          const grim_prior_spec *priors, const char *const *pop_names, uint32_t n_pops,
                                          const grim_stream_opts *opts) {
@@ -809,6 +940,8 @@ extern "C" grim_stream *grim_stream_open(grim_ctx *ctx, const grim_graph *g, con
   s->opt = *opts;
   s->n_pops = n_pops;
   s->next_line = opts->line_offset;
+  s->seg_end.push_back({{0, 0, 0, 0, 0, 0, 0}});
+  s->seg_set.push_back(0);
   memset(&s->st, 0, sizeof(s->st));
   dict_snapshot(dict, s->snap);
   s->races.ps.alpha = priors->alpha;
@@ -845,7 +978,7 @@ extern "C" grim_stream *grim_stream_open(grim_ctx *ctx, const grim_graph *g, con
   if (s->chunk_lines < s->granule) s->granule = s->chunk_lines;
   s->depth = opts->depth ? opts->depth : 4u;
   int nt = opts->n_threads;
-  if (nt <= 0) nt = (int)std::min<unsigned>(32u, std::max(1u, std::thread::hardware_concurrency()));
+  if (nt <= 0) nt = (int)grim_default_threads();
   s->n_threads = (uint32_t)nt;
   // row pool of a chunk: bounded; never less than the fixed-stride region of the half-wave kernel plus one subject's
   // worst case and the one-wave kernel's per-wave row blocks
@@ -857,25 +990,7 @@ extern "C" grim_stream *grim_stream_open(grim_ctx *ctx, const grim_graph *g, con
   if (rows < floor_rows && !(opts->rows_exact && opts->rows_per_chunk)) rows = floor_rows;
   if (rows > 0x7FFFFFF0ull) rows = 0x7FFFFFF0ull;
   s->rows_per_chunk = rows;
-  for (int k = 0; k < 6; ++k)
-    if (opts->out_path[k]) {
-      // An output file of an earlier run is moved aside and unlinked by a helper thread while the pipeline runs: truncating
-      // 400 MB of cached pages costs 30 ms at open(), and ext4 then flushes a truncated-and-rewritten file at close()
-      // (another 35 ms) -- more than the pipeline itself needs for a million subjects.
-      const std::string old = std::string(opts->out_path[k]) + ".grim_old";
-      struct stat sb;
-      if (stat(opts->out_path[k], &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > (1 << 20) && rename(opts->out_path[k], old.c_str()) == 0)
-        s->stale.push_back(old);
-      s->fd[k] = open(opts->out_path[k], O_WRONLY | O_CREAT | O_TRUNC, 0644);
-      if (s->fd[k] < 0) {
-        engine_set_error(ctx, (std::string("grim_stream_open: cannot create ") + opts->out_path[k] + ": " + strerror(errno)).c_str());
-        for (int j = 0; j < k; ++j)
-          if (s->fd[j] >= 0) close(s->fd[j]);
-        for (const std::string &f : s->stale) unlink(f.c_str());
-        delete s;
-        return nullptr;
-      }
-    }
+  // the batches first: a stream that cannot get its device memory leaves the caller's files alone
   EnginePlan plan0{s->chunk_lines, (uint64_t)s->chunk_lines * 48};
   for (uint32_t i = 0; i < s->depth; ++i) {
     std::unique_ptr<Chunk> c(new Chunk());
@@ -883,15 +998,38 @@ extern "C" grim_stream *grim_stream_open(grim_ctx *ctx, const grim_graph *g, con
     c->batch = engine_batch_create(ctx, g, prm, rows, &plan0);
     if (!c->batch) {
       for (auto &o : s->chunks) grim_batch_free(o->batch);
-      for (int k = 0; k < 6; ++k)
-        if (s->fd[k] >= 0) close(s->fd[k]);
-      for (const std::string &f : s->stale) unlink(f.c_str());
       delete s;
       return nullptr;
     }
     if (opts->timing) grim_batch_set_timing(c->batch, 1);
     s->chunks.push_back(std::move(c));
   }
+  // An output file of an earlier run is moved aside and unlinked by a helper thread while the pipeline runs: truncating
+  // 400 MB of cached pages costs 30 ms at open(), and ext4 then flushes a truncated-and-rewritten file at close() (another
+  // 35 ms) -- more than the pipeline itself needs for a million subjects.  The name it is parked under is this process's
+  // own and is never one that exists; when the stream cannot be opened after all, the parked files go back.
+  std::vector<std::pair<std::string, std::string>> parked;  // (parked name, original name)
+  static std::atomic<unsigned> park_no{0};
+  for (int k = 0; k < 6; ++k)
+    if (opts->out_path[k]) {
+      struct stat sb;
+      if (stat(opts->out_path[k], &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > (1 << 20)) {
+        const std::string old = std::string(opts->out_path[k]) + ".grim_old." + std::to_string((long)getpid()) + "." + std::to_string(park_no++);
+        struct stat so;
+        if (lstat(old.c_str(), &so) != 0 && errno == ENOENT && rename(opts->out_path[k], old.c_str()) == 0) parked.emplace_back(old, opts->out_path[k]);
+      }
+      s->fd[k] = open(opts->out_path[k], O_WRONLY | O_CREAT | O_TRUNC, 0644);
+      if (s->fd[k] < 0) {
+        engine_set_error(ctx, (std::string("grim_stream_open: cannot create ") + opts->out_path[k] + ": " + strerror(errno)).c_str());
+        for (int j = 0; j < k; ++j)
+          if (s->fd[j] >= 0) close(s->fd[j]);
+        for (auto &pr : parked) rename(pr.first.c_str(), pr.second.c_str());  // the earlier run's results stay what they were
+        for (auto &o : s->chunks) grim_batch_free(o->batch);
+        delete s;
+        return nullptr;
+      }
+    }
+  for (auto &pr : parked) s->stale.push_back(pr.first);
   if (!s->stale.empty())
     s->unlinker = std::thread([s]() {
       for (const std::string &f : s->stale) unlink(f.c_str());
@@ -906,7 +1044,7 @@ extern "C" grim_stream *grim_stream_open(grim_ctx *ctx, const grim_graph *g, con
 extern "C" void grim_stream_free(grim_stream *s) {
   if (!s) return;
   if (getenv("GRIM_DEBUG_STREAM"))
-    fprintf(stderr, "grim stream: device thread ms: staging %.3f load %.3f run %.3f fetch %.3f over %llu chunks\n", g_dbg_ns[0] / 1e6,
+    fprintf(stderr, "grim stream: device thread ms: staging %.3f load %.3f | copy thread ms: wait + stage 2 %.3f fetch %.3f over %llu chunks\n", g_dbg_ns[0] / 1e6,
             g_dbg_ns[1] / 1e6, g_dbg_ns[2] / 1e6, g_dbg_ns[3] / 1e6, (unsigned long long)s->st.chunks);
   {
     std::lock_guard<std::mutex> lk(s->mu);

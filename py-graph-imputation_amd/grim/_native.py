@@ -306,7 +306,8 @@ EXPORTS += [
     "grim_format_double", "grim_hostgraph_load_csv", "grim_hostgraph_desc", "grim_hostgraph_free", "grim_graphgen_csv", "grim_hostgraph_from_hpf",
     "grim_parsed_allele", "grim_prior_matrix", "grim_stream_open", "grim_stream_write", "grim_stream_write_file", "grim_stream_finish",
     "grim_stream_error", "grim_stream_text", "grim_stream_get_stats", "grim_stream_n_unsupported", "grim_stream_unsupported",
-    "grim_stream_next_records", "grim_stream_release_records", "grim_stream_free",
+    "grim_stream_next_records", "grim_stream_release_records", "grim_stream_free", "grim_stream_write_text",
+    "grim_stream_segment", "grim_stream_n_segments", "grim_stream_segment_end", "grim_default_threads",
 ]
 
 
@@ -427,6 +428,15 @@ def host_lib():
     L.grim_stream_release_records.restype = C.c_int
     L.grim_stream_release_records.argtypes = [C.c_void_p, C.POINTER(StreamRecords)]
     L.grim_stream_free.argtypes = [C.c_void_p]
+    L.grim_stream_write_text.restype = C.c_int
+    L.grim_stream_write_text.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64]
+    L.grim_stream_segment.restype = C.c_int
+    L.grim_stream_segment.argtypes = [C.c_void_p, C.c_uint64]
+    L.grim_stream_n_segments.restype = C.c_uint32
+    L.grim_stream_n_segments.argtypes = [C.c_void_p]
+    L.grim_stream_segment_end.restype = C.c_int
+    L.grim_stream_segment_end.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]
+    L.grim_default_threads.restype = C.c_uint32
     _host_ready = True
     return L
 
@@ -712,6 +722,24 @@ class Stream:
 
     def write(self, data):
         self._check(host_lib().grim_stream_write(self.h, data, len(data)))
+
+    def write_text(self, data):
+        """universal newlines, as Python's open(): "\r\n" and "\r" end a line too"""
+        self._check(host_lib().grim_stream_write_text(self.h, data, len(data)))
+
+    def segment(self, next_line_offset):
+        """end the current input segment; the next byte written starts the line with this global index"""
+        self._check(host_lib().grim_stream_segment(self.h, int(next_line_offset)))
+
+    def segment_ends(self):
+        """after finish(): per segment the cumulative bytes of the seven texts up to its end"""
+        L = host_lib()
+        out = []
+        for k in range(int(L.grim_stream_n_segments(self.h))):
+            v = (C.c_uint64 * 7)()
+            L.grim_stream_segment_end(self.h, k, v)
+            out.append([int(x) for x in v])
+        return out
 
     def write_file(self, path):
         self._check(host_lib().grim_stream_write_file(self.h, os.fsencode(path)))

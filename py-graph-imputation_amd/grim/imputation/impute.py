@@ -488,24 +488,29 @@ class Imputation(object):
         data = "".join(l if l.endswith("\n") else l + "\n" for l in lines).encode()
         return self._stream_run(config, planb, em_mr, em, data=data, line_offset=line_offset, as_bytes=as_bytes)
 
+    @staticmethod
+    def _phase_masks(config):
+        """phase masks (impute.py:2001-2005, 2030-2032, 277-290): position m may switch sides only where the subject's list
+        holds 1; an id missing from the file is a KeyError in the reference -> raw line to .problem.  None: no mask file."""
+        if not os.path.isfile(config["bin_imputation_input_file"]):
+            return None
+        import json
+        with open(config["bin_imputation_input_file"]) as fh:
+            f_bin = json.load(fh)
+        masks = {}
+        for sid, mask in f_bin.items():
+            fixed = 0
+            for m in range(nat.MAXL):
+                if not (m < len(mask) and mask[m] == 1):
+                    fixed |= 1 << m
+            masks[sid] = fixed
+        return masks
+
     def _stream_run(self, config, planb, em_mr, em, out_paths=None, in_path=None, data=None, line_offset=0, as_bytes=False):
         if planb is None:
             planb = config["planb"]
         self.unsupported = []
-        masks = None
-        if os.path.isfile(config["bin_imputation_input_file"]):
-            # phase masks (impute.py:2001-2005, 2030-2032, 277-290): position m may switch sides only where the
-            # subject's list holds 1; an id missing from the file is a KeyError in the reference -> raw line to .problem
-            import json
-            with open(config["bin_imputation_input_file"]) as fh:
-                f_bin = json.load(fh)
-            masks = {}
-            for sid, mask in f_bin.items():
-                fixed = 0
-                for m in range(nat.MAXL):
-                    if not (m < len(mask) and mask[m] == 1):
-                        fixed |= 1 << m
-                masks[sid] = fixed
+        masks = self._phase_masks(config)
         params = self._params(config, planb, em_mr, em)
         ps, keep = nat.prior_spec(config["priority"], self.unk_priors, self.count_by_prob)
         ctx = nat.default_context(self.device)

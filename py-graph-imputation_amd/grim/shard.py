@@ -1,25 +1,35 @@
 """
 Multi-GPU driver: one process per GPU, the subject file cut into fixed-size chunks of lines that the ranks PULL from a
-shared counter, graph replicated per GPU, NO collective on the data path; every chunk's six outputs go to part files and
-rank 0 concatenates them in chunk order.
+shared counter, graph replicated per GPU, NO collective on the data path.
 
 This is the split the reference's scripts/runfile_mp.py:109-148 intends (`split -l` + one worker per chunk + `cat` of the
 per-chunk outputs), with three differences: workers are GPU ranks; chunks are handed out dynamically (a subject's cost
 varies by more than 1000x with its ambiguity, so equal line counts are not equal work -- SURVEY 8e); `.miss/.problem`
 keep the GLOBAL line index (the reference's per-chunk runs restart at 0).
 
+Data path of a rank: ONE long-lived streaming pipeline (grim_stream: tokenizer threads -> device -> formatter threads ->
+ordered pwrite) for the whole job.  A pulled chunk is a byte range of the input file; its raw bytes go to the stream as one
+input SEGMENT (grim_stream_segment carries the chunk's global line index), so chunk k+1 is tokenised while chunk k is on
+the device -- no per-chunk stream, no Python line splitting.  The rank's six outputs are six PART FILES that grow in the
+order the rank pulled its chunks; a manifest records, per chunk, where its piece of every part file ends.  Rank 0 then
+assembles the final files in chunk order with copy_file_range (the kernel moves the bytes; nothing is read back into
+Python).
+
 The only communication is the control plane: an atomic fetch-add on the job's rendezvous store (the next chunk number),
-one barrier at the end, and an error slot per rank so that a rank that fails does not leave the others waiting.
+the job's unique parts directory name, one barrier at the end, and an error slot per rank so that a rank that fails does
+not leave the others waiting.
 
 Launch:  torchrun --nproc-per-node N --master-addr 127.0.0.1 your_script.py   ->  impute_sharded(conf)
 (`impute_sharded` joins the job itself -- gloo, control plane only -- when the caller has not initialised
 torch.distributed; alone, without WORLD_SIZE > 1, it runs every chunk in this process).
 """
 
+import json
 import os
 import pathlib
 import shutil
 import traceback
+import uuid
 
 OUTPUT_KEYS = ("umug", "umug_pops", "pmug", "pmug_pops", "miss", "problem")
 DEFAULT_CHUNK_LINES = 65536
@@ -38,27 +48,37 @@ def merge_texts(per_rank):
 
 def chunk_offsets(path, chunk_lines):
     """byte offset of every chunk_lines-th line start of the file, plus the file size: chunk c = bytes [off[c], off[c+1]).
-    A last line without its newline counts as a line."""
+    Lines end the way Python's universal-newline open() -- and the library's grim_stream_write_text -- ends them: at "\\n",
+    at "\\r\\n" (one end, after the "\\n") and at a lone "\\r".  A last line without its line end counts as a line."""
     import numpy as np
 
     size = os.path.getsize(path)
     if size == 0:
         return [0]
     offs = [0]
-    seen = 0  # newlines before the current block
+    seen = 0  # line ends before the current block
     with open(path, "rb") as fh:
         pos = 0
-        while True:
-            block = fh.read(1 << 24)
-            if not block:
-                break
-            nl = np.flatnonzero(np.frombuffer(block, dtype=np.uint8) == 10)
-            k = chunk_lines - (seen % chunk_lines) - 1  # index (inside nl) of the newline that ends the current chunk
-            while k < len(nl):
-                offs.append(pos + int(nl[k]) + 1)
+        block = fh.read(1 << 24)
+        while block:
+            nxt = fh.read(1 << 24)
+            a = np.frombuffer(block, dtype=np.uint8)
+            is_nl = a == 10
+            is_cr = a == 13
+            if is_cr.any():
+                follow = np.empty(len(a), dtype=bool)  # the byte after position i is "\n"
+                follow[:-1] = is_nl[1:]
+                follow[-1] = bool(nxt) and nxt[0] == 10
+                ends = np.flatnonzero(is_nl | (is_cr & ~follow))
+            else:
+                ends = np.flatnonzero(is_nl)
+            k = chunk_lines - (seen % chunk_lines) - 1  # index (inside ends) of the line end that closes the current chunk
+            while k < len(ends):
+                offs.append(pos + int(ends[k]) + 1)
                 k += chunk_lines
-            seen += len(nl)
+            seen += len(ends)
             pos += len(block)
+            block = nxt
     if offs[-1] >= size and len(offs) > 1:
         offs.pop()
     offs.append(size)
@@ -66,7 +86,7 @@ def chunk_offsets(path, chunk_lines):
 
 
 class _Control:
-    """the job's control plane: chunk counter, error slots, final barrier"""
+    """the job's control plane: chunk counter, shared values, error slots, final barrier"""
 
     def __init__(self):
         self.rank, self.world, self.dist, self.store = 0, 1, None, None
@@ -101,6 +121,16 @@ class _Control:
             self._next += 1
             return c
         return int(self.store.add("grim_chunk_" + tag, 1)) - 1
+
+    def share(self, key, make):
+        """rank 0's make() for every rank (the store's get() blocks until rank 0 has set the key)"""
+        if self.store is None:
+            return make()
+        if self.rank == 0:
+            v = make()
+            self.store.set(key, v)
+            return v
+        return self.store.get(key).decode()
 
     def report_error(self, tag, text):
         if self.store is not None:
@@ -137,85 +167,226 @@ class _Control:
             return False
 
 
-_run_counter = [0]
+class _StreamSink:
+    """a rank's data path: one grim_stream for the whole job, a chunk = one input segment, outputs = six part files"""
+
+    def __init__(self, imp, config, hap_pop_pair, part_paths, flags):
+        from . import _native as nat
+
+        self.nat = nat
+        planb = config["planb"]
+        params = imp._params(config, planb, hap_pop_pair, False)
+        ps, keep = nat.prior_spec(config["priority"], imp.unk_priors, imp.count_by_prob)
+        ctx = nat.default_context(imp.device)
+        out_paths = {k: part_paths[k] for k in OUTPUT_KEYS if flags[k]}
+        self._keep = (params, ps, keep)
+        self.imp = imp
+        self.st = nat.Stream(ctx, imp.netGraph.device(ctx), imp.netGraph.adict, params, ps, imp.populations,
+                             out_paths=out_paths, want_log=False, masks=imp._phase_masks(config))
+        self.first = True
+
+    def feed(self, raw, line_offset):
+        if not self.first or line_offset:
+            self.st.segment(line_offset)  # (the first chunk is segment 0 unless it does not start at line 0)
+        self.first = False
+        self.st.write_text(raw)
+
+    def finish(self):
+        """-> per fed chunk, cumulative bytes of the six texts at its end"""
+        try:
+            self.st.finish()
+            ends = self.st.segment_ends()
+            self.imp.unsupported = self.st.unsupported()
+        finally:
+            self.st.close()
+        return [e[:6] for e in ends]
+
+    def abort(self):
+        try:
+            self.st.close()
+        except Exception:
+            pass
+
+
+class _ComputeSink:
+    """the same layout from an injected per-chunk compute(config, lines, line_offset) -> texts (tests: the oracle)"""
+
+    def __init__(self, compute, config, part_paths, flags):
+        self.compute, self.config = compute, config
+        self.fh = {k: open(part_paths[k], "wb") for k in OUTPUT_KEYS if flags[k]}
+        self.pos = {k: 0 for k in OUTPUT_KEYS}
+        self.ends = [[0] * 6]  # segment 0 (empty until the first chunk without an offset arrives)
+        self.first = True
+
+    def feed(self, raw, line_offset):
+        import io
+
+        # universal newlines, as the product path's grim_stream_write_text
+        text = io.TextIOWrapper(io.BytesIO(raw), encoding="utf-8", newline=None).read()
+        lines = [l + "\n" for l in text.split("\n")]
+        if text.endswith("\n") or not text:
+            lines.pop()  # the text ended with a line end: what follows it is not a line
+        texts = self.compute(self.config, lines, line_offset)
+        for k in OUTPUT_KEYS:
+            data = texts.get(k, "")
+            if data and k in self.fh:
+                data = data if isinstance(data, bytes) else data.encode()
+                self.fh[k].write(data)
+                self.pos[k] += len(data)
+        if self.first and not line_offset:
+            self.ends[0] = [self.pos[k] for k in OUTPUT_KEYS]
+        else:
+            self.ends.append([self.pos[k] for k in OUTPUT_KEYS])
+        self.first = False
+
+    def finish(self):
+        for fh in self.fh.values():
+            fh.close()
+        return self.ends
+
+    def abort(self):
+        for fh in self.fh.values():
+            try:
+                fh.close()
+            except Exception:
+                pass
+
+
+def _copy_range(src_fd, dst_fd, off, n):
+    """n bytes of src from offset off, appended to dst: copy_file_range where the kernel offers it, sendfile / read-write else"""
+    while n > 0:
+        try:
+            k = os.copy_file_range(src_fd, dst_fd, n, offset_src=off)
+        except (AttributeError, OSError):
+            k = -1
+        if k <= 0:
+            os.lseek(src_fd, off, os.SEEK_SET)
+            buf = os.read(src_fd, min(n, 1 << 24))
+            if not buf:
+                raise IOError("part file shorter than its manifest says")
+            os.write(dst_fd, buf)
+            k = len(buf)
+        off += k
+        n -= k
 
 
 def impute_sharded(conf_file, hap_pop_pair=False, graph=None, compute=None, project_dir_graph="",
-                   project_dir_in_file="", chunk_lines=None):
+                   project_dir_in_file="", chunk_lines=None, return_texts=False):
     """Run `impute` across the ranks of the torch.distributed job (or alone if there is none).  `compute(config, lines,
-    line_offset) -> texts` can be injected (tests); the default runs the HIP engine on this rank's GPU (LOCAL_RANK).
-    Returns the merged texts on rank 0 (read back from the files it wrote), None elsewhere; every rank raises when any
-    rank failed."""
+    line_offset) -> texts` can be injected (tests); the default runs the HIP engine on this rank's GPU (LOCAL_RANK) as one
+    stream per rank.  Rank 0 returns {key: path of the final file} (the texts themselves with return_texts=True: a test
+    convenience -- the product path never reads its outputs back), the other ranks None; every rank raises when any rank
+    failed."""
     from .run_impute_def import load_config
+    from .imputation.impute import Imputation as _I
 
     ctl = _Control()
-    _run_counter[0] += 1
-    tag = str(_run_counter[0])  # several calls in one job keep separate counters
     chunk_lines = int(chunk_lines or os.environ.get("GRIM_SHARD_LINES", DEFAULT_CHUNK_LINES))
-    config, out_dir = load_config(conf_file, project_dir_graph, project_dir_in_file)
-    in_path = config["imputation_input_file"]
-    parts_dir = os.path.join(out_dir, ".grim_parts_" + tag)
+    names = {key: (path_key, flag) for key, path_key, flag in _I._OUT_FILES}
     error = None
+    sink = None
+    parts_dir = None
+    # the job's id: unique per call and per job, published by rank 0 -- a parts directory left behind by a run that died
+    # can never be taken for this run's (and the manifests, not a directory listing, say what gets merged)
+    tag = ctl.share("grim_job_%d" % _next_call(), lambda: uuid.uuid4().hex[:12])
     try:
-        offs = chunk_offsets(in_path, chunk_lines)
-        n_chunks = len(offs) - 1
+        config, out_dir = load_config(conf_file, project_dir_graph, project_dir_in_file)
+        in_path = config["imputation_input_file"]
+        flags = {k: (names[k][1] is None or bool(config[names[k][1]])) for k in OUTPUT_KEYS}
+        parts_dir = os.path.join(out_dir, ".grim_parts_" + tag)
         if ctl.rank == 0:
             pathlib.Path(out_dir).mkdir(parents=False, exist_ok=True)
         pathlib.Path(parts_dir).mkdir(parents=True, exist_ok=True)
+        offs = chunk_offsets(in_path, chunk_lines)
+        n_chunks = len(offs) - 1
+        part_paths = {k: os.path.join(parts_dir, "%s.rank%d" % (k, ctl.rank)) for k in OUTPUT_KEYS}
         if compute is None:
-            from .imputation.impute import Imputation
             from .imputation.networkx_graph import Graph
             from . import _native as nat
 
             if graph is None:
                 graph = Graph(config).build_graph(config["node_file"], config["top_links_file"], config["edges_file"])
             n_dev = max(1, nat.lib().grim_device_count())
-            imp = Imputation(graph, config, device=ctl.local % n_dev)
-
-            def compute(cfg, shard, offset):
-                return imp.impute_lines(shard, cfg, em_mr=hap_pop_pair, line_offset=offset, as_bytes=True)
-
+            imp = _I(graph, config, device=ctl.local % n_dev)
+            sink = _StreamSink(imp, config, hap_pop_pair, part_paths, flags)
+        else:
+            sink = _ComputeSink(compute, config, part_paths, flags)
+        mine = []  # chunks this rank pulled, in order
         with open(in_path, "rb") as fh:
             while True:
                 c = ctl.next_chunk(tag)
                 if c >= n_chunks:
                     break
                 fh.seek(offs[c])
-                raw = fh.read(offs[c + 1] - offs[c])
-                lines = raw.decode().splitlines(True)
-                texts = compute(config, lines, c * chunk_lines)
-                for k in OUTPUT_KEYS:
-                    data = texts.get(k, "")
-                    if data:
-                        with open(os.path.join(parts_dir, "%s.%08d" % (k, c)), "wb") as out:
-                            out.write(data if isinstance(data, bytes) else data.encode())
+                sink.feed(fh.read(offs[c + 1] - offs[c]), c * chunk_lines)
+                mine.append(c)
+        ends = sink.finish()
+        sink = None
+        # segment 0 exists even when the first chunk opened a new segment (it did unless it was chunk 0): drop the empty one
+        if len(ends) == len(mine) + 1:
+            ends = ends[1:]
+        if len(ends) != len(mine):
+            raise RuntimeError("internal: %d segments for %d chunks" % (len(ends), len(mine)))
+        with open(os.path.join(parts_dir, "manifest.rank%d.json" % ctl.rank), "w") as fh:
+            json.dump({"chunks": mine, "ends": ends}, fh)
     except BaseException as e:  # the other ranks must not wait for this one forever: report, reach the barrier, raise
         error = e
+        if sink is not None:
+            sink.abort()
         ctl.report_error(tag, "%s: %s\n%s" % (type(e).__name__, e, traceback.format_exc()))
     failed = ctl.barrier_and_errors(tag)
-    if error is not None:
-        raise error
-    if failed:
-        raise RuntimeError("impute_sharded: rank(s) %s failed:\n%s" % ([r for r, _ in failed], failed[0][1]))
-    merged = None
-    if ctl.rank == 0:
-        from .imputation.impute import Imputation as _I
+    result = None
+    try:
+        if error is not None:
+            raise error
+        if failed:
+            raise RuntimeError("impute_sharded: rank(s) %s failed:\n%s" % ([r for r, _ in failed], failed[0][1]))
+        if ctl.rank == 0:
+            where = {}  # chunk -> (rank, start offsets, end offsets)
+            for r in range(ctl.world):
+                with open(os.path.join(parts_dir, "manifest.rank%d.json" % r)) as fh:
+                    m = json.load(fh)
+                prev = [0] * 6
+                for c, e in zip(m["chunks"], m["ends"]):
+                    where[c] = (r, prev, e)
+                    prev = e
+            missing = [c for c in range(n_chunks) if c not in where]
+            if missing:
+                raise RuntimeError("impute_sharded: no rank reported chunk(s) %s" % missing[:8])
+            result = {}
+            for ki, k in enumerate(OUTPUT_KEYS):
+                path_key, _ = names[k]
+                if not flags[k]:
+                    result[k] = "" if return_texts else None
+                    continue
+                src = {}
+                dst = os.open(config[path_key], os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+                try:
+                    for c in range(n_chunks):  # `cat` of the chunks' pieces in chunk order
+                        r, a, e = where[c]
+                        if e[ki] > a[ki]:
+                            if r not in src:
+                                src[r] = os.open(os.path.join(parts_dir, "%s.rank%d" % (k, r)), os.O_RDONLY)
+                            _copy_range(src[r], dst, a[ki], e[ki] - a[ki])
+                finally:
+                    os.close(dst)
+                    for fd in src.values():
+                        os.close(fd)
+                if return_texts:
+                    with open(config[path_key]) as fh:
+                        result[k] = fh.read()
+                else:
+                    result[k] = config[path_key]
+    finally:
+        ctl.barrier()  # nobody removes the parts before rank 0 is through with them
+        if ctl.rank == 0 and parts_dir is not None:
+            shutil.rmtree(parts_dir, ignore_errors=True)
+    return result
 
-        names = {key: (path_key, flag) for key, path_key, flag in _I._OUT_FILES}
-        merged = {}
-        for k in OUTPUT_KEYS:
-            path_key, flag = names[k]
-            if flag is not None and not config[flag]:
-                merged[k] = ""
-                continue
-            with open(config[path_key], "wb") as out:  # `cat` of the per-chunk parts in chunk order
-                for c in range(n_chunks):
-                    part = os.path.join(parts_dir, "%s.%08d" % (k, c))
-                    if os.path.exists(part):
-                        with open(part, "rb") as src:
-                            shutil.copyfileobj(src, out, 1 << 24)
-            with open(config[path_key]) as fh:
-                merged[k] = fh.read()
-        shutil.rmtree(parts_dir, ignore_errors=True)
-    ctl.barrier()
-    return merged
+
+_call_counter = [0]
+
+
+def _next_call():
+    _call_counter[0] += 1
+    return _call_counter[0]

@@ -191,6 +191,43 @@ def test_one_wave_kernel_equals_general_kernel(monkeypatch):
         assert fast[k] == slow[k], k
 
 
+def test_pair_pass_without_dedup_equals_pair_pass_with_dedup(monkeypatch):
+    """Subjects whose two '/' lists are disjoint at every differing position skip the first-wins dedup of the pair passes
+    (prepare_lists, grim_plan_a.h: no haplotype can belong to two phase sides).  GRIM_NO_NODUP=1 sends every subject through
+    the dedup; both ways must give the same files -- on mixed subjects of both graphs (Plan A, B and C), on subjects whose
+    lists OVERLAP or are homozygous (the flag must stay off: side 1 and side 2 share haplotypes), and against the oracle."""
+    rows = synth.read_freqs(synth.CAU_FREQS)
+    for gname, pops, seed in (("cau", ["CAU"], 141), ("pop4", harness.POPS["pop4"], 142)):
+        gen = synth.SubjectGen(rows, seed, pops=pops)
+        lines = gen.mixed(1200) + gen.mixed(300, amb=0.8, miss=0.4) + synth.edge_cases(pops[0]) + synth.plan_c_cases(pops[0])
+        # overlapping lists: side 2 repeats one of side 1's alternatives; and all-homozygous subjects
+        extra = []
+        for k, l in enumerate(gen.mixed(200, amb=0.9, miss=0.2, recomb=0.3)):
+            f = l.split(",")
+            loci = f[1].split("^")
+            for i, loc in enumerate(loci):
+                a, b = loc.split("+")
+                if k % 2 == 0:
+                    loci[i] = a + "+" + a.split("/")[0] + "/" + b   # the lists of the two sides share an allele
+                else:
+                    loci[i] = a + "+" + a                          # homozygous everywhere: ONE phase, identical sides
+            extra.append(",".join(["X%d" % k, "^".join(loci)] + f[2:]))
+        lines += extra
+        conf = harness.base_conf(pops)
+        conf["UNK_priors"] = "MR"
+        monkeypatch.delenv("GRIM_NO_NODUP", raising=False)
+        fast, _, _ = _run(gname, conf, lines, "nodup_on")
+        monkeypatch.setenv("GRIM_NO_NODUP", "1")
+        slow, _, _ = _run(gname, conf, lines, "nodup_off")
+        monkeypatch.delenv("GRIM_NO_NODUP", raising=False)
+        for k in fast:
+            assert fast[k] == slow[k], (gname, k)
+        exp, _ = harness.run_oracle(gname, conf, extra, tag="nodup_orc")
+        got, _, _ = _run(gname, conf, extra, "nodup_x")
+        for k in exp:
+            assert got[k] == exp[k], (gname, k)
+
+
 def test_config4_style_20k_properties_and_oracle_sample():
     """BASELINE config 4 at reduced size: 4-population graph, 20k subjects with missing loci, ambiguity,
     recombinants (Plan B / C exercised), mixed race columns."""

@@ -29,7 +29,7 @@ if FAIL_RANK == dist.get_rank():
     def compute(cfg, lines, offset):
         raise ValueError("boom on rank %d" % dist.get_rank())
 try:
-    merged = shard.impute_sharded(CONF, compute=compute, chunk_lines=CHUNK)
+    merged = shard.impute_sharded(CONF, compute=compute, chunk_lines=CHUNK, return_texts=True)
     if dist.get_rank() == 0:
         json.dump(merged, open(OUT, "w"))
 except Exception as e:
@@ -64,6 +64,29 @@ def test_chunk_offsets(tmp_path):
             assert all(len(x.splitlines()) == chunk for x in parts[:-1]) and (not parts or 0 < len(parts[-1].splitlines()) <= chunk)
 
 
+def test_chunk_offsets_universal_newlines(tmp_path):
+    """lines end as Python's universal-newline open() ends them -- "\n", "\r\n", a lone "\r" -- and at nothing else
+    (\x0c and \x85 inside an id are data); chunk starts are line starts, whichever block boundary the "\r\n" straddles"""
+    import io
+
+    from grim import shard
+
+    rows = ["A%d,x\x0cy" % i for i in range(23)]
+    for sep_cycle in (["\n"], ["\r\n"], ["\r"], ["\n", "\r\n", "\r"]):
+        data = "".join(r + sep_cycle[i % len(sep_cycle)] for i, r in enumerate(rows)).encode()
+        p = tmp_path / "u.csv"
+        p.write_bytes(data)
+        want = io.TextIOWrapper(io.BytesIO(data), newline=None).read().split("\n")[:-1]
+        for chunk in (1, 3, 7, 50):
+            offs = shard.chunk_offsets(str(p), chunk)
+            got = []
+            for c in range(len(offs) - 1):
+                piece = io.TextIOWrapper(io.BytesIO(data[offs[c]:offs[c + 1]]), newline=None).read().split("\n")
+                assert piece[-1] == "" and len(piece) - 1 == (chunk if c < len(offs) - 2 else len(rows) - chunk * (len(offs) - 2))
+                got += piece[:-1]
+            assert got == want
+
+
 def _launch(tmp_path, world, chunk, lines, port, fail_rank=-1, tag="mr"):
     work = harness.ensure_graph("cau")
     conf = harness.base_conf(["CAU"])
@@ -91,6 +114,31 @@ def test_world_size_2_gloo(tmp_path):
     for k in single:
         assert got[k] == single[k], "file " + k
     assert not [f for f in os.listdir(os.path.join(work, "output_mr")) if f.startswith(".grim_parts")]
+
+
+def test_failed_run_then_good_run_in_the_same_directory(tmp_path):
+    """a job that dies leaves nothing a later job in the same output directory could pick up: the parts directory is the
+    job's own (unique id from the store), is removed on the error path too, and the merge follows the manifests"""
+    rows = synth.read_freqs(synth.CAU_FREQS)
+    lines = synth.SubjectGen(rows, 81).mixed(30) + synth.edge_cases("CAU")[:4]
+    work, conf, out = _launch(tmp_path, 2, 5, lines, 29523, fail_rank=1, tag="mrs")
+    assert not os.path.exists(out)
+    out_dir = os.path.join(work, "output_mrs")
+    # what an older build's failed run would have left behind, under the old naming scheme and the new one
+    for name in (".grim_parts_1", ".grim_parts_deadbeef0000"):
+        os.makedirs(os.path.join(out_dir, name), exist_ok=True)
+        for k in ("miss", "umug", "problem"):
+            with open(os.path.join(out_dir, name, "%s.%08d" % (k, 3)), "w") as fh:
+                fh.write("STALE\n")
+            with open(os.path.join(out_dir, name, "%s.rank0" % k), "w") as fh:
+                fh.write("STALE\n")
+    lines2 = lines[:17]  # a different input: fewer chunks than the stale parts name
+    work, conf, out = _launch(tmp_path, 2, 5, lines2, 29525, tag="mrs")
+    merged = json.load(open(out))
+    single, _ = harness.run_oracle("cau", conf, lines2, tag="mrs_single")
+    for k in single:
+        assert merged[k] == single[k], k
+        assert "STALE" not in merged[k]
 
 
 def test_world_size_3_more_ranks_than_chunks(tmp_path):

@@ -18,7 +18,7 @@ import json, os, sys
 os.environ["GRIM_QUIET"] = "1"
 os.chdir(WORK)
 from grim import shard
-merged = shard.impute_sharded(CONF, chunk_lines=CHUNK)
+merged = shard.impute_sharded(CONF, chunk_lines=CHUNK, return_texts=True)
 if int(os.environ["RANK"]) == 0:
     json.dump(merged, open(OUT, "w"))
 '''
