@@ -35,6 +35,29 @@ def test_small_variant_vs_oracle():
         assert got[k] == exp[k], k
 
 
+def test_full_size_graph_vs_reference_golden():
+    """The REAL reference's answer on the full-size graph (1.06 M nodes, three populations): tests/golden/wmda_full holds the
+    six output files and per-subject counts it produced in the build container for six high-ambiguity subjects (8 / 16
+    alternatives per locus and side; tools/make_golden_wmda.py, 6 minutes of reference time).  Byte for byte."""
+    import json
+
+    gdir = os.path.join(harness.GOLD, "wmda_full")
+    meta = json.load(open(os.path.join(gdir, "meta.json")))
+    assert meta["n_haps"] == wmda_scale.N_HAPS
+    wmda_scale.ensure()
+    name = wmda_scale.name_of()
+    lines = [l.rstrip("\n") for l in open(os.path.join(gdir, "input.csv"))]
+    assert lines == wmda_scale.subjects(len(lines))  # the generator still makes the subjects the fixture was made from
+    got, glog, imp = harness.run_product(name, wmda_scale.conf(), lines, tag="w5g", quiet=False)
+    assert not imp.unsupported
+    for k, f in harness.OUT_FILES.items():
+        p = os.path.join(gdir, f)
+        exp = open(p).read() if os.path.exists(p) else ""
+        assert got[k] == exp, k
+    elog = [l for l in open(os.path.join(gdir, "log.txt")).read().splitlines() if "Subject:" in l]
+    assert glog == elog
+
+
 def test_full_size_graph_properties(monkeypatch):
     work = wmda_scale.ensure()
     name = wmda_scale.name_of()
