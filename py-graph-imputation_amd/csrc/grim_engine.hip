@@ -19,7 +19,9 @@
 #include "grim_small.h"
 #include "grim_medium.h"
 #include "grim_tables.h"
+#include "grim_tokdev.h"
 #include "grim_engine_internal.h"
+#include "grim_host_internal.h"
 
 // =================================================================================================
 // Plan-A kernel: one workgroup per subject, pulled from a work counter.  Waves build the phase
@@ -155,15 +157,17 @@ __global__ __launch_bounds__(GRIM_WG, GRIM_WG_PER_CU) void grim_plan_a_kernel(De
 // the TOP of the row pool; most of that region stays empty (3 + ~1.3 of 13 rows per subject).  This kernel moves the
 // rows that exist into the bump-allocated part of the pool -- one allocation per wave of 64 subjects -- and re-bases the
 // subjects' row offsets, so that the batch's D2H copy carries 144 instead of 416 bytes of rows per subject.
-__global__ __launch_bounds__(64) void grim_small_compact_kernel(DevArgs A, const uint32_t *order_s, uint32_t n_small, uint32_t stage_base,
-                                                                 uint32_t stride) {
+__global__ __launch_bounds__(64) void grim_small_compact_kernel(DevArgs A, const uint32_t *order_s, const SmallRec *recs, uint32_t n_small,
+                                                                 uint32_t stage_base, uint32_t stride) {
   const uint32_t w = blockIdx.x * 64 + threadIdx.x;
   const int lane = lane_id();
   // a subject's staged rows are one run: [.umug, .umug.pops, .pmug.pops, its .pmug rows] from stage_base + w * stride
   uint32_t si = 0, cnt = 0;
   uint4 ro = make_uint4(0, 0, 0, 0), nr = make_uint4(0, 0, 0, 0);
-  if (w < n_small) {
-    si = order_s[w];
+  // record w's subject: from the class list (host-tokenised subjects), or from the record itself (device-tokenised
+  // lines: GRIM_NONE where the line is not a device subject)
+  if (w < n_small) si = order_s ? order_s[w] : recs[w].si;
+  if (w < n_small && si != GRIM_NONE) {
     const uint32_t *r = (const uint32_t *)(A.res + si);  // dwords 3..6 row_off, 7..10 n_rows
     ro = make_uint4(r[3], r[4], r[5], r[6]);
     nr = make_uint4(r[7], r[8], r[9], r[10]);
@@ -289,19 +293,28 @@ struct grim_batch {
   unsigned long long *hstate;  // pinned: counters + work/row heads of the last run
   SmallRec *d_small;
   uint32_t *d_os, *d_om;
+  // device tokenizer (plan.text_cap != 0)
+  const grim_devdict *dict;
+  LineRec *d_lines;
+  uint8_t *d_text;
+  SmallRec *d_dsmall;   // its half-wave records, one slot per line (work arena)
+  uint64_t off_subj;    // the input arena up to here is all a run without host-tokenised subjects needs
+  uint32_t dev_lo, dev_hi, n_dev_lines, n_irregular;
+  uint32_t n_host_small_waves;
+  float ms_k;           // timing mode: the tokenizer kernel
   uint32_t n_medium;
   uint32_t n_small, n_general, small_stride;
   uint64_t scratch_need;  // bytes of per-workgroup scratch this batch's runs need (bound at run time)
   hipEvent_t ev_done;  // recorded behind the last kernel of a stage: what engine_batch_wait waits for (not the whole stream --
                        // the device thread may have queued the next chunk's kernels behind it already)
   bool enqueued;       // stage 1 is in flight (engine_batch_enqueue without its engine_batch_wait)
-  hipEvent_t ev[14];  // timing mode, kernel start/stop: [3]/[5] half-wave, [0]/[1] one-wave, [6]/[7] general, [4]/[2] Plan B,
+  hipEvent_t ev[16];  // timing mode, kernel start/stop ([14]/[15] device tokenizer): [3]/[5] half-wave, [0]/[1] one-wave, [6]/[7] general, [4]/[2] Plan B,
                       // [8]/[9] table kernels of stage 1, [10]/[11] table kernels after Plan B
   bool timing;       // GRIM_TIMING=1 or grim_batch_set_timing: direct launches with per-kernel events instead of the graph replay
   hipGraphExec_t gexec;
   int graph_state;  // 0 not tried, 1 captured, -1 direct launches
   float ms_a, ms_b, ms_s, ms_g, ms_m, ms_t, ms_c;  // ms_c: the half-wave kernel's row compaction
-  double acc_ms[8];   // sums over the timed runs since timing was switched on (index = `which`)
+  double acc_ms[9];   // sums over the timed runs since timing was switched on (index = `which`)
   uint32_t n_timed;
   uint32_t rows_used;
   unsigned long long counters[8];
@@ -550,14 +563,19 @@ static bool batch_plan(grim_batch *b, const EnginePlan &pl) {
   uint64_t o = 0;
   auto take = [&](uint64_t bytes) { uint64_t r = o; o = align256(o + bytes); return r; };
   const uint64_t o_state = take(8ull * (GRIM_NCTR + GRIM_NQ / 2));
+  // device tokenizer: line records and the chunk's text come first -- a run whose lines are all tokenised on the device
+  // copies the arena only up to here
+  const bool devtok = pl.text_cap != 0;
+  const uint64_t o_lines = take(devtok ? sizeof(LineRec) * n : 0), o_text = take(devtok ? pl.text_cap + 64 : 0);
   const uint64_t o_subj = take(sizeof(grim_subject) * n);
   const uint64_t o_small = take(sizeof(SmallRec) * n);
   const uint64_t o_os = take(4 * n), o_om = take(4 * n), o_og = take(4 * n);
-  const uint64_t o_tok = take(2 * (pl.tok_cap ? pl.tok_cap : 1));
+  const uint64_t o_tok = take(2 * ((pl.tok_cap ? pl.tok_cap : 1) + (devtok ? (uint64_t)TOK_LANES * n : 0)));  // device-written tokens behind the host's
   const uint64_t in_bytes = o;
   o = 0;
   const uint64_t small_waves = ((n + GRIM_WG / 32 - 1) / (GRIM_WG / 32)) * (GRIM_WG / 64);
-  const uint64_t w_bail = take(4 * n), w_next = take(4 * n), w_ctr = take(4 * (2 * small_waves + 2));
+  const uint64_t w_bail = take(4 * n), w_next = take(4 * n), w_ctr = take(4 * (4 * small_waves + 4));  // host- and device-tokenised launches
+  const uint64_t w_dsmall = take(devtok ? sizeof(SmallRec) * n : 0);
   const uint64_t w_t1 = take(sizeof(TabWork) * 2 * n), w_t2 = take(sizeof(TabWork) * 2 * n);  // a subject queues at most two items
   const uint64_t work_bytes = o;
   o = 0;
@@ -591,6 +609,12 @@ static bool batch_plan(grim_batch *b, const EnginePlan &pl) {
   A.next_count = A.queue + 2;
   A.subj = (const grim_subject *)(b->d_in + o_subj);
   b->d_small = (SmallRec *)(b->d_in + o_small);
+  b->d_lines = devtok ? (LineRec *)(b->d_in + o_lines) : nullptr;
+  b->d_text = devtok ? b->d_in + o_text : nullptr;
+  b->d_dsmall = devtok ? (SmallRec *)(b->d_work + w_dsmall) : nullptr;
+  b->off_subj = o_subj;
+  b->h.lines = devtok ? (LineRec *)(b->h_in + o_lines) : nullptr;
+  b->h.text = devtok ? b->h_in + o_text : nullptr;
   b->d_os = (uint32_t *)(b->d_in + o_os);
   b->d_om = (uint32_t *)(b->d_in + o_om);
   A.order = (const uint32_t *)(b->d_in + o_og);
@@ -696,7 +720,7 @@ grim_batch *engine_batch_create(grim_ctx *c, const grim_graph *g, const grim_par
       b->hstate = nullptr;
       ok = false;
     }
-    for (int i = 0; i < 14 && ok; ++i) ok = hipEventCreate(&b->ev[i]) == hipSuccess;
+    for (int i = 0; i < 16 && ok; ++i) ok = hipEventCreate(&b->ev[i]) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&b->ev_done, hipEventDisableTiming | hipEventReleaseToSystem) == hipSuccess;
     if (!ok) {
       set_err(c, "grim_batch: device or pinned-host allocation failed");
@@ -745,6 +769,76 @@ int engine_batch_plan(grim_batch *b, const EnginePlan *plan) {
 void engine_set_error(grim_ctx *c, const char *msg) { set_err(c, msg); }
 const EngineHost *engine_batch_host(grim_batch *b) { return b ? &b->h : nullptr; }
 uint64_t engine_bytes_moved(const grim_batch *, int dir) { return g_moved[dir ? 1 : 0]; }
+
+struct grim_devdict {
+  grim_ctx *ctx;
+  DevDict d;
+  std::vector<void *> bufs;
+};
+
+static void pack_name(const char *p, size_t n, uint32_t (&w)[6]) {
+  for (int i = 0; i < 6; ++i) w[i] = 0;
+  for (size_t k = 0; k < n && k < GRIM_TOKNAME; ++k) w[k >> 2] |= (uint32_t)(uint8_t)p[k] << (24 - 8 * (k & 3));
+}
+
+grim_devdict *engine_devdict_create(grim_ctx *c, const DictSnap *snap) {
+  if (!c || !snap) return nullptr;
+  use_device(c->device);
+  grim_devdict *dd = new grim_devdict();
+  dd->ctx = c;
+  memset(&dd->d, 0, sizeof(dd->d));
+  dd->d.n_loci = snap->n_loci;
+  for (uint32_t s = 0; s < GRIM_MAXL; ++s) dd->d.locus_len[s] = 0xFFFFFFFFu;  // matches no name
+  for (const DictSnap::Locus &L : snap->loci) {
+    if (L.slot >= GRIM_MAXL || L.name.empty() || L.name.size() > 8) continue;  // (longer locus names: host tokenizer)
+    uint64_t v = 0;
+    for (size_t k = 0; k < L.name.size(); ++k) v |= (uint64_t)(uint8_t)L.name[k] << (56 - 8 * k);
+    dd->d.locus[L.slot] = v;
+    dd->d.locus_len[L.slot] = (uint32_t)L.name.size();
+  }
+  bool ok = true;
+  for (uint32_t s = 0; s < snap->n_loci && s < GRIM_MAXL && ok; ++s) {
+    const uint32_t cnt = snap->base[s];
+    uint32_t cap = 16;
+    while (cap < 4ull * cnt) cap <<= 1;  // load <= 1/4: a wave waits for its unluckiest lane
+    std::vector<DictEnt> tab(cap);
+    memset(tab.data(), 0, sizeof(DictEnt) * cap);
+    for (uint32_t id = 0; id < cnt; ++id) {
+      const sv nm = snap->name(s, id);
+      if (nm.empty() || nm.size() > GRIM_TOKNAME) continue;  // never found on the device: such a line goes to the host tokenizer
+      DictEnt e;
+      pack_name(nm.data(), nm.size(), e.w);
+      e.hash = tokname_hash(e.w, (uint32_t)nm.size());
+      e.meta = 0x80000000u | ((uint32_t)nm.size() << 16) | (id & 0xFFFFu);
+      uint32_t k = e.hash & (cap - 1);
+      while (tab[k].meta >> 31) k = (k + 1) & (cap - 1);
+      tab[k] = e;
+    }
+    DictEnt *dt = upload(c, dd->bufs, tab.data(), cap, nullptr);
+    ok = dt != nullptr;
+    dd->d.tab[s] = dt;
+    dd->d.mask[s] = cap - 1;
+  }
+  if (!ok) {
+    set_err(c, "engine_devdict_create: device allocation or copy failed");
+    engine_devdict_free(dd);
+    return nullptr;
+  }
+  return dd;
+}
+
+void engine_devdict_free(grim_devdict *d) {
+  if (!d) return;
+  use_device(d->ctx->device);
+  for (void *p : d->bufs) hipFree(p);
+  delete d;
+}
+
+void engine_batch_set_dict(grim_batch *b, const grim_devdict *d) {
+  if (b) b->dict = d;
+}
+
+uint32_t engine_batch_irregular(const grim_batch *b) { return b ? b->n_irregular : 0; }
 
 // After grim_batch_run returned -2: when the PAIR POOL was what ran out and the demand fits `max_records`, the next
 // engine_batch_load sizes the pool for it (returns 1: load and run the same subjects again); 0: something else
@@ -799,6 +893,14 @@ int engine_batch_load(grim_batch *b, const EngineLoad *ld) {
   }
   A.priors = b->d_priors;
   A.ones_prior = b->priors_up;
+  if (ld->dev_hi > ld->dev_lo && (!b->dict || !b->d_lines || ld->text_bytes > b->plan.text_cap || ld->dev_hi > ld->n_subj)) {
+    set_err(c, "engine_batch_load: the batch was not planned for the device tokenizer");
+    return -1;
+  }
+  b->dev_lo = ld->dev_lo;
+  b->dev_hi = ld->dev_hi;
+  b->n_dev_lines = ld->dev_hi > ld->dev_lo ? ld->dev_hi - ld->dev_lo : 0;  // record slots of the device tokenizer: one per line of the range
+  b->n_irregular = 0;
   b->n_subj = ld->n_subj;
   b->n_small = ld->n_small;
   b->n_medium = ld->n_medium;
@@ -811,8 +913,13 @@ int engine_batch_load(grim_batch *b, const EngineLoad *ld) {
   unsigned long long *hs = (unsigned long long *)b->h_in;
   memset(hs, 0, 8 * (GRIM_NCTR + GRIM_NQ / 2));
   // (rows are bump-allocated from 0; the half-wave kernel's staging region is the top of the pool)
-  A.row_cap = (uint32_t)b->row_limit - ((uint64_t)b->n_small * b->small_stride <= b->row_limit ? b->n_small * b->small_stride : 0u);
-  const uint64_t bytes = b->off_tok + 2 * ld->tok_used;
+  {
+    const uint64_t staged = ((uint64_t)b->n_small + b->n_dev_lines) * b->small_stride;
+    A.row_cap = (uint32_t)(b->row_limit - (staged <= b->row_limit ? staged : 0));
+  }
+  // everything up to the last token in use; a load without host-tokenised subjects ends with the chunk's text
+  const bool host_subjects = ld->n_small + ld->n_medium + ld->n_general > 0;
+  const uint64_t bytes = (!host_subjects && b->n_dev_lines) ? b->off_subj : b->off_tok + 2 * ld->tok_used;
   HIPCHK(hipMemcpyAsync(b->d_in, b->h_in, bytes, hipMemcpyHostToDevice, st), c, -1);
   g_moved[0] += bytes;
   {
@@ -862,12 +969,14 @@ int engine_batch_load(grim_batch *b, const EngineLoad *ld) {
     A.pprob = (double *)(b->d_pool + o_prob);
   }
   const uint32_t per_block = GRIM_WG / 32;
-  b->n_small_waves = ((b->n_small + per_block - 1) / per_block) * (GRIM_WG / 64);
+  b->n_host_small_waves = ((b->n_small + per_block - 1) / per_block) * (GRIM_WG / 64);
+  b->n_small_waves = b->n_host_small_waves + ((b->n_dev_lines + per_block - 1) / per_block) * (GRIM_WG / 64);
   uint32_t slots = (uint32_t)c->n_cu * GRIM_WG_PER_CU;
   static const int env_slots = env_int("GRIM_SLOTS", 0);
   if (env_slots > 0) slots = (uint32_t)env_slots;
   if (slots > ld->n_subj) slots = ld->n_subj;
   if (slots == 0) slots = 1;
+  // (a device-tokenised subject can only ever reach the Plan-B kernel: it is the half-wave kernel's)
   b->n_slots = slots;
   b->scratch_need = (uint64_t)A.lay.stride * slots;
   if (b->gexec) {
@@ -993,23 +1102,62 @@ static void enqueue_tables(grim_batch *b, hipEvent_t start, hipEvent_t stop) {
 static int enqueue_stage1(grim_batch *b, bool timing) {
   grim_ctx *c = b->ctx;
   DevArgs &A = b->a;
+  const uint32_t per_block = GRIM_WG / 32;
+  // staging region of the half-wave kernel's rows, at the top of the pool: host-tokenised subjects first, then one slot per
+  // line of the device tokenizer
+  const uint32_t stage0 = (uint32_t)b->row_limit - (b->n_small + b->n_dev_lines) * b->small_stride;
+  const bool both = b->n_small && b->n_dev_lines;  // (timing mode brackets the device-tokenised launch when there are two)
   if (b->n_small) {
-    uint32_t per_block = GRIM_WG / 32;
     const dim3 grid((b->n_small + per_block - 1) / per_block), block(GRIM_WG);
-    const uint32_t stage_base = (uint32_t)b->row_limit - b->n_small * b->small_stride;  // the staging region: top of the pool
-    if (timing)
+    if (timing && !both)
       hipExtLaunchKernelGGL(grim_plan_a_small_kernel, grid, block, 0, c->stream, b->ev[3], b->ev[5], 0, A,
-                            (const SmallRec *)b->d_small, b->n_small, stage_base, b->small_stride);
+                            (const SmallRec *)b->d_small, b->n_small, stage0, b->small_stride);
     else
-      hipLaunchKernelGGL(grim_plan_a_small_kernel, grid, block, 0, c->stream, A, (const SmallRec *)b->d_small, b->n_small, stage_base,
+      hipLaunchKernelGGL(grim_plan_a_small_kernel, grid, block, 0, c->stream, A, (const SmallRec *)b->d_small, b->n_small, stage0,
                          b->small_stride);
     const dim3 cgrid((b->n_small + 63) / 64), cblock(64);
-    if (timing)
+    if (timing && !both)
       hipExtLaunchKernelGGL(grim_small_compact_kernel, cgrid, cblock, 0, c->stream, b->ev[12], b->ev[13], 0, A,
-                            (const uint32_t *)b->d_os, b->n_small, stage_base, b->small_stride);
+                            (const uint32_t *)b->d_os, (const SmallRec *)nullptr, b->n_small, stage0, b->small_stride);
     else
-      hipLaunchKernelGGL(grim_small_compact_kernel, cgrid, cblock, 0, c->stream, A, (const uint32_t *)b->d_os, b->n_small, stage_base,
+      hipLaunchKernelGGL(grim_small_compact_kernel, cgrid, cblock, 0, c->stream, A, (const uint32_t *)b->d_os, (const SmallRec *)nullptr,
+                         b->n_small, stage0, b->small_stride);
+  }
+  if (b->n_dev_lines) {
+    // GL strings -> half-wave records on the device, then the half-wave kernel over one record slot per line
+    DevTok T;
+    T.text = b->d_text;
+    T.lines = b->d_lines;
+    T.lo = b->dev_lo;
+    T.hi = b->dev_hi;
+    T.dict = b->dict->d;
+    T.dsmall = b->d_dsmall;
+    T.subj = const_cast<grim_subject *>(A.subj);
+    T.tok = const_cast<uint16_t *>(A.tok);
+    T.tok_base = (uint32_t)(b->plan.tok_cap ? b->plan.tok_cap : 1);
+    T.graph_loci = A.g.n_loci;
+    const dim3 tgrid((b->n_dev_lines + (GRIM_WG / 64) * TOK_LINES_PER_WAVE - 1) / ((GRIM_WG / 64) * TOK_LINES_PER_WAVE)), block(GRIM_WG);
+    if (timing)
+      hipExtLaunchKernelGGL(grim_tokenize_kernel, tgrid, block, 0, c->stream, b->ev[14], b->ev[15], 0, A, T);
+    else
+      hipLaunchKernelGGL(grim_tokenize_kernel, tgrid, block, 0, c->stream, A, T);
+    DevArgs A2 = A;
+    A2.small_ctr = A.small_ctr + 2 * b->n_host_small_waves;
+    const uint32_t stage_d = stage0 + b->n_small * b->small_stride;
+    const dim3 grid((b->n_dev_lines + per_block - 1) / per_block);
+    if (timing)
+      hipExtLaunchKernelGGL(grim_plan_a_small_kernel, grid, block, 0, c->stream, b->ev[3], b->ev[5], 0, A2,
+                            (const SmallRec *)b->d_dsmall, b->n_dev_lines, stage_d, b->small_stride);
+    else
+      hipLaunchKernelGGL(grim_plan_a_small_kernel, grid, block, 0, c->stream, A2, (const SmallRec *)b->d_dsmall, b->n_dev_lines, stage_d,
                          b->small_stride);
+    const dim3 cgrid((b->n_dev_lines + 63) / 64), cblock(64);
+    if (timing)
+      hipExtLaunchKernelGGL(grim_small_compact_kernel, cgrid, cblock, 0, c->stream, b->ev[12], b->ev[13], 0, A, (const uint32_t *)nullptr,
+                            (const SmallRec *)b->d_dsmall, b->n_dev_lines, stage_d, b->small_stride);
+    else
+      hipLaunchKernelGGL(grim_small_compact_kernel, cgrid, cblock, 0, c->stream, A, (const uint32_t *)nullptr, (const SmallRec *)b->d_dsmall,
+                         b->n_dev_lines, stage_d, b->small_stride);
   }
   if (b->n_medium) {
     static const int waves_per_cu = env_int("GRIM_MEDIUM_WAVES", GRIM_MEDIUM_WAVES_PER_CU);
@@ -1050,13 +1198,13 @@ int engine_batch_enqueue(grim_batch *b) {
   if (!b) return -1;
   grim_ctx *c = b->ctx;
   use_device(c->device);
-  if ((uint64_t)b->n_small * b->small_stride > b->row_limit) {
+  if (((uint64_t)b->n_small + b->n_dev_lines) * b->small_stride > b->row_limit) {
     // the half-wave kernel's rows have fixed places in the staging region at the top of the pool: they must all exist
     b->rows_used = 0;
     set_err(c, "grim_batch_run: output row pool smaller than the half-wave kernel's fixed region");
     return -2;
   }
-  b->ms_s = b->ms_a = b->ms_g = b->ms_m = b->ms_t = b->ms_c = b->ms_b = 0;
+  b->ms_s = b->ms_a = b->ms_g = b->ms_m = b->ms_t = b->ms_c = b->ms_b = b->ms_k = 0;
   std::lock_guard<std::mutex> lk(c->run_mu);
   if (bind_scratch(b) != 0) return -1;
   if (b->timing) {
@@ -1104,10 +1252,11 @@ int engine_batch_wait(grim_batch *b) {
   b->enqueued = false;
   HIPCHK(hipEventSynchronize(b->ev_done), c, -1);
   if (b->timing) {
-    if (b->n_small) HIPCHK(hipEventElapsedTime(&b->ms_s, b->ev[3], b->ev[5]), c, -1);
+    if (b->n_small || b->n_dev_lines) HIPCHK(hipEventElapsedTime(&b->ms_s, b->ev[3], b->ev[5]), c, -1);
     if (b->n_medium) HIPCHK(hipEventElapsedTime(&b->ms_m, b->ev[0], b->ev[1]), c, -1);
     if (b->n_general + b->n_medium) HIPCHK(hipEventElapsedTime(&b->ms_g, b->ev[6], b->ev[7]), c, -1);
-    if (b->n_small) HIPCHK(hipEventElapsedTime(&b->ms_c, b->ev[12], b->ev[13]), c, -1);
+    if (b->n_small || b->n_dev_lines) HIPCHK(hipEventElapsedTime(&b->ms_c, b->ev[12], b->ev[13]), c, -1);
+    if (b->n_dev_lines) HIPCHK(hipEventElapsedTime(&b->ms_k, b->ev[14], b->ev[15]), c, -1);
     b->ms_a = b->ms_s + b->ms_m + b->ms_g;
   }
   uint32_t head[GRIM_NQ];
@@ -1141,8 +1290,8 @@ int engine_batch_wait(grim_batch *b) {
     memcpy(head, b->hstate + GRIM_NCTR, 4 * GRIM_NQ);
   }
   if (b->timing) {
-    const double v[8] = {(double)b->ms_a + b->ms_b + b->ms_t + b->ms_c, b->ms_a, b->ms_b, b->ms_s, b->ms_g, b->ms_m, b->ms_t, b->ms_c};
-    for (int k = 0; k < 8; ++k) b->acc_ms[k] += v[k];
+    const double v[9] = {(double)b->ms_a + b->ms_b + b->ms_t + b->ms_c + b->ms_k, b->ms_a, b->ms_b, b->ms_s, b->ms_g, b->ms_m, b->ms_t, b->ms_c, b->ms_k};
+    for (int k = 0; k < 9; ++k) b->acc_ms[k] += v[k];
     b->n_timed++;
   }
   static const int dbg_classes = env_int("GRIM_DEBUG_CLASSES", 0);
@@ -1150,11 +1299,12 @@ int engine_batch_wait(grim_batch *b) {
     fprintf(stderr, "grim classes: small %u medium %u general %u | medium->general %u (+%u heavier), to plan B %u (+%u heavy) | table items %u one-wave, %u bigger (%u work units), %u pair records | stage 1 %s\n",
             b->n_small, b->n_medium, b->n_general, head[5], head[7], head[2], head[6], head[9], head[10], head[14], head[8], b->graph_state == 1 ? "replayed as a hipGraph" : "launched directly");
   memcpy(b->counters, b->hstate, 64);
-  b->small_ctr_pending = b->n_small > 0;
+  b->small_ctr_pending = b->n_small + b->n_dev_lines > 0;
   for (int sh = 0; sh < 64; ++sh)
     for (int k = 0; k < 3; ++k) b->counters[k] += b->hstate[8 + 4 * sh + k];
   b->rows_used = head[1];
   b->pool_asked = head[8];
+  b->n_irregular = head[GRIM_Q_IRREGULAR];
 #ifdef GRIM_STAMPS
   fprintf(stderr, "grim stamps (us):");
   for (int k = 0; k < 16; ++k) fprintf(stderr, " [%d]%.0f", k, b->hstate[GRIM_STAMP_BASE + k] / 100.0);
@@ -1204,7 +1354,7 @@ extern "C" double grim_batch_kernel_ms(const grim_batch *b, int which) {
   if (!b) return 0.0;
   if (which & 0x10) {  // mean over the timed runs since grim_batch_set_timing(b, 1)
     const int k = which & 0xF;
-    return (k < 8 && b->n_timed) ? b->acc_ms[k] / b->n_timed : 0.0;
+    return (k < 9 && b->n_timed) ? b->acc_ms[k] / b->n_timed : 0.0;
   }
   if (which == 1) return b->ms_a;
   if (which == 2) return b->ms_b;
@@ -1213,7 +1363,8 @@ extern "C" double grim_batch_kernel_ms(const grim_batch *b, int which) {
   if (which == 5) return b->ms_m;
   if (which == 6) return b->ms_t;
   if (which == 7) return b->ms_c;
-  return (double)b->ms_a + (double)b->ms_b + (double)b->ms_t + (double)b->ms_c;
+  if (which == 8) return b->ms_k;
+  return (double)b->ms_a + (double)b->ms_b + (double)b->ms_t + (double)b->ms_c + (double)b->ms_k;
 }
 
 extern "C" int grim_batch_counters(const grim_batch *cb, uint64_t out[4]) {
@@ -1304,7 +1455,7 @@ static void batch_destroy(grim_batch *b) {
   if (!b) return;
   use_device(b->ctx->device);
   hipStreamSynchronize(b->ctx->stream);
-  for (int i = 0; i < 14; ++i)
+  for (int i = 0; i < 16; ++i)
     if (b->ev[i]) hipEventDestroy(b->ev[i]);
   if (b->ev_done) hipEventDestroy(b->ev_done);
   if (b->gexec) hipGraphExecDestroy(b->gexec);

@@ -6,10 +6,12 @@
 
 #include "../../include/grim_hip.h"
 #include "grim_layout.h"
+#include "grim_tok.h"
 
 struct EnginePlan {   // what the next load holds at most
   uint32_t n_subj;    // subject records (= result headers)
   uint64_t tok_cap;   // u16 tokens
+  uint64_t text_cap;  // bytes of chunk text for the device tokenizer (0: the batch never runs it)
 };
 
 struct EngineHost {  // pinned host memory of a batch: inputs are written here, results land here
@@ -19,6 +21,8 @@ struct EngineHost {  // pinned host memory of a batch: inputs are written here, 
   uint32_t *order_s, *order_m, *order_g;
   grim_subject_result *res;  // valid after engine_batch_fetch
   grim_row *rows;
+  LineRec *lines;            // device tokenizer (EnginePlan.text_cap != 0): one record per line ...
+  uint8_t *text;             // ... and the chunk's text
 };
 
 struct EngineLoad {
@@ -27,6 +31,10 @@ struct EngineLoad {
   uint64_t tok_used;                      // tokens [0, tok_used) are copied
   uint32_t n_priors;                      // prior matrices [n_priors][P*P] at `priors` (host memory, copied when the
   const double *priors;                   // count differs from what the batch holds; the set only ever grows)
+  // device tokenizer: lines [dev_lo, dev_hi) of the n_subj line records are tokenised on the device (0, 0: none);
+  // text_bytes of chunk text go up with them
+  uint32_t dev_lo, dev_hi;
+  uint64_t text_bytes;
 };
 
 // row_limit: rows one run may produce (the row pool); plan: first layout
@@ -54,6 +62,15 @@ int engine_batch_fetch_async(grim_batch *b);
 // asks for it and returns grim_batch_run's code (0, -1, -2 = a pool overflowed)
 int engine_batch_enqueue(grim_batch *b);
 int engine_batch_wait(grim_batch *b);
+// device form of the allele dictionary (grim_tok.h), built once per stream from the frozen snapshot the host tokenizer
+// reads; batches that run the device tokenizer are given it with engine_batch_set_dict
+struct DictSnap;
+typedef struct grim_devdict grim_devdict;
+grim_devdict *engine_devdict_create(grim_ctx *ctx, const DictSnap *snap);
+void engine_devdict_free(grim_devdict *d);
+void engine_batch_set_dict(grim_batch *b, const grim_devdict *d);
+// lines the device tokenizer of the last run handed back to the host (status GRIM_ST_UNSUPPORTED, reason 7)
+uint32_t engine_batch_irregular(const grim_batch *b);
 uint64_t engine_batch_pool_want(const grim_batch *b);
 void engine_batch_hint_pool(grim_batch *b, uint64_t records);
 int engine_batch_grow_pool(grim_batch *b, uint64_t max_records);

@@ -469,7 +469,8 @@ void tokenize_range(const TokParams &prm, const char *text, uint64_t lo, uint64_
     uint32_t race = 0;
     grim_subject sj;
     uint64_t tok_before = R.n_tok;
-    bool tok_overflow = false;
+    bool tok_overflow = false, dev_line = false;
+    if (prm.line_dst) prm.line_dst[line_no] = LineRec{0, 0, 0};
     if (ns == 0 || ns == 2) {  // fewer than two fields, or exactly three: IndexError in the reference -> raw line
       kind = K_PROBLEM_RAW;
       li.id_len = (uint32_t)(ns ? s[0] : line.size());
@@ -503,7 +504,12 @@ void tokenize_range(const TokParams &prm, const char *text, uint64_t lo, uint64_
         sc.have_last = true;
       }
       const sv gl = ns >= 2 ? line.substr(s[0] + 1, s[1] - s[0] - 1) : line.substr(s[0] + 1);
-      if (R.dense) {
+      if (prm.line_dst && !R.dense && !gl.empty() && gl.size() <= GRIM_TOK_MAXGL && !memchr(gl.data(), '/', gl.size()) && race < 0xFFFFu) {
+        // no '/' list: the device tokenizer's line (grim_tokdev.h); what it cannot take comes back through tokenize_lines
+        prm.line_dst[line_no] = LineRec{(uint32_t)(gl.data() - text), (uint16_t)gl.size(), (uint16_t)race};
+        kind = K_DEV;
+        dev_line = true;
+      } else if (R.dense) {
         // worst case one token per two bytes
         if (tmp_tok.size() < gl.size() / 2 + 8) tmp_tok.resize(gl.size() / 2 + 8);
         uint64_t nt = 0;
@@ -525,7 +531,7 @@ void tokenize_range(const TokParams &prm, const char *text, uint64_t lo, uint64_
       }
     }
     if (kind == K_DEV || kind == K_MISS_NO_DEVICE || kind == K_PROBLEM_ID) {
-      if (prm.masks) {
+      if (prm.masks && !dev_line) {
         auto it = prm.masks->fixed.find(std::string(line.substr(0, li.id_len)));
         if (it == prm.masks->fixed.end()) {
           if (kind == K_DEV) {
@@ -539,7 +545,10 @@ void tokenize_range(const TokParams &prm, const char *text, uint64_t lo, uint64_
         }
       }
     }
-    if (kind == K_DEV) {
+    if (dev_line) {
+      ++R.n_subj;
+      ++R.n_devtok;
+    } else if (kind == K_DEV) {
       sj.prior_idx = (uint16_t)race;
       const uint32_t subject_no = R.dense ? R.n_subj : line_no;
       if (R.dense) {
@@ -572,6 +581,46 @@ void tokenize_range(const TokParams &prm, const char *text, uint64_t lo, uint64_
     ++line_no;
     a = next;
   }
+}
+
+void tokenize_lines(const TokParams &prm, const char *text, TokRange &R, const std::vector<uint32_t> &lines, const LineRec *lrec,
+                    std::vector<uint32_t> &os, std::vector<uint32_t> &om, std::vector<uint32_t> &og, std::vector<SmallRec> &small) {
+  const DictSnap &D = *prm.snap;
+  Scratch sc;
+  for (uint32_t j : lines) {
+    if (j >= R.kind.size() || R.kind[j] != K_DEV) continue;
+    const sv gl(text + lrec[j].gl_off, lrec[j].gl_len);
+    grim_subject sj;
+    bool tok_overflow = false;
+    const uint64_t before = R.n_tok;
+    int kind;
+    if (tokenise_gl_fast(D, gl, sj, R.tok_dst, R.tok_cap, R.n_tok))
+      kind = K_DEV;
+    else
+      kind = tokenise_gl(D, gl, prm.planb, sc, sj, R.tok_dst, R.tok_cap, R.n_tok, R.ov, R.ov_pool, j, tok_overflow);
+    R.kind[j] = (uint8_t)kind;
+    if (kind != K_DEV) {
+      if (R.n_subj) --R.n_subj;
+      continue;
+    }
+    sj.tok_off = (uint32_t)(R.tok_base + before);
+    sj.prior_idx = lrec[j].prior_idx;
+    R.subj_dst[j] = sj;
+    const uint32_t si = R.first_subject + j;
+    const int cls = prm.classify ? grim_classify(*prm.classify, sj) : GRIM_CLS_GENERAL;
+    if (cls == GRIM_CLS_SMALL) {
+      SmallRec rec;
+      grim_small_rec(sj, R.tok_dst + (sj.tok_off - R.tok_base), si, rec);
+      small.push_back(rec);
+      os.push_back(si);
+    } else if (cls == GRIM_CLS_MEDIUM) {
+      om.push_back(si);
+    } else {
+      og.push_back(si);
+    }
+  }
+  // the formatter finds a line's overlay alleles by binary search over the line numbers
+  std::stable_sort(R.ov.begin(), R.ov.end(), [](const OvEnt &a, const OvEnt &b) { return a.line < b.line; });
 }
 
 // ------------------------------------------------------------------------------------------------

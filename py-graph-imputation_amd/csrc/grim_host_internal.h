@@ -10,6 +10,7 @@
 
 #include "../../include/grim_hip.h"
 #include "grim_layout.h"
+#include "grim_tok.h"
 
 using sv = std::string_view;
 
@@ -160,6 +161,10 @@ struct TokParams {
   RaceResolver *races;
   const MaskTable *masks;     // or null
   const ClassRule *classify;  // or null: no class lists
+  // device tokenizer (slab mode only): line_dst[k] = the k-th line of the range.  A line whose GL field has no '/' list
+  // gets its record filled in and is left to the device (kind K_DEV, no subject record, no tokens, no class list entry);
+  // every other line gets gl_len = 0 and is tokenised here as usual.  null: everything is tokenised here.
+  LineRec *line_dst = nullptr;
 };
 
 struct TokRange {
@@ -177,6 +182,7 @@ struct TokRange {
   uint64_t tok_cap = 0, tok_base = 0;
   uint64_t n_tok = 0;
   uint32_t n_subj = 0;
+  uint32_t n_devtok = 0;  // lines left to the device tokenizer
   std::vector<OvEnt> ov;
   std::string ov_pool;
   bool race_overflow = false;  // more than 65534 distinct race pairs
@@ -187,12 +193,17 @@ struct TokRange {
   void clear() {
     kind.clear(); line.clear(); dev.clear(); subj.clear(); tok.clear(); ov.clear(); ov_pool.clear(); os.clear(); om.clear(); og.clear();
     small.clear();
-    n_tok = 0; n_subj = 0; race_overflow = false;
+    n_tok = 0; n_subj = 0; n_devtok = 0; race_overflow = false;
   }
 };
 
 // text[lo, hi) must consist of whole lines ('\n' terminated, except possibly the last one)
 void tokenize_range(const TokParams &prm, const char *text, uint64_t lo, uint64_t hi, TokRange &out);
+// Lines the device tokenizer handed back (numbers inside the range, ascending; slab mode): tokenised here after all, with
+// the range's own state -- subject records at subj_dst[line], tokens behind the range's, overlay alleles, kinds -- and
+// appended to the class lists given.  lrec: the range's line records (GL extent, prior index).
+void tokenize_lines(const TokParams &prm, const char *text, TokRange &R, const std::vector<uint32_t> &lines, const LineRec *lrec,
+                    std::vector<uint32_t> &os, std::vector<uint32_t> &om, std::vector<uint32_t> &og, std::vector<SmallRec> &small);
 
 // ---- formatter core ---------------------------------------------------------------------------------------------------
 struct OutBuf {

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_a_small_kernel(DevArgs A, c
   const DevGraph &g = A.g;
   const int hl = threadIdx.x & 31;            // lane inside the half wave = combination
   const uint32_t w = blockIdx.x * (GRIM_WG / 32) + (threadIdx.x >> 5);
-  const bool live = w < n;
+  bool live = w < n;
   const int n_ladder = A.prm.n_ladder;
   double lad[8];
 #pragma unroll
@@ -66,7 +66,8 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_a_small_kernel(DevArgs A, c
     // tok[k] = half k&1 of word k>>1; slot[l] = byte l of bytes 20..24; same = byte 25; prior = bytes 26..27
     same = (words[6] >> 8) & 0xFFu;
     si = words[7];
-    w_prior = A.priors[(uint64_t)(words[6] >> 16)];  // P == 1: the matrix is one number
+    live = si != GRIM_NONE;  // a record slot of the device tokenizer that holds no subject (grim_tokdev.h)
+    w_prior = live ? A.priors[(uint64_t)(words[6] >> 16)] : 0.0;  // P == 1: the matrix is one number
 #pragma unroll
     for (int l = 0; l < GRIM_MAXL; ++l) {
       const uint32_t tw = words[l];                       // tok[2l] | tok[2l+1] << 16
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_a_small_kernel(DevArgs A, c
       mykey |= (uint64_t)(t + 1u) << (GRIM_ABITS * slot);
     }
     uint32_t h = fht_hash(mykey) & g.fht_mask;
-    for (;;) {
+    for (; live;) {
       const FullEnt e = g.fht[h];
       if (e.key == mykey) { hit = true; f = e.f0; break; }
       if (e.key == 0) break;

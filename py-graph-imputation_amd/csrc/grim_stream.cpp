@@ -99,6 +99,7 @@ struct Chunk {
   const grim_row *rows = nullptr;
   double device_s = 0;
   uint32_t n_dev_subjects = 0;
+  uint32_t n_devtok = 0;  // lines left to the device tokenizer
   bool records_out = false, records_released = false;
 };
 
@@ -124,6 +125,8 @@ struct grim_stream {
   uint32_t n_pops = 0;
   uint32_t chunk_lines = 0, granule = 1024, n_threads = 1, depth = 0;
   uint64_t rows_per_chunk = 0;
+  grim_devdict *devdict = nullptr;  // device tokenizer: the dictionary on the device (null: every line is tokenised on the host)
+  bool dev_tok = false;
   std::atomic<uint64_t> pool_hint{0};  // pair-pool records a chunk of this stream needed: every later load starts there
   // input segments (grim_stream_segment): cumulative text bytes at the end of each, known once its chunks are committed
   uint32_t cur_segment = 0;
@@ -165,6 +168,7 @@ struct grim_stream {
   Clock::time_point t_open;
   grim_stream_stats st;
   std::atomic<uint64_t> tok_ns{0}, fmt_ns{0}, wr_ns{0};
+  std::atomic<uint64_t> handed_back{0};  // lines the device tokenizer gave back to the host's
 
   void fail(const std::string &m) {  // mu held
     if (!failed) {
@@ -201,6 +205,7 @@ static void assemble(grim_stream *s, Chunk *c) {
   c->og.clear();
   c->small.clear();
   c->n_dev_subjects = 0;
+  c->n_devtok = 0;
   bool race_overflow = false;
   for (uint32_t r = 0; r < c->n_ranges; ++r) {
     TokRange &T = c->tr[r];
@@ -209,6 +214,7 @@ static void assemble(grim_stream *s, Chunk *c) {
     c->om.insert(c->om.end(), T.om.begin(), T.om.end());
     c->og.insert(c->og.end(), T.og.begin(), T.og.end());
     c->n_dev_subjects += T.n_subj;
+    c->n_devtok += T.n_devtok;
     race_overflow = race_overflow || T.race_overflow;
   }
   if (s->opt.want_records) {
@@ -233,6 +239,10 @@ static void run_tokenize(grim_stream *s, Chunk *c, uint32_t r) {
   T.tok_cap = c->slab_cap[r];
   T.tok_base = c->slab_off[r];
   TokParams tp{&s->snap, s->prm.planb != 0, &s->races, s->have_masks ? &s->masks : nullptr, &s->rule};
+  if (s->dev_tok && H->lines && H->text) {
+    tp.line_dst = H->lines + c->range_first_line[r];
+    memcpy(H->text + c->cut[r], c->text.data() + c->cut[r], c->cut[r + 1] - c->cut[r]);  // the device reads the GL fields from here
+  }
   tokenize_range(tp, c->text.data(), c->cut[r], c->cut[r + 1], T);
   const uint32_t expect = c->range_first_line[r + 1] - c->range_first_line[r];
   if (T.kind.size() != expect) {
@@ -283,7 +293,12 @@ static int stage_part(grim_stream *s, Chunk *c, uint32_t lo, uint32_t hi, size_t
   {
     // the race table only grows: a batch that holds fewer matrices than the table has gets all of them again
     std::lock_guard<std::mutex> lk(s->races.mu);
-    EngineLoad ld{c->n_lines, (uint32_t)(s1 - s0), (uint32_t)(m1 - m0), ng, tok_used, s->races.n, s->races.mats.data()};
+    EngineLoad ld{c->n_lines, (uint32_t)(s1 - s0), (uint32_t)(m1 - m0), ng, tok_used, s->races.n, s->races.mats.data(), 0, 0, 0};
+    if (c->n_devtok) {  // the lines of [lo, hi) whose record says so are tokenised on the device
+      ld.dev_lo = lo;
+      ld.dev_hi = hi;
+      ld.text_bytes = c->text.size();
+    }
     static const double one = 1.0;
     if (!s->races.n) {  // no line had two parsable fields: nothing indexes a matrix, the engine still wants one
       ld.n_priors = 0;
@@ -306,6 +321,80 @@ static void part_stats(grim_stream *s, grim_batch *b, PartStats &ps) {
 
 // synchronous run of the subjects of lines [lo, hi) (copy thread: the second try of a chunk, or a part of it)
 static int device_part_sync(grim_stream *s, Chunk *c, uint32_t lo, uint32_t hi, bool whole, PartStats &ps);
+
+// The device tokenizer handed lines of [lo, hi) back (an allele the graph does not know, 'g' / 'L' characters, loci out of
+// order, ...: grim_tokdev.h).  The run's results are brought over as a PART of the chunk, the flagged lines go through the
+// host's tokenizer after all (tokenize_lines) and -- those that are subjects -- through the device as a second small run,
+// whose rows land behind the first run's.  Rare by construction; never a different answer, only a second pass.
+static int fixup_part(grim_stream *s, Chunk *c, uint32_t lo, uint32_t hi, PartStats &ps) {
+  grim_batch *b = c->batch;
+  const uint32_t nrows1 = grim_batch_total_rows(b);
+  const size_t base1 = c->extra_rows.size();
+  c->extra_rows.resize(base1 + nrows1);
+  if (engine_batch_fetch(b, lo, hi, nrows1 ? c->extra_rows.data() + base1 : nullptr) != 0) return -1;
+  const EngineHost *H = engine_batch_host(b);
+  grim_subject_result *res = H->res;
+  std::vector<uint32_t> fos, fom, fog;
+  std::vector<SmallRec> fsmall;
+  std::vector<uint8_t> fixed(hi - lo, 0);
+  TokParams tp{&s->snap, s->prm.planb != 0, &s->races, nullptr, &s->rule};
+  uint64_t n_back = 0;
+  for (uint32_t r = 0; r < c->n_ranges; ++r) {
+    const uint32_t f0 = c->range_first_line[r], f1 = c->range_first_line[r + 1];
+    if (f1 <= lo || f0 >= hi) continue;
+    std::vector<uint32_t> list;
+    for (uint32_t g = std::max(f0, lo); g < std::min(f1, hi); ++g)
+      if (H->lines[g].gl_len && c->tr[r].kind[g - f0] == K_DEV && res[g].status == GRIM_ST_UNSUPPORTED && res[g].reason == 7) {
+        list.push_back(g - f0);
+        fixed[g - lo] = 1;
+      }
+    if (list.empty()) continue;
+    n_back += list.size();
+    tokenize_lines(tp, c->text.data(), c->tr[r], list, H->lines + f0, fos, fom, fog, fsmall);
+    for (uint32_t j : list) {
+      H->lines[f0 + j].gl_len = 0;  // no longer the device tokenizer's
+      if (s->opt.want_records && f0 + j < c->kinds.size()) c->kinds[f0 + j] = c->tr[r].kind[j];
+    }
+  }
+  s->handed_back += n_back;
+  size_t base2 = c->extra_rows.size();
+  if (!fos.empty() || !fom.empty() || !fog.empty()) {
+    if (!fos.empty()) {
+      memcpy(H->small, fsmall.data(), sizeof(SmallRec) * fsmall.size());
+      memcpy(H->order_s, fos.data(), 4 * fos.size());
+    }
+    if (!fom.empty()) memcpy(H->order_m, fom.data(), 4 * fom.size());
+    if (!fog.empty()) memcpy(H->order_g, fog.data(), 4 * fog.size());
+    uint64_t tok_used = 0;
+    for (uint32_t r = 0; r < c->n_ranges; ++r)
+      if (c->tr[r].n_tok) tok_used = c->slab_off[r] + c->tr[r].n_tok;
+    int rc;
+    {
+      std::lock_guard<std::mutex> lk(s->races.mu);
+      EngineLoad ld{c->n_lines, (uint32_t)fos.size(), (uint32_t)fom.size(), (uint32_t)fog.size(), tok_used, s->races.n, s->races.mats.data(), 0, 0, 0};
+      rc = engine_batch_load(b, &ld);
+    }
+    if (rc == 0) rc = grim_batch_run(b);  // (grows the pair pool and runs again by itself when a subject needs it)
+    if (rc != 0) return -1;
+    part_stats(s, b, ps);
+    const uint32_t nrows2 = grim_batch_total_rows(b);
+    c->extra_rows.resize(base2 + nrows2);
+    // the headers again: the second run rewrote those of its subjects, the others still hold the first run's values
+    if (engine_batch_fetch(b, lo, hi, nrows2 ? c->extra_rows.data() + base2 : nullptr) != 0) return -1;
+    res = engine_batch_host(b)->res;
+  }
+  for (uint32_t r = 0; r < c->n_ranges; ++r) {
+    const uint32_t f0 = c->range_first_line[r], f1 = c->range_first_line[r + 1];
+    for (uint32_t g = std::max(f0, lo); g < std::min(f1, hi); ++g) {
+      if (c->tr[r].kind[g - f0] != K_DEV) continue;
+      const uint32_t off = (uint32_t)(fixed[g - lo] ? base2 : base1);
+      if (off)
+        for (int t = 0; t < GRIM_T_COUNT; ++t) res[g].row_off[t] += off;
+    }
+  }
+  c->fetch_pending = false;
+  return 0;
+}
 
 // after a run of [lo, hi) ended with `rc`: results stay on the device (whole chunk) or are fetched as a part; a pool that
 // overflowed sends the range through device_part_sync again
@@ -333,6 +422,7 @@ static int finish_part(grim_stream *s, Chunk *c, uint32_t lo, uint32_t hi, bool 
     while (want > cur && !s->pool_hint.compare_exchange_weak(cur, want)) {
     }
   }
+  if (engine_batch_irregular(b)) return fixup_part(s, c, lo, hi, ps);
   const uint32_t nrows = grim_batch_total_rows(b);
   if (whole) {
     c->fetch_pending = true;
@@ -342,12 +432,13 @@ static int finish_part(grim_stream *s, Chunk *c, uint32_t lo, uint32_t hi, bool 
     c->extra_rows.resize(base + nrows);
     if (engine_batch_fetch(b, lo, hi, nrows ? c->extra_rows.data() + base : nullptr) != 0) return -1;
     grim_subject_result *res = engine_batch_host(b)->res;
-    auto rebase = [&](uint32_t si) {
-      for (int t = 0; t < GRIM_T_COUNT; ++t) res[si].row_off[t] += (uint32_t)base;
-    };
-    for (size_t k = rng[0]; k < rng[1]; ++k) rebase(c->os[k]);
-    for (size_t k = rng[2]; k < rng[3]; ++k) rebase(c->om[k]);
-    for (uint32_t k = 0; k < ng; ++k) rebase(engine_batch_host(b)->order_g[k]);
+    if (base)  // every device subject of the lines [lo, hi): host- and device-tokenised alike
+      for (uint32_t r = 0; r < c->n_ranges; ++r) {
+        const uint32_t f0 = c->range_first_line[r], f1 = c->range_first_line[r + 1];
+        for (uint32_t g = std::max(f0, lo); g < std::min(f1, hi); ++g)
+          if (c->tr[r].kind[g - f0] == K_DEV)
+            for (int t = 0; t < GRIM_T_COUNT; ++t) res[g].row_off[t] += (uint32_t)base;
+      }
   }
   return 0;
 }
@@ -658,7 +749,7 @@ static int dispatch(grim_stream *s, Chunk *c) {
   if (c->tr.size() < R) c->tr.resize(R);
   while (c->fr.size() < R) c->fr.emplace_back(new FmtRange());
   if (c->file_off.size() < R) c->file_off.resize(R);
-  EnginePlan pl{n, tok_total};
+  EnginePlan pl{n, tok_total, s->dev_tok ? (uint64_t)c->text.size() : 0ull};
   if (engine_batch_plan(c->batch, &pl) != 0) {
     std::lock_guard<std::mutex> lk(s->mu);
     s->fail(std::string("laying out a chunk's buffers failed: ") + grim_last_error(s->ctx));
@@ -990,17 +1081,32 @@ extern "C" grim_stream *grim_stream_open(grim_ctx *ctx, const grim_graph *g, con
   if (rows < floor_rows && !(opts->rows_exact && opts->rows_per_chunk)) rows = floor_rows;
   if (rows > 0x7FFFFFF0ull) rows = 0x7FFFFFF0ull;
   s->rows_per_chunk = rows;
+  // Device tokenizer: lines without a '/' list are parsed on the GPU when their subjects are the half-wave kernel's (one
+  // population, five loci, no phase masks); GRIM_DEVICE_TOKENIZER=0 keeps every line on the host (tests hold the two together)
+  {
+    const char *e = getenv("GRIM_DEVICE_TOKENIZER");
+    s->dev_tok = s->rule.small_ok && !s->have_masks && s->snap.n_loci == GRIM_MAXL && !(e && atoi(e) == 0);
+    if (s->dev_tok) {
+      s->devdict = engine_devdict_create(ctx, &s->snap);
+      if (!s->devdict) {
+        delete s;
+        return nullptr;
+      }
+    }
+  }
   // the batches first: a stream that cannot get its device memory leaves the caller's files alone
-  EnginePlan plan0{s->chunk_lines, (uint64_t)s->chunk_lines * 48};
+  EnginePlan plan0{s->chunk_lines, (uint64_t)s->chunk_lines * 48, s->dev_tok ? (uint64_t)s->chunk_lines * 128 : 0ull};
   for (uint32_t i = 0; i < s->depth; ++i) {
     std::unique_ptr<Chunk> c(new Chunk());
     c->slot_no = (int)i;
     c->batch = engine_batch_create(ctx, g, prm, rows, &plan0);
     if (!c->batch) {
       for (auto &o : s->chunks) grim_batch_free(o->batch);
+      engine_devdict_free(s->devdict);
       delete s;
       return nullptr;
     }
+    engine_batch_set_dict(c->batch, s->devdict);
     if (opts->timing) grim_batch_set_timing(c->batch, 1);
     s->chunks.push_back(std::move(c));
   }
@@ -1025,6 +1131,7 @@ extern "C" grim_stream *grim_stream_open(grim_ctx *ctx, const grim_graph *g, con
           if (s->fd[j] >= 0) close(s->fd[j]);
         for (auto &pr : parked) rename(pr.first.c_str(), pr.second.c_str());  // the earlier run's results stay what they were
         for (auto &o : s->chunks) grim_batch_free(o->batch);
+        engine_devdict_free(s->devdict);
         delete s;
         return nullptr;
       }
@@ -1058,7 +1165,11 @@ extern "C" void grim_stream_free(grim_stream *s) {
   if (s->dev_thread.joinable()) s->dev_thread.join();
   if (s->copy_thread.joinable()) s->copy_thread.join();
   if (s->unlinker.joinable()) s->unlinker.join();
-  for (auto &c : s->chunks) engine_batch_recycle(c->batch);
+  for (auto &c : s->chunks) {
+    engine_batch_set_dict(c->batch, nullptr);
+    engine_batch_recycle(c->batch);  // (waits for the stream: nothing uses the dictionary any more)
+  }
+  engine_devdict_free(s->devdict);
   for (int k = 0; k < 6; ++k)
     if (s->fd[k] >= 0) close(s->fd[k]);
   for (int k = 0; k < 7; ++k)

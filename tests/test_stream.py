@@ -227,3 +227,64 @@ def test_config3_one_million_subjects_properties_and_oracle_slice():
     for key in ("umug", "umug_pops", "pmug", "pmug_pops"):
         mine = [l for l in got[key].splitlines() if l.split(",", 1)[0] in ids]
         assert mine == exp[key].splitlines(), key
+
+
+def test_device_tokenizer_equals_host_tokenizer(monkeypatch):
+    """GL strings parsed ON THE DEVICE (lines without a '/' list on a one-population graph: grim_tokdev.h) against the
+    host tokenizer (GRIM_DEVICE_TOKENIZER=0) and against the oracle: fully typed subjects with the fuzzer's mutations --
+    alleles the graph has never seen (overlay ids), 'g' / 'L' suffixes, UUUU loci, homozygous loci, missing loci, malformed
+    and truncated lines, '/' lists -- so that the device takes most lines, hands some back (the fix-up pass) and never sees
+    the rest.  Small chunks, ragged pieces, several ranges per chunk; then one big chunk; then records mode."""
+    import sys
+
+    from grim import _native as nat
+
+    sys.path.insert(0, os.path.join(harness.ROOT, "tools"))
+    import fuzz
+
+    rows = synth.read_freqs(synth.CAU_FREQS)
+    rng = np.random.default_rng(21)
+    gen = synth.SubjectGen(rows, 98)
+    lines = gen.full(5000) + gen.mixed(800, amb=0.3, miss=0.3, recomb=0.2)
+    lines = [fuzz.mutate(l, rng, gen.by_locus) if rng.random() < 0.25 else l for l in lines]
+    # loci out of sorted order (gl2haps sorts: same subject), a locus twice, a long allele name, '%' separators
+    swapped = []
+    for l in gen.full(40):
+        f = l.split(",")
+        loci = f[1].split("^")
+        loci[1], loci[3] = loci[3], loci[1]
+        swapped.append(",".join([f[0] + "s", "^".join(loci)] + f[2:]))
+    twice = [l.replace("^C*", "^A*", 1) for l in gen.full(10)]
+    longname = [l.replace("+", ":01:01:01:01:01:01:01+", 1) for l in gen.full(10)]
+    percent = [l.replace(",", "%") for l in gen.full(30)]
+    lines += swapped + twice + longname + percent
+    conf = harness.base_conf(["CAU"])
+    imp, cfg = _imp("cau", conf)
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GRIM_DEVICE_TOKENIZER", mode)
+        out[mode, "small"], st_small, unsup = _stream_texts(imp, cfg, lines, chunk_lines=700, n_threads=3, depth=3)
+        assert not unsup
+        out[mode, "big"], st_big, unsup = _stream_texts(imp, cfg, lines, n_threads=5)
+        assert not unsup
+    monkeypatch.delenv("GRIM_DEVICE_TOKENIZER", raising=False)
+    for k in nat.TEXT_KEYS:
+        assert out["1", "small"][k] == out["0", "small"][k], k
+        assert out["1", "big"][k] == out["0", "big"][k], k
+        assert out["1", "big"][k] == out["1", "small"][k], k
+    # against the oracle (without the lines that name a locus twice: the reference runs Plan C on them, this build sends
+    # them to .problem -- DESIGN section 7)
+    plain = [l for l in lines if l not in set(twice)]
+    got, _, unsup = _stream_texts(imp, cfg, plain, chunk_lines=900, n_threads=4)
+    exp, _ = harness.run_oracle("cau", conf, plain, tag="devtok_orc")
+    for k in exp:
+        assert got[k] == exp[k], k
+    # the device really took part: a stream of only regular lines has no host-tokenised subject at all
+    clean = gen.full(3000)
+    t1, st1, _ = _stream_texts(imp, cfg, clean, chunk_lines=1000, n_threads=2, timing=True)
+    monkeypatch.setenv("GRIM_DEVICE_TOKENIZER", "0")
+    t0, st0, _ = _stream_texts(imp, cfg, clean, chunk_lines=1000, n_threads=2, timing=True)
+    monkeypatch.delenv("GRIM_DEVICE_TOKENIZER", raising=False)
+    for k in nat.TEXT_KEYS:
+        assert t1[k] == t0[k], k
+    assert st1.bytes_h2d > 0 and st1.subjects == st0.subjects == 3000
