@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--cpu-workers", type=int, default=8, help="processes of the CPU baseline (cpu_baseline.cores)")
     ap.add_argument("--kernel-steps", type=int, default=50, help="runs of the resident-batch kernel loop (roofline)")
     ap.add_argument("--chunk-lines", type=int, default=0, help="lines per device batch of the stream (default: the whole step, at most %d)" % MAX_CHUNK)
+    ap.add_argument("--depth", type=int, default=8, help="device batches the stream keeps in flight (a step's latency through tokenizer, H2D, kernels, "
+                    "D2H and the consumer is several steps long: the depth, not the slowest stage, bounds the rate when it is too small)")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="the timed region of --steps steps is repeated until it has run this long in total; "
                     "ms_per_step is the MEDIAN region (min / max beside it)")
     ap.add_argument("--max-repeats", type=int, default=400)
@@ -177,7 +179,7 @@ def main():
     # short to measure on a shared box, so the region is repeated (same stream, pipeline drained in between) until the regions
     # add up to --min-seconds; the reported step time is the median region's, with the fastest and slowest beside it.
     st = nat.Stream(ctx, dgraph, graph.adict, params, ps, cfg["pops"], want_text=False, want_records=True,
-                    chunk_lines=chunk_lines, depth=4)
+                    chunk_lines=chunk_lines, depth=args.depth)
     chunks_per_step = n_step // chunk_lines
     import queue
     cmds = queue.Queue()
@@ -189,15 +191,17 @@ def main():
                 n = cmds.get()
                 if n is None:
                     break
-                for _ in range(n):
-                    st.write(text)
+                # one call per region (the way a file comes in: big blocks): the library cuts the text into steps of
+                # chunk_lines lines itself, and this thread does not compete for the interpreter with the consumer
+                st.write(region_text if n == args.steps else text * n)
             st.finish()
         except Exception as e:  # pragma: no cover
             feed_err.append(e)
 
+    region_text = text * args.steps
     th = threading.Thread(target=feed)
     th.start()
-    seen = {"lines": 0, "ok": 0, "rows": 0}
+    seen = {"lines": 0, "ok": 0}
 
     def drain(n_chunks):
         for _ in range(n_chunks):
@@ -206,8 +210,10 @@ def main():
                 raise RuntimeError("stream ended early: %r" % feed_err)
             first_line, kinds, res, rows_addr, handle = rec
             seen["lines"] += len(kinds)
-            seen["ok"] += int((res["status"][kinds == nat.K_DEVICE] == nat.ST_OK).sum())
-            seen["rows"] += int(res["n_rows"].sum()) if len(res) else 0
+            # the consumer reads every record's status (a byte view: the structured-field version of this line cost 80 us
+            # per 10 000 records and had become the slowest stage of the pipeline)
+            status = res.view(np.uint8).reshape(len(res), nat.RESULT_DT.itemsize)[:, 0]
+            seen["ok"] += int(np.count_nonzero((status == nat.ST_OK) & (kinds == nat.K_DEVICE)))
             st.release(handle)
 
     def agree_max(x):
@@ -228,7 +234,7 @@ def main():
 
     cmds.put(args.warmup)
     drain(args.warmup * chunks_per_step)
-    seen.update(lines=0, ok=0, rows=0)
+    seen.update(lines=0, ok=0)
     regions = [region()]
     n_ok_per_step = seen["ok"] // max(1, args.steps)
     repeats = int(min(args.max_repeats, max(3, -(-args.min_seconds // max(regions[0], 1e-9)))))  # the same on every rank
@@ -318,8 +324,8 @@ def main():
                 "graph_nodes": int(graph.arrays["n_nodes"]), "populations": P,
                 "timed_region": "host GL strings in memory -> grim_stream (tokenizer threads, pinned staging, H2D, kernels, D2H) -> "
                                 "result records in pinned host memory, read by the caller; %d device batch(es) of %d lines per step, "
-                                "4 in flight; value = subjects of one region of --steps steps / the MEDIAN region time over `repeats` "
-                                "back-to-back regions (barrier + drained pipeline on both sides of each)" % (chunks_per_step, chunk_lines),
+                                "%d in flight; value = subjects of one region of --steps steps / the MEDIAN region time over `repeats` "
+                                "back-to-back regions (barrier + drained pipeline on both sides of each)" % (chunks_per_step, chunk_lines, args.depth),
                 "host_threads": int(os.environ.get("GRIM_HOST_THREADS", "0")) or int(nat.host_lib().grim_default_threads()),
                 "stream_cpu_s": {"tokenize": sstats.tokenize_cpu_s, "device_thread_busy": sstats.device_s},
             },

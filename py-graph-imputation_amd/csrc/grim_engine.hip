@@ -240,6 +240,7 @@ struct grim_ctx {
   int device;
   hipStream_t stream;
   hipStream_t copy_stream;  // D2H of a finished batch while the next batch's kernels run (engine_batch_fetch_async)
+  hipStream_t up_stream;    // H2D of the next batch's input while this batch's kernels run (engine_batch_load)
   // Two threads of a stream use one context at the same time (device thread: loads and launches; copy thread: waits,
   // second stages, D2H), so the error text is written and read under its own lock; grim_last_error hands out a
   // per-thread copy.  Everything else a context owns is either immutable after grim_create or guarded by run_mu.
@@ -305,6 +306,8 @@ struct grim_batch {
   uint32_t n_medium;
   uint32_t n_small, n_general, small_stride;
   uint64_t scratch_need;  // bytes of per-workgroup scratch this batch's runs need (bound at run time)
+  hipEvent_t ev_copy;  // behind the D2H copy of engine_batch_fetch_issue
+  hipEvent_t ev_up;    // behind the H2D copy of engine_batch_load: the batch's kernels wait for it
   hipEvent_t ev_done;  // recorded behind the last kernel of a stage: what engine_batch_wait waits for (not the whole stream --
                        // the device thread may have queued the next chunk's kernels behind it already)
   bool enqueued;       // stage 1 is in flight (engine_batch_enqueue without its engine_batch_wait)
@@ -358,8 +361,10 @@ extern "C" grim_ctx *grim_create(int device_id) {
   grim_ctx *c = new grim_ctx();
   c->device = device_id;
   c->copy_stream = nullptr;
+  c->up_stream = nullptr;
   if (hipSetDevice(device_id) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess ||
-      hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+      hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking) != hipSuccess) {
     g_err = "grim_create: cannot initialise device";
     delete c;
     return nullptr;
@@ -382,6 +387,7 @@ extern "C" void grim_destroy(grim_ctx *c) {
   if (c->scratch) hipFree(c->scratch);
   hipStreamDestroy(c->stream);
   if (c->copy_stream) hipStreamDestroy(c->copy_stream);
+  if (c->up_stream) hipStreamDestroy(c->up_stream);
   delete c;
 }
 
@@ -722,6 +728,8 @@ grim_batch *engine_batch_create(grim_ctx *c, const grim_graph *g, const grim_par
     }
     for (int i = 0; i < 16 && ok; ++i) ok = hipEventCreate(&b->ev[i]) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&b->ev_done, hipEventDisableTiming | hipEventReleaseToSystem) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&b->ev_copy, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&b->ev_up, hipEventDisableTiming) == hipSuccess;
     if (!ok) {
       set_err(c, "grim_batch: device or pinned-host allocation failed");
       batch_destroy(b);
@@ -920,7 +928,11 @@ int engine_batch_load(grim_batch *b, const EngineLoad *ld) {
   // everything up to the last token in use; a load without host-tokenised subjects ends with the chunk's text
   const bool host_subjects = ld->n_small + ld->n_medium + ld->n_general > 0;
   const uint64_t bytes = (!host_subjects && b->n_dev_lines) ? b->off_subj : b->off_tok + 2 * ld->tok_used;
-  HIPCHK(hipMemcpyAsync(b->d_in, b->h_in, bytes, hipMemcpyHostToDevice, st), c, -1);
+  // the input goes up on the upload stream -- the copy of THIS batch overlaps the kernels of the batch before it -- and the
+  // launch stream waits for it (the batch's buffers are its own: nothing else orders the two streams)
+  HIPCHK(hipMemcpyAsync(b->d_in, b->h_in, bytes, hipMemcpyHostToDevice, c->up_stream), c, -1);
+  HIPCHK(hipEventRecord(b->ev_up, c->up_stream), c, -1);
+  HIPCHK(hipStreamWaitEvent(st, b->ev_up, 0), c, -1);
   g_moved[0] += bytes;
   {
     // arena of the table kernels: a pair pool of 512 records per subject that can reach them directly, a few for the
@@ -1397,7 +1409,25 @@ int engine_batch_fetch(grim_batch *b, uint32_t res_lo, uint32_t res_hi, grim_row
 // the whole batch's results over the context's copy stream: the caller has synchronised the kernels (grim_batch_run
 // returned) and may run the NEXT batch's kernels while this copy is in flight; any thread
 int engine_batch_fetch_async(grim_batch *b) { return b ? batch_fetch_on(b, 0, b->n_subj, nullptr, b->ctx->copy_stream) : -1; }
+// the same in two halves: the copy is queued on the copy stream with an event behind it (issue), another thread waits for
+// that event (wait) -- so the thread that watches the kernels is not held up by a PCIe transfer
+static int batch_fetch_on(grim_batch *b, uint32_t res_lo, uint32_t res_hi, grim_row *rows_dst, hipStream_t st, bool wait);
+int engine_batch_fetch_issue(grim_batch *b) {
+  if (!b) return -1;
+  if (batch_fetch_on(b, 0, b->n_subj, nullptr, b->ctx->copy_stream, false) != 0) return -1;
+  HIPCHK(hipEventRecord(b->ev_copy, b->ctx->copy_stream), b->ctx, -1);
+  return 0;
+}
+int engine_batch_fetch_wait(grim_batch *b) {
+  if (!b) return -1;
+  use_device(b->ctx->device);
+  HIPCHK(hipEventSynchronize(b->ev_copy), b->ctx, -1);
+  return 0;
+}
 static int batch_fetch_on(grim_batch *b, uint32_t res_lo, uint32_t res_hi, grim_row *rows_dst, hipStream_t st) {
+  return batch_fetch_on(b, res_lo, res_hi, rows_dst, st, true);
+}
+static int batch_fetch_on(grim_batch *b, uint32_t res_lo, uint32_t res_hi, grim_row *rows_dst, hipStream_t st, bool wait) {
   if (!b) return -1;
   grim_ctx *c = b->ctx;
   use_device(c->device);
@@ -1436,7 +1466,7 @@ static int batch_fetch_on(grim_batch *b, uint32_t res_lo, uint32_t res_hi, grim_
       g_moved[1] += sizeof(grim_row) * (uint64_t)b->rows_used;
     }
   }
-  HIPCHK(hipStreamSynchronize(st), c, -1);
+  if (wait) HIPCHK(hipStreamSynchronize(st), c, -1);
   return 0;
 }
 
@@ -1458,6 +1488,8 @@ static void batch_destroy(grim_batch *b) {
   for (int i = 0; i < 16; ++i)
     if (b->ev[i]) hipEventDestroy(b->ev[i]);
   if (b->ev_done) hipEventDestroy(b->ev_done);
+  if (b->ev_copy) hipEventDestroy(b->ev_copy);
+  if (b->ev_up) hipEventDestroy(b->ev_up);
   if (b->gexec) hipGraphExecDestroy(b->gexec);
   void *dev[] = {b->d_in, b->d_work, b->d_out, b->d_priors, b->d_pool};
   for (void *p : dev)

@@ -57,6 +57,9 @@ void engine_batch_recycle(grim_batch *b);
 // after a run that returned -2: 1 = the pair pool ran out and the next load will make it big enough (run the same subjects
 // again), 0 = split the batch
 int engine_batch_fetch_async(grim_batch *b);
+// ... in two halves: queue the copy (an event behind it) / wait for that event, possibly on another thread
+int engine_batch_fetch_issue(grim_batch *b);
+int engine_batch_fetch_wait(grim_batch *b);
 // a run in two halves (grim_batch_run = enqueue + wait): stage 1 is launched behind whatever the context's stream holds and
 // the call returns; engine_batch_wait (any thread, after enqueue returned) waits for it, runs stage 2 when the run state
 // asks for it and returns grim_batch_run's code (0, -1, -2 = a pool overflowed)

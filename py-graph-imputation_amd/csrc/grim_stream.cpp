@@ -147,9 +147,9 @@ struct grim_stream {
   std::atomic<bool> failed{false};
   std::string err;
   std::vector<std::thread> workers;
-  std::thread dev_thread, copy_thread;
-  std::deque<Chunk *> copy_q;
-  std::condition_variable cv_copy;
+  std::thread dev_thread, copy_thread, fetch_thread;
+  std::deque<Chunk *> copy_q, fetch_q;
+  std::condition_variable cv_copy, cv_fetch;
   uint64_t next_device = 0, next_commit = 0, next_record = 0, n_done = 0;
 
   int fd[6] = {-1, -1, -1, -1, -1, -1};
@@ -178,6 +178,7 @@ struct grim_stream {
     cv_work.notify_all();
     cv_dev.notify_all();
     cv_copy.notify_all();
+    cv_fetch.notify_all();
     cv_slot.notify_all();
     cv_rec.notify_all();
     cv_done.notify_all();
@@ -260,7 +261,7 @@ static void run_tokenize(grim_stream *s, Chunk *c, uint32_t r) {
 // brings the results over on the copy stream and hands the chunk to the formatter.  A chunk whose results overflow a pool
 // is run again by the copy thread, synchronously: the pair pool grown to what the run asked for, else in halves (a single
 // subject always fits: the row pool is never smaller than one subject's worst case).
-static std::atomic<uint64_t> g_dbg_ns[4];  // GRIM_DEBUG_STREAM: staging / load + launch (device thread), wait + stage 2 / fetch (copy thread)
+static std::atomic<uint64_t> g_dbg_ns[8];  // [4] reader: scan + copy + dispatch, [5] reader: waiting for a free chunk slot, [6] next_records: waiting  // GRIM_DEBUG_STREAM: staging / load + launch (device thread), wait + stage 2 / fetch (copy thread)
 
 struct PartStats {  // what a part's run adds to the stream's statistics (applied under the lock by the caller)
   double kernel_ms[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -401,7 +402,7 @@ static int fixup_part(grim_stream *s, Chunk *c, uint32_t lo, uint32_t hi, PartSt
 static int finish_part(grim_stream *s, Chunk *c, uint32_t lo, uint32_t hi, bool whole, int rc, const size_t (&rng)[4], uint32_t ng, PartStats &ps) {
   grim_batch *b = c->batch;
   part_stats(s, b, ps);
-  if (getenv("GRIM_DEBUG_STREAM"))
+  if (getenv("GRIM_DEBUG_STREAM") && atoi(getenv("GRIM_DEBUG_STREAM")) > 1)
     fprintf(stderr, "grim stream: chunk %llu lines [%u,%u) small %zu medium %zu general %u -> rc %d, rows %u (pool %llu)\n",
             (unsigned long long)c->index, lo, hi, rng[1] - rng[0], rng[3] - rng[2], ng, rc, grim_batch_total_rows(b), (unsigned long long)s->rows_per_chunk);
   if (rc == -2) {
@@ -545,11 +546,11 @@ static void copy_loop(grim_stream *s) {
     }
     const auto t1 = Clock::now();
     g_dbg_ns[2] += (uint64_t)(secs(t0, t1) * 1e9);
-    bool fetched_ok = true;
+    // the results come over on the copy stream; the fetch thread waits for them, this one goes back to watching kernels
+    bool issued = false, fetched_ok = true;
     if (rc == 0 && c->n_dev_subjects && c->fetch_pending && c->extra_rows.empty()) {
-      fetched_ok = engine_batch_fetch_async(c->batch) == 0;
-      if (fetched_ok) c->rows = engine_batch_host(c->batch)->rows;
-      g_dbg_ns[3] += (uint64_t)(secs(t1, Clock::now()) * 1e9);
+      fetched_ok = engine_batch_fetch_issue(c->batch) == 0;
+      issued = fetched_ok;
     }
     c->device_s = secs(c->t_dev0, Clock::now());
     {
@@ -562,6 +563,44 @@ static void copy_loop(grim_stream *s) {
         s->fail(std::string(rc != 0 ? "device stage failed: " : "device stage failed: copying the results to the host: ") + (e ? e : ""));
         return;
       }
+      if (issued) {
+        s->fetch_q.push_back(c);
+        s->cv_fetch.notify_all();
+      } else {
+        c->state = CH_DEVICE_DONE;
+      }
+    }
+    if (!issued) enqueue_format(s, c);
+  }
+}
+
+// the fetch thread: waits for a chunk's D2H copy and hands the chunk to the formatter
+static void fetch_loop(grim_stream *s) {
+  for (;;) {
+    Chunk *c = nullptr;
+    {
+      std::unique_lock<std::mutex> lk(s->mu);
+      for (;;) {
+        if (s->stop || s->failed) return;
+        if (!s->fetch_q.empty()) {
+          c = s->fetch_q.front();
+          s->fetch_q.pop_front();
+          break;
+        }
+        s->cv_fetch.wait(lk);
+      }
+    }
+    const auto t0 = Clock::now();
+    const bool ok = engine_batch_fetch_wait(c->batch) == 0;
+    g_dbg_ns[3] += (uint64_t)(secs(t0, Clock::now()) * 1e9);
+    {
+      std::lock_guard<std::mutex> lk(s->mu);
+      if (!ok) {
+        const char *e = grim_last_error(s->ctx);
+        s->fail(std::string("device stage failed: copying the results to the host: ") + (e ? e : ""));
+        return;
+      }
+      c->rows = engine_batch_host(c->batch)->rows;
       c->state = CH_DEVICE_DONE;
     }
     enqueue_format(s, c);
@@ -767,31 +806,100 @@ static int dispatch(grim_stream *s, Chunk *c) {
   return 0;
 }
 
+// The reader's line counter.  It only has to know where the chunk ends and where every `granule`-th line starts, so it counts
+// line ends 32 bytes at a time and looks at single bytes only in the few blocks where one of those events falls (a memchr
+// per line was 80 us of the reader's 125 us per 10 000-line chunk -- the stream's bottleneck once GL parsing had moved to the
+// device).  Returns the lines found (at most `want`); *used = bytes up to and including the last line end found, or len
+// when fewer than `want` were found.  have: lines the chunk holds already; base: offset of p[0] inside the chunk's text.
+struct LineScan {
+  uint32_t granule, chunk_lines;
+  std::vector<uint64_t> *marks;
+};
+static inline bool scan_event(const LineScan &L, uint32_t ln, uint64_t off_after) {  // line end number ln (1-based in the chunk)
+  if (ln % L.granule == 0 && ln < L.chunk_lines) L.marks->push_back(off_after);
+  return false;
+}
+static uint32_t scan_lines_scalar(const LineScan &L, const char *p, uint64_t len, uint32_t want, uint32_t have, uint64_t base, uint64_t *used) {
+  uint64_t b = 0;
+  uint32_t got = 0;
+  while (b < len && got < want) {
+    const char *nl = (const char *)memchr(p + b, '\n', len - b);
+    if (!nl) {
+      b = len;
+      break;
+    }
+    b = (uint64_t)(nl - p) + 1;
+    ++got;
+    scan_event(L, have + got, base + b);
+  }
+  *used = b;
+  return got;
+}
+#if defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("avx2,popcnt"))) static uint32_t scan_lines_avx2(const LineScan &L, const char *p, uint64_t len, uint32_t want, uint32_t have,
+                                                                        uint64_t base, uint64_t *used) {
+  const __m256i nlv = _mm256_set1_epi8('\n');
+  uint64_t i = 0;
+  uint32_t got = 0;
+  while (i + 32 <= len && got < want) {
+    const uint32_t m = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i *)(p + i)), nlv));
+    const uint32_t c = (uint32_t)_mm_popcnt_u32(m);
+    const uint32_t ln0 = have + got;                                   // line ends before this block
+    const uint32_t to_mark = L.granule - ln0 % L.granule;              // line ends until the next multiple of the granule
+    if (c < to_mark && got + c < want) {                               // no event in this block
+      got += c;
+      i += 32;
+      continue;
+    }
+    for (uint32_t mm = m; mm; mm &= mm - 1) {
+      const uint32_t k = (uint32_t)__builtin_ctz(mm);
+      ++got;
+      scan_event(L, have + got, base + i + k + 1);
+      if (got == want) {
+        *used = i + k + 1;
+        return got;
+      }
+    }
+    i += 32;
+  }
+  if (got < want && i < len) {
+    uint64_t u2 = 0;
+    got += scan_lines_scalar(L, p + i, len - i, want - got, have + got, base + i, &u2);
+    *used = i + u2;
+    return got;
+  }
+  *used = got < want ? len : i;
+  return got;
+}
+#endif
+static uint32_t scan_lines(const LineScan &L, const char *p, uint64_t len, uint32_t want, uint32_t have, uint64_t base, uint64_t *used) {
+#if defined(__x86_64__)
+  static const bool avx2 = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("popcnt");
+  if (avx2) return scan_lines_avx2(L, p, len, want, have, base, used);
+#endif
+  return scan_lines_scalar(L, p, len, want, have, base, used);
+}
+
 extern "C" int grim_stream_write(grim_stream *s, const char *text, uint64_t len) {
   if (!s || s->input_closed) return -1;
   uint64_t a = 0;
   while (a < len) {
+    const auto tr0 = Clock::now();
     if (!s->filling) {
       s->filling = acquire_chunk(s);
       if (!s->filling) return -1;
     }
+    const auto tr1 = Clock::now();
+    g_dbg_ns[5] += (uint64_t)(secs(tr0, tr1) * 1e9);
     Chunk *c = s->filling;
     // take whole lines until the chunk is full; a partial last line stays open (the next call continues it)
     const uint32_t want = s->chunk_lines - c->n_lines;
-    uint64_t b = a;
-    uint32_t got = 0;
     const uint64_t base = c->text.size();
-    while (b < len && got < want) {
-      const char *nl = (const char *)memchr(text + b, '\n', len - b);
-      if (!nl) {
-        b = len;
-        break;
-      }
-      b = (uint64_t)(nl - text) + 1;
-      ++got;
-      const uint32_t ln = c->n_lines + got;
-      if (ln % s->granule == 0 && ln < s->chunk_lines) c->mark_off.push_back(base + (b - a));
-    }
+    const LineScan L{s->granule, s->chunk_lines, &c->mark_off};
+    uint64_t used = 0;
+    const uint32_t got = scan_lines(L, text + a, len - a, want, c->n_lines, base, &used);
+    const uint64_t b = a + used;
     c->text.append(text + a, b - a);
     c->n_lines += got;
     a = b;
@@ -799,6 +907,7 @@ extern "C" int grim_stream_write(grim_stream *s, const char *text, uint64_t len)
       s->filling = nullptr;
       if (dispatch(s, c) != 0) return -1;
     }
+    g_dbg_ns[4] += (uint64_t)(secs(tr1, Clock::now()) * 1e9);
   }
   return s->failed ? -1 : 0;
 }
@@ -987,7 +1096,9 @@ extern "C" int grim_stream_next_records(grim_stream *s, grim_stream_records *out
       return 1;
     }
     if (s->input_closed && s->next_record >= s->next_index) return 0;
+    const auto tw0 = Clock::now();
     s->cv_rec.wait_for(lk, std::chrono::milliseconds(50));
+    g_dbg_ns[6] += (uint64_t)(secs(tw0, Clock::now()) * 1e9);
   }
 }
 
@@ -1145,25 +1256,29 @@ extern "C" grim_stream *grim_stream_open(grim_ctx *ctx, const grim_graph *g, con
   for (uint32_t i = 0; i < s->n_threads; ++i) s->workers.emplace_back(worker_loop, s);
   s->dev_thread = std::thread(device_loop, s);
   s->copy_thread = std::thread(copy_loop, s);
+  s->fetch_thread = std::thread(fetch_loop, s);
   return s;
 }
 
 extern "C" void grim_stream_free(grim_stream *s) {
   if (!s) return;
   if (getenv("GRIM_DEBUG_STREAM"))
-    fprintf(stderr, "grim stream: device thread ms: staging %.3f load %.3f | copy thread ms: wait + stage 2 %.3f fetch %.3f over %llu chunks\n", g_dbg_ns[0] / 1e6,
-            g_dbg_ns[1] / 1e6, g_dbg_ns[2] / 1e6, g_dbg_ns[3] / 1e6, (unsigned long long)s->st.chunks);
+    fprintf(stderr, "grim stream: device thread ms: staging %.3f load %.3f | copy thread ms: wait + stage 2 %.3f fetch %.3f | reader ms: work %.3f "
+            "waiting for a slot %.3f | consumer waiting %.3f over %llu chunks\n", g_dbg_ns[0] / 1e6, g_dbg_ns[1] / 1e6, g_dbg_ns[2] / 1e6,
+            g_dbg_ns[3] / 1e6, g_dbg_ns[4] / 1e6, g_dbg_ns[5] / 1e6, g_dbg_ns[6] / 1e6, (unsigned long long)s->st.chunks);
   {
     std::lock_guard<std::mutex> lk(s->mu);
     s->stop = true;
     s->cv_work.notify_all();
     s->cv_dev.notify_all();
     s->cv_copy.notify_all();
+    s->cv_fetch.notify_all();
     s->cv_slot.notify_all();
   }
   for (auto &t : s->workers) t.join();
   if (s->dev_thread.joinable()) s->dev_thread.join();
   if (s->copy_thread.joinable()) s->copy_thread.join();
+  if (s->fetch_thread.joinable()) s->fetch_thread.join();
   if (s->unlinker.joinable()) s->unlinker.join();
   for (auto &c : s->chunks) {
     engine_batch_set_dict(c->batch, nullptr);

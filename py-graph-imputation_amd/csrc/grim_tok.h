@@ -21,7 +21,7 @@ struct LineRec {       // one input line as the host's line splitter leaves it
 };                     // 8 bytes
 
 #define GRIM_TOKNAME 24  // allele names up to this many bytes are in the device dictionary (longer ones: host tokenizer)
-#define GRIM_TOK_MAXGL 160  // longest GL field the device tokenizer looks at
+#define GRIM_TOK_MAXGL 144  // longest GL field the device tokenizer looks at (a 160-byte window from the 16-byte boundary before it)
 
 struct DictEnt {       // one slot of a locus's open-addressing table: the name inline, so a probe is two 16-byte loads
   uint32_t w[6];       // name bytes packed BIG-endian, zero padded: comparing the words in order compares the strings

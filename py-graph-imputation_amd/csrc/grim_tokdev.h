@@ -44,29 +44,53 @@ __global__ __launch_bounds__(GRIM_WG) void grim_tokenize_kernel(DevArgs A, DevTo
   const bool active = in_grid && lr.gl_len != 0;
   bool bad = active && lr.gl_len > GRIM_TOK_MAXGL;
   const uint32_t n = (active && !bad) ? lr.gl_len : 0;
-  // ---- the shape of the GL field; where this lane's allele starts and ends ---------------------------------------
+  // ---- the GL field into LDS: the ten lanes of a line fetch 16 bytes each (one coalesced 160-byte window that starts at the
+  // 16-byte boundary before the field), and every later step reads bytes from there ---------------------------------------
+  __shared__ uint4 lbuf[GRIM_WG / 64][TOK_LINES_PER_WAVE + 1][TOK_LANES];
+  uint4 *mybuf = lbuf[wave_id()][lw < TOK_LINES_PER_WAVE ? lw : TOK_LINES_PER_WAVE];
+  const uint32_t a0 = lr.gl_off & ~15u, skip = lr.gl_off - a0, tot = n ? skip + n : 0;  // tot <= 15 + GRIM_TOK_MAXGL = 159
+  uint4 q = make_uint4(0, 0, 0, 0);
+  if (16u * (uint32_t)a < tot) q = ((const uint4 *)(T.text + a0))[a];
+  mybuf[a] = q;
+  // this lane's 16 bytes: where the separators are, which of them are '+', whether a character rules the line out
+  uint32_t m_sep = 0, m_plus = 0;
+  {
+    const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int bb = 0; bb < 16; ++bb) {
+      const uint32_t pos = 16u * (uint32_t)a + (uint32_t)bb;
+      const uint32_t c = (wd[bb >> 2] >> (8 * (bb & 3))) & 0xFFu;
+      const bool in = pos >= skip && pos < tot;
+      if (in && c == '+') m_plus |= 1u << bb;
+      if (in && (c == '+' || c == '^')) m_sep |= 1u << bb;
+      if (in && (c == '/' || c == 'g' || c == 'L')) bad = true;  // a '/' list (not the half-wave kernel's subject) / what clean_up_gl deletes
+    }
+  }
+  WAVE_SYNC();
+  // separator number a - 1 opens this lane's allele, separator number a closes it ("x+y" per position, '^' between
+  // positions: separator k must be '+' for even k, '^' for odd k; nine in all)
   uint32_t nsep = 0, start = 0, end = n;
   {
-    const uint32_t a0 = lr.gl_off & ~15u, skip = lr.gl_off - a0, tot = n ? skip + n : 0;
-    const uint4 *vp = (const uint4 *)(T.text + a0);
-    for (uint32_t v = 0; v * 16 < tot; ++v) {
-      const uint4 q = vp[v];
-      const uint32_t wd[4] = {q.x, q.y, q.z, q.w};
+    const int base0 = lw * TOK_LANES;
 #pragma unroll
-      for (int b = 0; b < 16; ++b) {
-        const uint32_t pos = v * 16 + (uint32_t)b;
-        if (pos < skip || pos >= tot) continue;
-        const uint32_t i = pos - skip;
-        const uint32_t c = (wd[b >> 2] >> (8 * (b & 3))) & 0xFFu;
-        if (c == '+' || c == '^') {
-          if (c != ((nsep & 1u) ? (uint32_t)'^' : (uint32_t)'+')) bad = true;  // "x+y" per position, '^' between positions
-          if (nsep == (uint32_t)a) end = i;
-          ++nsep;
-          if (nsep == (uint32_t)a) start = i + 1;
-        } else if (c == '/' || c == 'g' || c == 'L') {
-          bad = true;  // a '/' list (not the half-wave kernel's subject) / characters clean_up_gl deletes
-        }
+    for (int v = 0; v < TOK_LANES; ++v) {
+      const int src = base0 + v < 64 ? base0 + v : 0;
+      uint32_t mv = (uint32_t)__shfl((int)m_sep, src);
+      const uint32_t pv = (uint32_t)__shfl((int)m_plus, src);
+      const uint32_t c = (uint32_t)__popc(mv);
+      if (a > 0 && nsep < (uint32_t)a && nsep + c >= (uint32_t)a) {  // separator a - 1 is in this vector
+        uint32_t m2 = mv;
+        for (uint32_t k = nsep; k + 1 < (uint32_t)a; ++k) m2 &= m2 - 1;
+        start = 16u * (uint32_t)v + (uint32_t)__builtin_ctz(m2) + 1u - skip;
       }
+      if (nsep <= (uint32_t)a && nsep + c > (uint32_t)a) {  // separator a
+        uint32_t m2 = mv;
+        for (uint32_t k = nsep; k < (uint32_t)a; ++k) m2 &= m2 - 1;
+        const uint32_t bit = (uint32_t)__builtin_ctz(m2);
+        end = 16u * (uint32_t)v + bit - skip;
+        if (((pv >> bit) & 1u) != ((a & 1) == 0 ? 1u : 0u)) bad = true;
+      }
+      nsep += c;
     }
     if (n && nsep != TOK_LANES - 1) bad = true;  // fewer or more than five positions of two sides
   }
@@ -77,19 +101,21 @@ __global__ __launch_bounds__(GRIM_WG) void grim_tokenize_kernel(DevArgs A, DevTo
   uint32_t star = len;
   uint64_t locus = 0;
   if (active && !bad) {
-    const uint8_t *p = T.text + lr.gl_off + start;
-    for (uint32_t k = 0; k < len; ++k) {
-      const uint32_t c = p[k];
-      if (c == '*' && star == len) star = k;
-      const uint32_t sh = 24 - 8 * (k & 3);
+    const uint8_t *p = (const uint8_t *)mybuf + skip + start;
+    uint32_t cb[GRIM_TOKNAME];
 #pragma unroll
-      for (int i = 0; i < 6; ++i)
-        if ((int)(k >> 2) == i) w[i] |= c << sh;
-      if (star == len && k < 8) locus |= (uint64_t)c << (56 - 8 * k);
-    }
+    for (int k = 0; k < GRIM_TOKNAME; ++k) cb[k] = (uint32_t)k < len ? (uint32_t)p[k] : 0u;  // independent LDS byte reads
+#pragma unroll
+    for (int k = GRIM_TOKNAME - 1; k >= 0; --k)
+      if ((uint32_t)k < len && cb[k] == '*') star = (uint32_t)k;  // the first '*'
+#pragma unroll
+    for (int k = 0; k < GRIM_TOKNAME; ++k) w[k >> 2] |= cb[k] << (24 - 8 * (k & 3));
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if ((uint32_t)k < star) locus |= (uint64_t)cb[k] << (56 - 8 * k);
     if (star > 8) bad = true;  // a locus name longer than the table holds (or no '*' in a long name)
     // an entry that starts or ends with 'U' ("A*UUUU"): clean_up_gl drops the position (impute.py:110-117)
-    if (((a & 1) == 0 && p[0] == 'U') || ((a & 1) == 1 && p[len - 1] == 'U')) bad = true;
+    if (((a & 1) == 0 && cb[0] == 'U') || ((a & 1) == 1 && p[len - 1] == 'U')) bad = true;
   }
   int slot = -1;
   if (active && !bad) {
