@@ -337,6 +337,11 @@ int grim_stream_write_file(grim_stream *s, const char *path);
 int grim_stream_segment(grim_stream *s, uint64_t next_line_offset);
 uint32_t grim_stream_n_segments(const grim_stream *s);
 int grim_stream_segment_end(const grim_stream *s, uint32_t k, uint64_t out[7]);
+/* byte offsets of every chunk_lines-th line start of a file, the file size last (universal newlines, as
+ * grim_stream_write_text; what scripts/runfile_mp.py:113-124 does with `split -l`, without writing the pieces): the number of
+ * entries or -1; *out is the library's, released with grim_free */
+int64_t grim_chunk_offsets(const char *path, uint32_t chunk_lines, uint64_t **out);
+void grim_free(void *p);
 /* worker threads a stream starts when opts.n_threads is 0: cores of this process's affinity mask / ranks on this host
  * (LOCAL_WORLD_SIZE, else WORLD_SIZE), at most 32 */
 uint32_t grim_default_threads(void);

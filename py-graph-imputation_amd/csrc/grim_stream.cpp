@@ -881,6 +881,89 @@ static uint32_t scan_lines(const LineScan &L, const char *p, uint64_t len, uint3
   return scan_lines_scalar(L, p, len, want, have, base, used);
 }
 
+// Byte offsets of every chunk_lines-th line start of a file (and the file's size as the last entry): what a rank of
+// grim/shard.py needs to pull "chunk c" of the input as a byte range.  Lines end as grim_stream_write_text ends them
+// (universal newlines: "\n", "\r\n", a lone "\r"); a last line without its line end counts.  Returns the number of
+// entries (>= 1), or -1 (errno says why); *out is malloc'd, the caller frees it with grim_free.
+extern "C" int64_t grim_chunk_offsets(const char *path, uint32_t chunk_lines, uint64_t **out) {
+  if (!path || !out || chunk_lines == 0) return -1;
+  *out = nullptr;
+  const int fd = open(path, O_RDONLY);
+  if (fd < 0) return -1;
+  struct stat sb;
+  if (fstat(fd, &sb) != 0) {
+    close(fd);
+    return -1;
+  }
+  const uint64_t size = (uint64_t)sb.st_size;
+  std::vector<uint64_t> offs;
+  offs.push_back(0);
+  if (size) {
+    std::vector<char> buf(16u << 20);
+    uint64_t pos = 0;
+    uint32_t have = 0;  // line ends so far, modulo chunk_lines
+    bool pending_cr = false;  // the last byte of the previous block was a '\r' that may be the first half of "\r\n"
+    const LineScan L{chunk_lines, 0xFFFFFFFFu, &offs};
+    for (;;) {
+      const ssize_t n = read(fd, buf.data(), buf.size());
+      if (n < 0) {
+        if (errno == EINTR) continue;
+        close(fd);
+        return -1;
+      }
+      if (n == 0) break;
+      char *p = buf.data();
+      const uint64_t m = (uint64_t)n;
+      if (!pending_cr && !memchr(p, '\r', m)) {  // the usual file: '\n' only -- the vector scan
+        uint64_t done = 0;
+        while (done < m) {
+          uint64_t used = 0;
+          const uint32_t got = scan_lines(L, p + done, m - done, 0x40000000u, have, pos + done, &used);
+          have = (have + got) % chunk_lines;
+          done += used;
+          if (got < 0x40000000u) break;
+        }
+      } else {
+        for (uint64_t i = 0; i < m; ++i) {
+          const char ch = p[i];
+          bool end = false;
+          if (pending_cr) {  // the '\r' before this byte: a line end of its own unless this is its '\n'
+            pending_cr = false;
+            if (ch == '\n') {
+              end = true;  // "\r\n": one line end, after the '\n'
+            } else {
+              have = (have + 1) % chunk_lines;
+              if (have == 0) offs.push_back(pos + i);
+            }
+          }
+          if (!end) {
+            if (ch == '\n') end = true;
+            else if (ch == '\r') pending_cr = true;
+          }
+          if (end) {
+            have = (have + 1) % chunk_lines;
+            if (have == 0) offs.push_back(pos + i + 1);
+          }
+        }
+      }
+      pos += m;
+    }
+    if (pending_cr) {
+      have = (have + 1) % chunk_lines;
+      if (have == 0) offs.push_back(pos);
+    }
+    if (offs.back() >= size && offs.size() > 1) offs.pop_back();
+    offs.push_back(size);
+  }
+  close(fd);
+  uint64_t *r = (uint64_t *)malloc(sizeof(uint64_t) * offs.size());
+  if (!r) return -1;
+  memcpy(r, offs.data(), sizeof(uint64_t) * offs.size());
+  *out = r;
+  return (int64_t)offs.size();
+}
+extern "C" void grim_free(void *p) { free(p); }
+
 extern "C" int grim_stream_write(grim_stream *s, const char *text, uint64_t len) {
   if (!s || s->input_closed) return -1;
   uint64_t a = 0;

@@ -307,7 +307,7 @@ EXPORTS += [
     "grim_parsed_allele", "grim_prior_matrix", "grim_stream_open", "grim_stream_write", "grim_stream_write_file", "grim_stream_finish",
     "grim_stream_error", "grim_stream_text", "grim_stream_get_stats", "grim_stream_n_unsupported", "grim_stream_unsupported",
     "grim_stream_next_records", "grim_stream_release_records", "grim_stream_free", "grim_stream_write_text",
-    "grim_stream_segment", "grim_stream_n_segments", "grim_stream_segment_end", "grim_default_threads",
+    "grim_stream_segment", "grim_stream_n_segments", "grim_stream_segment_end", "grim_default_threads", "grim_chunk_offsets", "grim_free",
 ]
 
 
@@ -437,6 +437,9 @@ def host_lib():
     L.grim_stream_segment_end.restype = C.c_int
     L.grim_stream_segment_end.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]
     L.grim_default_threads.restype = C.c_uint32
+    L.grim_chunk_offsets.restype = C.c_int64
+    L.grim_chunk_offsets.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.POINTER(C.c_uint64))]
+    L.grim_free.argtypes = [C.c_void_p]
     _host_ready = True
     return L
 
@@ -573,6 +576,19 @@ class Parsed:
             self.close()
         except Exception:
             pass
+
+
+def chunk_offsets(path, chunk_lines):
+    """grim_chunk_offsets: byte offsets of every chunk_lines-th line start of the file, the file size last"""
+    L = host_lib()
+    out = C.POINTER(C.c_uint64)()
+    n = L.grim_chunk_offsets(os.fsencode(path), int(chunk_lines), C.byref(out))
+    if n < 0:
+        raise OSError("grim_chunk_offsets(%s) failed" % path)
+    try:
+        return [int(out[i]) for i in range(n)]
+    finally:
+        L.grim_free(out)
 
 
 def format_double(x):

@@ -49,40 +49,11 @@ def merge_texts(per_rank):
 def chunk_offsets(path, chunk_lines):
     """byte offset of every chunk_lines-th line start of the file, plus the file size: chunk c = bytes [off[c], off[c+1]).
     Lines end the way Python's universal-newline open() -- and the library's grim_stream_write_text -- ends them: at "\\n",
-    at "\\r\\n" (one end, after the "\\n") and at a lone "\\r".  A last line without its line end counts as a line."""
-    import numpy as np
+    at "\\r\\n" (one end, after the "\\n") and at a lone "\\r".  A last line without its line end counts as a line.
+    (The library scans the file: grim_chunk_offsets, csrc/grim_stream.cpp.)"""
+    from . import _native as nat
 
-    size = os.path.getsize(path)
-    if size == 0:
-        return [0]
-    offs = [0]
-    seen = 0  # line ends before the current block
-    with open(path, "rb") as fh:
-        pos = 0
-        block = fh.read(1 << 24)
-        while block:
-            nxt = fh.read(1 << 24)
-            a = np.frombuffer(block, dtype=np.uint8)
-            is_nl = a == 10
-            is_cr = a == 13
-            if is_cr.any():
-                follow = np.empty(len(a), dtype=bool)  # the byte after position i is "\n"
-                follow[:-1] = is_nl[1:]
-                follow[-1] = bool(nxt) and nxt[0] == 10
-                ends = np.flatnonzero(is_nl | (is_cr & ~follow))
-            else:
-                ends = np.flatnonzero(is_nl)
-            k = chunk_lines - (seen % chunk_lines) - 1  # index (inside ends) of the line end that closes the current chunk
-            while k < len(ends):
-                offs.append(pos + int(ends[k]) + 1)
-                k += chunk_lines
-            seen += len(ends)
-            pos += len(block)
-            block = nxt
-    if offs[-1] >= size and len(offs) > 1:
-        offs.pop()
-    offs.append(size)
-    return offs
+    return nat.chunk_offsets(path, chunk_lines)
 
 
 class _Control:
@@ -252,21 +223,22 @@ class _ComputeSink:
                 pass
 
 
-def _copy_range(src_fd, dst_fd, off, n):
-    """n bytes of src from offset off, appended to dst: copy_file_range where the kernel offers it, sendfile / read-write else"""
+def _copy_range(src_fd, dst_fd, off, n, dst_off):
+    """n bytes of src from offset off to dst at offset dst_off: copy_file_range where the kernel offers it (the bytes never
+    enter this process), pread / pwrite otherwise"""
     while n > 0:
         try:
-            k = os.copy_file_range(src_fd, dst_fd, n, offset_src=off)
+            k = os.copy_file_range(src_fd, dst_fd, n, offset_src=off, offset_dst=dst_off)
         except (AttributeError, OSError):
             k = -1
         if k <= 0:
-            os.lseek(src_fd, off, os.SEEK_SET)
-            buf = os.read(src_fd, min(n, 1 << 24))
+            buf = os.pread(src_fd, min(n, 1 << 24), off)
             if not buf:
                 raise IOError("part file shorter than its manifest says")
-            os.write(dst_fd, buf)
+            os.pwrite(dst_fd, buf, dst_off)
             k = len(buf)
         off += k
+        dst_off += k
         n -= k
 
 
@@ -286,6 +258,7 @@ def impute_sharded(conf_file, hap_pop_pair=False, graph=None, compute=None, proj
     error = None
     sink = None
     parts_dir = None
+    alone = ctl.world == 1  # nothing to merge: the one rank's part files ARE the outputs
     # the job's id: unique per call and per job, published by rank 0 -- a parts directory left behind by a run that died
     # can never be taken for this run's (and the manifests, not a directory listing, say what gets merged)
     tag = ctl.share("grim_job_%d" % _next_call(), lambda: uuid.uuid4().hex[:12])
@@ -293,13 +266,16 @@ def impute_sharded(conf_file, hap_pop_pair=False, graph=None, compute=None, proj
         config, out_dir = load_config(conf_file, project_dir_graph, project_dir_in_file)
         in_path = config["imputation_input_file"]
         flags = {k: (names[k][1] is None or bool(config[names[k][1]])) for k in OUTPUT_KEYS}
-        parts_dir = os.path.join(out_dir, ".grim_parts_" + tag)
         if ctl.rank == 0:
             pathlib.Path(out_dir).mkdir(parents=False, exist_ok=True)
-        pathlib.Path(parts_dir).mkdir(parents=True, exist_ok=True)
+        if alone:
+            part_paths = {k: config[names[k][0]] for k in OUTPUT_KEYS}
+        else:
+            parts_dir = os.path.join(out_dir, ".grim_parts_" + tag)
+            pathlib.Path(parts_dir).mkdir(parents=True, exist_ok=True)
+            part_paths = {k: os.path.join(parts_dir, "%s.rank%d" % (k, ctl.rank)) for k in OUTPUT_KEYS}
         offs = chunk_offsets(in_path, chunk_lines)
         n_chunks = len(offs) - 1
-        part_paths = {k: os.path.join(parts_dir, "%s.rank%d" % (k, ctl.rank)) for k in OUTPUT_KEYS}
         if compute is None:
             from .imputation.networkx_graph import Graph
             from . import _native as nat
@@ -327,8 +303,9 @@ def impute_sharded(conf_file, hap_pop_pair=False, graph=None, compute=None, proj
             ends = ends[1:]
         if len(ends) != len(mine):
             raise RuntimeError("internal: %d segments for %d chunks" % (len(ends), len(mine)))
-        with open(os.path.join(parts_dir, "manifest.rank%d.json" % ctl.rank), "w") as fh:
-            json.dump({"chunks": mine, "ends": ends}, fh)
+        if not alone:
+            with open(os.path.join(parts_dir, "manifest.rank%d.json" % ctl.rank), "w") as fh:
+                json.dump({"chunks": mine, "ends": ends}, fh)
     except BaseException as e:  # the other ranks must not wait for this one forever: report, reach the barrier, raise
         error = e
         if sink is not None:
@@ -341,8 +318,11 @@ def impute_sharded(conf_file, hap_pop_pair=False, graph=None, compute=None, proj
             raise error
         if failed:
             raise RuntimeError("impute_sharded: rank(s) %s failed:\n%s" % ([r for r, _ in failed], failed[0][1]))
-        if ctl.rank == 0:
-            where = {}  # chunk -> (rank, start offsets, end offsets)
+        if not alone:
+            # every rank reads every manifest: where chunk c's piece of every output sits in its rank's part file, hence
+            # where it belongs in the final file (the sizes of the chunks before it) -- and moves ITS OWN pieces there, so the
+            # merge is as parallel as the job.  Rank 0 creates the files at their final size first.
+            where = {}  # chunk -> (rank, start offsets in the part file, end offsets)
             for r in range(ctl.world):
                 with open(os.path.join(parts_dir, "manifest.rank%d.json" % r)) as fh:
                     m = json.load(fh)
@@ -353,34 +333,50 @@ def impute_sharded(conf_file, hap_pop_pair=False, graph=None, compute=None, proj
             missing = [c for c in range(n_chunks) if c not in where]
             if missing:
                 raise RuntimeError("impute_sharded: no rank reported chunk(s) %s" % missing[:8])
-            result = {}
+            final_off = [[0] * 6]  # final_off[c][k]: where chunk c's piece of output k starts in the final file
+            for c in range(n_chunks):
+                r, a, e = where[c]
+                final_off.append([final_off[-1][k] + e[k] - a[k] for k in range(6)])
+            if ctl.rank == 0:
+                for ki, k in enumerate(OUTPUT_KEYS):
+                    if flags[k]:
+                        fd = os.open(config[names[k][0]], os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+                        try:
+                            os.ftruncate(fd, final_off[n_chunks][ki])
+                        finally:
+                            os.close(fd)
+            ctl.barrier()
             for ki, k in enumerate(OUTPUT_KEYS):
+                if not flags[k]:
+                    continue
+                pieces = [(c, where[c]) for c in range(n_chunks) if where[c][0] == ctl.rank and where[c][2][ki] > where[c][1][ki]]
+                if not pieces:
+                    continue
+                src = os.open(os.path.join(parts_dir, "%s.rank%d" % (k, ctl.rank)), os.O_RDONLY)
+                dst = os.open(config[names[k][0]], os.O_WRONLY)
+                try:
+                    for c, (r, a, e) in pieces:
+                        _copy_range(src, dst, a[ki], e[ki] - a[ki], final_off[c][ki])
+                finally:
+                    os.close(src)
+                    os.close(dst)
+        if ctl.rank == 0:
+            result = {}
+            for k in OUTPUT_KEYS:
                 path_key, _ = names[k]
                 if not flags[k]:
                     result[k] = "" if return_texts else None
-                    continue
-                src = {}
-                dst = os.open(config[path_key], os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
-                try:
-                    for c in range(n_chunks):  # `cat` of the chunks' pieces in chunk order
-                        r, a, e = where[c]
-                        if e[ki] > a[ki]:
-                            if r not in src:
-                                src[r] = os.open(os.path.join(parts_dir, "%s.rank%d" % (k, r)), os.O_RDONLY)
-                            _copy_range(src[r], dst, a[ki], e[ki] - a[ki])
-                finally:
-                    os.close(dst)
-                    for fd in src.values():
-                        os.close(fd)
-                if return_texts:
-                    with open(config[path_key]) as fh:
-                        result[k] = fh.read()
-                else:
+                elif not return_texts:
                     result[k] = config[path_key]
     finally:
-        ctl.barrier()  # nobody removes the parts before rank 0 is through with them
+        ctl.barrier()  # nobody removes the parts before every rank is through with them
         if ctl.rank == 0 and parts_dir is not None:
             shutil.rmtree(parts_dir, ignore_errors=True)
+    if ctl.rank == 0 and return_texts and result is not None:
+        for k in OUTPUT_KEYS:
+            if flags[k]:
+                with open(config[names[k][0]]) as fh:
+                    result[k] = fh.read()
     return result
 
 

@@ -161,3 +161,37 @@ def test_a_failing_rank_does_not_hang_the_others(tmp_path):
     e0, e1 = open(out + ".err0").read(), open(out + ".err1").read()
     assert "rank(s) [1] failed" in e0 and "boom on rank 1" in e0
     assert e1.startswith("ValueError: boom on rank 1")
+
+
+def test_alone_writes_the_final_files_directly():
+    """no process group: one rank pulls every chunk and its part files ARE the outputs (no parts directory, no merge)"""
+    import grim_oracle as go
+    from grim import shard
+
+    rows = synth.read_freqs(synth.CAU_FREQS)
+    lines = synth.SubjectGen(rows, 82).mixed(25) + synth.edge_cases("CAU")[:5]
+    work = harness.ensure_graph("cau")
+    conf = harness.base_conf(["CAU"])
+    conf, cpath = harness._write_inputs(work, conf, lines, "mr1")
+    cwd = os.getcwd()
+    os.chdir(work)
+    try:
+        def compute(cfg, chunk, offset):
+            ocfg = go.config_from_json(json.load(open(cpath)))
+            g = go.OGraph(ocfg["full_loci"]).load(ocfg["node_file"], ocfg["top_links_file"], ocfg["edges_file"])
+            texts = go.OracleImputer(g, ocfg).impute_lines(["PAD,,X,X"] * offset + [l.rstrip("\n") for l in chunk])
+            texts["problem"] = "".join(l for l in texts["problem"].splitlines(True) if not l.endswith(",PAD\n"))
+            return texts
+
+        env_world = os.environ.pop("WORLD_SIZE", None)
+        try:
+            merged = shard.impute_sharded(cpath, compute=compute, chunk_lines=7, return_texts=True)
+        finally:
+            if env_world is not None:
+                os.environ["WORLD_SIZE"] = env_world
+    finally:
+        os.chdir(cwd)
+    single, _ = harness.run_oracle("cau", conf, lines, tag="mr1_single")
+    for k in single:
+        assert merged[k] == single[k], k
+    assert not [f for f in os.listdir(os.path.join(work, "output_mr1")) if f.startswith(".grim_parts")]
