@@ -26,6 +26,9 @@ extern "C" {
 
 #define GRIM_MAXL 5        /* loci per haplotype (A,B,C,DQB1,DRB1)                         */
 #define GRIM_ABITS 12      /* bits per locus in a 64-bit haplotype key: (allele_id+1)<<12*slot */
+#define GRIM_KEY_GRAPH_ORDER 60 /* bit of a haplotype key in a result row: the haplotype is a graph node's NAME (alleles in
+                                  loci_map index order), not a joined key (alleles sorted); matters to the phased writer only,
+                                  and only under a loci_map that is not alphabetical */
 #define GRIM_MAXPH 16      /* 2^(GRIM_MAXL-1) phases (impute.py:274-303)                     */
 #define GRIM_MAXPOP 64     /* populations                                                    */
 #define GRIM_TOPCAP 128    /* upper bound for max_haplotypes_number_in_phase (impute.py:436) */
@@ -68,6 +71,12 @@ typedef struct {
   uint64_t n_b_nbr;
   const uint32_t *lab_start; /* [(1<<GRIM_MAXL)+1] */
   const uint32_t *lab_nodes; /* [n_nodes] */
+  /* bit m set: a haplotype NAME over the loci of label mask m built from a subject's alleles never equals a graph name --
+   * the subject's alleles come in sorted STRING order (gl2haps, impute.py:271), graph names in loci_map index order
+   * (generate_neo4j_multi_hpf.py:59-68), and for this locus set the two orders differ (a loci_map that is not alphabetical,
+   * e.g. the reference's own default A 1, B 3, C 2: every set that holds both B and C).  0: the two orders agree everywhere. */
+  uint32_t label_order_bad;
+  uint32_t reserved;
 } grim_graph_desc;
 
 grim_graph *grim_graph_upload(grim_ctx *ctx, const grim_graph_desc *desc);

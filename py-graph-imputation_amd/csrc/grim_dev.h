@@ -50,6 +50,8 @@ struct DevGraph {
   const HtEnt *ht;  // exact-name index: one 16-byte entry per slot, key == 0 marks an empty slot
   uint32_t n_nodes, P, full_mask, ht_mask, n_conn, n_loci;
   uint32_t scan_ok;  // names unique and every top-link row shorter than 2^22: the intersection opening may be used
+  uint32_t order_bad;  // bit m: a name over label mask m built from a SUBJECT's alleles (sorted string order, impute.py:271)
+                       // is never a graph name (loci_map index order) -- a loci_map that is not alphabetical; 0 as a rule
 };
 
 // ---- per-workgroup scratch slot in HBM (offsets in bytes, filled by the host) -------------------
@@ -256,6 +258,13 @@ __device__ __forceinline__ uint32_t graph_lookup_from(const DevGraph &g, uint64_
 
 __device__ __forceinline__ uint32_t graph_lookup(const DevGraph &g, uint64_t key) {
   return graph_lookup_from(g, key, (uint32_t)mix64(key) & g.ht_mask);
+}
+
+// look-up of a name made of a subject's alleles in the subject's (sorted) order over the loci of `mask`: a miss when that
+// order is not the graph's for this set of loci (DevGraph::order_bad)
+__device__ __forceinline__ bool subject_order_ok(const DevGraph &g, uint32_t mask) { return !((g.order_bad >> mask) & 1u); }
+__device__ __forceinline__ uint32_t graph_lookup_subject(const DevGraph &g, uint64_t key, uint32_t mask) {
+  return subject_order_ok(g, mask) ? graph_lookup(g, key) : GRIM_NONE;
 }
 
 // plan-A neighbour range of a partial node, with the reference's sentinel quirk: the range is

@@ -478,6 +478,7 @@ extern "C" grim_graph *grim_graph_upload(grim_ctx *c, const grim_graph_desc *d) 
     D.lab_key = upload(c, g->bufs, lk.data(), d->n_nodes, &g->bytes);
   }
   D.scan_ok = (unique_names && max_deg < (1u << 22) && d->n_pops <= 64) ? 1u : 0u;
+  D.order_bad = d->label_order_bad;
   {
     std::vector<HtEnt> ht(cap);
     for (uint32_t i = 0; i < cap; ++i) {
@@ -847,6 +848,7 @@ void engine_batch_set_dict(grim_batch *b, const grim_devdict *d) {
 }
 
 uint32_t engine_batch_irregular(const grim_batch *b) { return b ? b->n_irregular : 0; }
+uint32_t engine_graph_order_bad(const grim_graph *g) { return g ? g->d.order_bad : 0; }
 
 // After grim_batch_run returned -2: when the PAIR POOL was what ran out and the demand fits `max_records`, the next
 // engine_batch_load sizes the pool for it (returns 1: load and run the same subjects again); 0: something else
@@ -1007,8 +1009,10 @@ extern "C" grim_batch *grim_batch_upload(grim_ctx *c, const grim_graph *g, const
   const uint32_t P = g->d.P;
   // subject classes
   ClassRule rule;
-  rule.small_ok = (P == 1) && p->opt_threshold > 1 && !getenv("GRIM_NO_SMALL");
-  rule.medium_ok = !getenv("GRIM_NO_MEDIUM");
+  // (a loci_map that is not alphabetical -- DevGraph::order_bad -- goes through the general kernel only: its look-ups are
+  // the ones that reproduce the reference's misses)
+  rule.small_ok = (P == 1) && p->opt_threshold > 1 && !getenv("GRIM_NO_SMALL") && g->d.order_bad == 0;
+  rule.medium_ok = !getenv("GRIM_NO_MEDIUM") && g->d.order_bad == 0;
   rule.graph_loci = g->d.n_loci;
   rule.opt_threshold = p->opt_threshold;
   std::vector<uint32_t> os, om, og;

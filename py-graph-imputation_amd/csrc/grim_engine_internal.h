@@ -74,6 +74,8 @@ void engine_devdict_free(grim_devdict *d);
 void engine_batch_set_dict(grim_batch *b, const grim_devdict *d);
 // lines the device tokenizer of the last run handed back to the host (status GRIM_ST_UNSUPPORTED, reason 7)
 uint32_t engine_batch_irregular(const grim_batch *b);
+// DevGraph::order_bad of an uploaded graph (non-zero: a loci_map that is not alphabetical; general kernel only)
+uint32_t engine_graph_order_bad(const grim_graph *g);
 uint64_t engine_batch_pool_want(const grim_batch *b);
 void engine_batch_hint_pool(grim_batch *b, uint64_t records);
 int engine_batch_grow_pool(grim_batch *b, uint64_t max_records);

@@ -334,6 +334,8 @@ extern "C" int grim_hostgraph_desc(const grim_hostgraph *h, grim_graph_desc *out
   out->n_b_nbr = h->b_nbr.size();
   out->lab_start = h->lab_start.data();
   out->lab_nodes = h->lab_nodes.data();
+  out->label_order_bad = 0;  // (the caller knows the loci_map: grim/imputation/networkx_graph.py sets it)
+  out->reserved = 0;
   return 0;
 }
 

@@ -829,17 +829,18 @@ struct NameLookup {  // allele id of a key field -> text: dictionary, or the sub
       if (R.ov[o].slot == slot && R.ov[o].id == id) return sv(R.ov_pool.data() + R.ov[o].off, R.ov[o].len);
     return sv();
   }
-  // the allele names of a haplotype key in sorted() order; returns how many
-  inline int alleles(uint64_t key, sv *out) const {
+  // the allele names of a haplotype key in sorted() order -- or, graph_order, in the order of a graph node's name (loci_map
+  // index order = slot order: the two differ only under a loci_map that is not alphabetical); returns how many
+  inline int alleles(uint64_t key, sv *out, bool graph_order = false) const {
     int n = 0;
     for (uint32_t q = 0; q < D.n_loci; ++q) {
-      const uint32_t s = D.order[q];
+      const uint32_t s = graph_order ? q : D.order[q];
       const uint32_t a = (uint32_t)((key >> (GRIM_ABITS * s)) & 0xFFF);
       if (!a) continue;
       const sv nm = get(s, a - 1);
       if (nm.data()) out[n++] = nm;
     }
-    if (!D.fixed_order) std::sort(out, out + n);
+    if (!D.fixed_order && !graph_order) std::sort(out, out + n);
     return n;
   }
 };
@@ -853,8 +854,11 @@ void format_range(const FmtParams &fp, const char *text, const TokRange &tr, con
   sv a[GRIM_MAXL], b[GRIM_MAXL];
   const size_t nl = tr.kind.size();
   auto pop_name = [&](uint32_t idx, int plan) -> sv { return plan == 'c' ? sv("all_pops") : sv(fp.pops[idx < fp.pops.size() ? idx : 0]); };
-  auto hap_name = [&](uint64_t key, OutBuf &out) {
-    const int n = names.alleles(key, a);
+  // A phased row prints the haplotype STRINGS the reference holds (impute.py:24-58): names of graph nodes as the graph
+  // spells them (Plan A, and Plan-B rows answered by one look-up: bit GRIM_KEY_GRAPH_ORDER of the key), keys of joined
+  // blocks with their alleles sorted (open_option_, impute.py:1041-1069).  Only a loci_map that is not alphabetical can tell.
+  auto hap_name = [&](uint64_t key, OutBuf &out, int plan) {
+    const int n = names.alleles(key, a, plan == 'a' || ((key >> GRIM_KEY_GRAPH_ORDER) & 1ull));
     size_t need = (size_t)n;
     for (int i = 0; i < n; ++i) need += a[i].size();
     char *q = out.room(need);
@@ -995,17 +999,17 @@ void format_range(const FmtParams &fp, const char *text, const TokRange &tr, con
           out.n = (size_t)(q - out.p);
         } else if (table == GRIM_T_PMUG) {
           if (prm->em_mr) {  // impute.py:79-99
-            hap_name(row.a, out);
+            hap_name(row.a, out, plan);
             out.put(';');
             out.put(pop_name(row.popa, plan));
             out.put(',');
-            hap_name(row.b, out);
+            hap_name(row.b, out, plan);
             out.put(';');
             out.put(pop_name(row.popb, plan));
           } else {
-            hap_name(row.a, out);
+            hap_name(row.a, out, plan);
             out.put('+');
-            hap_name(row.b, out);
+            hap_name(row.b, out, plan);
           }
         } else {
           out.put(pop_name((uint32_t)row.a, plan));

@@ -278,6 +278,7 @@ __device__ inline bool shared_scan_wanted(const DevArgs &A, WgShared &sh) {
     uint32_t ok = g.scan_ok && sj.n_loci >= 1 && sh.ntok > 2u * sj.n_loci && hit_cap(A) >= 1024u;
     uint32_t mask = 0;
     for (int l = 0; l < sj.n_loci; ++l) mask |= 1u << sj.slot[l];
+    if (!subject_order_ok(g, mask)) ok = 0;  // cartesian sides of such a subject find nothing: the sides are opened one by one
     const uint32_t la = g.lab_start[mask], lb = g.lab_start[mask + 1];
     uint64_t work = 0;  // what the per-side openings would cost, in label nodes / probes
     for (int s = 0; s < 2 * sh.nph && ok; ++s) {
@@ -554,7 +555,11 @@ __device__ inline void build_side_plan_a(const DevArgs &A, WgShared &sh, const S
     // (coalesced key stream, one LDS bit per position) and give each hit its position in the cartesian
     // order; the ranked top-K then yields the list the in-order probe stream would.
     const uint32_t la = g.lab_start[mask], lb = g.lab_start[mask + 1];
-    const bool intersect = g.scan_ok && in_lds && ncand >= 1024u && ncand < (1u << 28) && 2ull * ncand > (uint64_t)(lb - la);
+    // a loci_map whose order is not the subject's for these loci: every candidate NAME misses (the candidates still count
+    // as candidates: open_phases keeps the phase, impute.py:932-944)
+    const bool findable = subject_order_ok(g, mask);
+    if (!findable) ncand = 0;
+    const bool intersect = findable && g.scan_ok && in_lds && ncand >= 1024u && ncand < (1u << 28) && 2ull * ncand > (uint64_t)(lb - la);
     if (intersect) {
       st.ge = true;
       for (uint32_t i0 = la; i0 < lb; i0 += 64) {

@@ -24,6 +24,10 @@
 
 struct SideSpec {
   uint32_t cn[GRIM_MAXL], to[GRIM_MAXL], sl[GRIM_MAXL];
+  // bsl[l]: the locus the REFERENCE takes position l for when it cuts a cartesian candidate into Plan-B blocks: the l-th
+  // smallest typed index (create_haplos_string counts places by locus index, impute.py:1015-1039) -- the candidate's alleles,
+  // though, are in sorted string order (impute.py:271).  The same as sl[l] unless the loci_map is not alphabetical.
+  uint32_t bsl[GRIM_MAXL];
   int n;
   uint32_t typed_mask, ncand;
   bool expansion;
@@ -72,6 +76,21 @@ __device__ __forceinline__ SideSpec side_spec(const DevArgs &A, const WgShared &
     }
   }
   sp.expansion = options < A.prm.opt_threshold;
+#pragma unroll
+  for (int l = 0; l < GRIM_MAXL; ++l) sp.bsl[l] = sp.sl[l];
+  if (A.g.order_bad) {
+#pragma unroll
+    for (int l = 0; l < GRIM_MAXL; ++l)
+      if (l < sp.n) {
+        int rank = 0;
+#pragma unroll
+        for (int l2 = 0; l2 < GRIM_MAXL; ++l2)
+          if (l2 < sp.n && sp.sl[l2] < sp.sl[l]) ++rank;
+#pragma unroll
+        for (int r = 0; r < GRIM_MAXL; ++r)
+          if (r == rank) sp.bsl[r] = sp.sl[l];
+      }
+  }
   return sp;
 }
 
@@ -132,6 +151,9 @@ __device__ inline bool side_lookup_full(const DevArgs &A, WgShared &sh, const Sl
   st.nrun = 0; st.nbuf = 0; st.K = (int)A.prm.top_n; st.full = false; st.ge = false; st.thr = 0;
   uint64_t item_base = 0, c_nbr = 0, c_freq = 0;
   const bool direct = (sp.typed_mask == g.full_mask);
+  // the haplotypes of this list are graph node NAMES (adjs_query's keys), spelled in the graph's locus order; the keys the
+  // block joins make are sorted (open_option_) -- different strings, hence different haplotypes, when the two orders differ
+  const uint64_t name_flag = g.order_bad ? (1ull << GRIM_KEY_GRAPH_ORDER) : 0ull;
   if (!sp.expansion) {
     // candidates = the nodes the label scan lets through, in node order
     const uint32_t a = g.lab_start[sp.typed_mask], b = g.lab_start[sp.typed_mask + 1];
@@ -142,7 +164,7 @@ __device__ inline bool side_lookup_full(const DevArgs &A, WgShared &sh, const Sl
         const uint32_t nd = g.lab_nodes[i];
         if (node_passes(g, sp, tok, nd)) node = nd;
       }
-      expand_chunk<true>(A, prior, L, st, node, direct, g.a_start, g.a_nbr, 1.0, 0, item_base, c_nbr, c_freq);
+      expand_chunk<true>(A, prior, L, st, node, direct, g.a_start, g.a_nbr, 1.0, name_flag, item_base, c_nbr, c_freq);
     }
     store_top<true>(S, sh, L, st, row);
     return st.nrun > 0;
@@ -161,9 +183,9 @@ __device__ inline bool side_lookup_full(const DevArgs &A, WgShared &sh, const Sl
           key |= (uint64_t)(tok[sp.to[l] + d] + 1u) << (GRIM_ABITS * sp.sl[l]);
         }
       }
-      node = graph_lookup(g, key);
+      node = graph_lookup_subject(g, key, sp.typed_mask);
     }
-    expand_chunk<true>(A, prior, L, st, node, direct, g.a_start, g.a_nbr, 1.0, 0, item_base, c_nbr, c_freq);
+    expand_chunk<true>(A, prior, L, st, node, direct, g.a_start, g.a_nbr, 1.0, name_flag, item_base, c_nbr, c_freq);
   }
   store_top<true>(S, sh, L, st, row);
   return st.nrun > 0;
@@ -208,7 +230,7 @@ __device__ inline bool side_absent(const DevArgs &A, WgShared &sh, const Slot &S
             if ((absent >> l) & 1u) outside |= a; else key |= a;
           }
         }
-        uint32_t node = graph_lookup(g, key);
+        uint32_t node = graph_lookup_subject(g, key, src_mask);
         if (node != GRIM_NONE) src = direct ? node : g.b_conn[(uint64_t)node * GRIM_MAXL + add_slot];
       }
       expand_chunk<true>(A, prior, L, st, src, direct, g.b_start, g.b_nbr, scale, outside, item_base, c_nbr, c_freq);
@@ -250,16 +272,29 @@ __device__ inline bool side_blocks(const DevArgs &A, WgShared &sh, const Slot &S
           if (setn[b] == 0) ok = false;
         }
       } else {
-        const uint32_t added = bm & ~tb;
+        // The positions of a cartesian candidate that make up this block's name, and the loci their alleles really belong
+        // to: the same thing (the block's typed loci) unless the loci_map is not alphabetical -- then the reference picks
+        // positions by index rank (sp.bsl) out of a candidate that is in sorted string order, the name it builds holds the
+        // alleles of the loci `am`, is a graph name only when those come in graph order, and reaches the block's label
+        // either as a node of that label (am == bm) or over a connector to it (bm = am + one locus).
+        uint32_t selpos = 0, am = 0;
+#pragma unroll
+        for (int l = 0; l < GRIM_MAXL; ++l)
+          if (l < sp.n && ((bm >> (sp.expansion ? sp.bsl[l] : sp.sl[l])) & 1u)) {
+            selpos |= 1u << l;
+            am |= 1u << sp.sl[l];
+          }
+        const bool findable = !sp.expansion || (subject_order_ok(g, am) && (am & ~bm) == 0);
+        const uint32_t added = bm & ~am;
         const int nadd = __popc(added);
-        if (nadd > 1) {
+        if (nadd > 1 || !findable) {
           ok = false;  // parents are exactly one locus larger: no connector exists
         } else {
           const int add_slot = nadd ? (__ffs(added) - 1) : 0;
           uint32_t nsub = 1;
 #pragma unroll
           for (int l = 0; l < GRIM_MAXL; ++l)
-            if (l < sp.n && ((tb >> sp.sl[l]) & 1u)) nsub *= sp.cn[l];
+            if (l < sp.n && ((selpos >> l) & 1u)) nsub *= sp.cn[l];
           uint32_t *out = wset + (uint64_t)b * A.bset_cap;
           uint32_t cnt = 0;
           if (!sp.expansion) {
@@ -334,7 +369,7 @@ __device__ inline bool side_blocks(const DevArgs &A, WgShared &sh, const Slot &S
               uint32_t rem = c;
 #pragma unroll
               for (int l = GRIM_MAXL - 1; l >= 0; --l) {
-                if (l < sp.n && ((tb >> sp.sl[l]) & 1u)) {
+                if (l < sp.n && ((selpos >> l) & 1u)) {
                   uint32_t d = rem % sp.cn[l];
                   rem /= sp.cn[l];
                   key |= (uint64_t)(tok[sp.to[l] + d] + 1u) << (GRIM_ABITS * sp.sl[l]);
@@ -402,7 +437,8 @@ __device__ inline bool side_blocks(const DevArgs &A, WgShared &sh, const Slot &S
           if (b < nb) acc = acc * g.freq[(uint64_t)nd[b] * P + j] * GRIM_FACTOR_JOIN;
         bool act = valid && acc > 0.0;
         uint64_t tie = ((c * (uint64_t)P + (uint64_t)j) << 8) | (uint64_t)j;
-        top_push(L, st, act, acc, acc * prior[j * P + j], tie, 0, key);
+        // (a row of ONE block is answered by one look-up: graph names, not joined keys)
+        top_push(L, st, act, acc, acc * prior[j * P + j], tie, 0, (nb == 1 && g.order_bad) ? key | (1ull << GRIM_KEY_GRAPH_ORDER) : key);
       }
     }
   }

@@ -30,7 +30,7 @@ class GraphDesc(C.Structure):
         ("a_start", C.c_void_p), ("a_nbr", C.c_void_p), ("n_a_nbr", C.c_uint64),
         ("b_conn", C.c_void_p), ("b_start", C.c_void_p), ("b_nbr", C.c_void_p),
         ("n_conn", C.c_uint32), ("n_b_nbr", C.c_uint64),
-        ("lab_start", C.c_void_p), ("lab_nodes", C.c_void_p),
+        ("lab_start", C.c_void_p), ("lab_nodes", C.c_void_p), ("label_order_bad", C.c_uint32), ("reserved", C.c_uint32),
     ]
 
 
@@ -208,6 +208,7 @@ class DeviceGraph:
         d.n_a_nbr = arrays["a_nbr"].shape[0]
         d.n_conn = arrays["b_start"].shape[0] - 1
         d.n_b_nbr = arrays["b_nbr"].shape[0]
+        d.label_order_bad = int(arrays.get("label_order_bad", 0))
         self.h = L.grim_graph_upload(ctx.h, C.byref(d))
         if not self.h:
             raise NativeError("grim_graph_upload failed: " + ctx.error())

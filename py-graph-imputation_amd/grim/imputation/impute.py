@@ -342,8 +342,13 @@ class Imputation(object):
         b = sorted(x for x in g.key_alleles(key_b) if x)
         return "^".join("+".join(sorted(z)) for z in zip(a, b))
 
-    def _hap_name(self, key):
-        return "~".join(sorted(x for x in self.netGraph.key_alleles(key) if x))
+    def _hap_name(self, key, plan=None):
+        """a haplotype as the reference's phased writer spells it: a graph node's name (Plan A; a Plan-B list answered by one
+        look-up: bit 60 of the key) in the graph's locus order, a joined key with its alleles sorted (impute.py:1041-1069)"""
+        alleles = [x for x in self.netGraph.key_alleles(key) if x]
+        if plan == ord("a") or (int(key) >> 60) & 1:
+            return "~".join(alleles)
+        return "~".join(sorted(alleles))
 
     def _pop_name(self, idx, plan):
         return "all_pops" if plan == ord("c") else self.populations[int(idx)]
@@ -383,7 +388,7 @@ class Imputation(object):
             plan = int(r["plan_phased"]) or plan
             res_h["MaxProb"] = float(r["max_prob"])
             for row in rows[r["row_off"][nat.T_PMUG]: r["row_off"][nat.T_PMUG] + r["n_rows"][nat.T_PMUG]]:
-                res_h["Haps"].append([self._hap_name(row["a"]), self._hap_name(row["b"])])
+                res_h["Haps"].append([self._hap_name(row["a"], plan), self._hap_name(row["b"], plan)])
                 res_h["Probs"].append(float(row["prob"]))
                 res_h["Pops"].append([self._pop_name(row["popa"], plan), self._pop_name(row["popb"], plan)])
         return subject_id, res_m, res_h
@@ -694,10 +699,10 @@ class Imputation(object):
                 text = self._genotype(row["a"], row["b"])
             elif table == nat.T_PMUG:
                 if em_mr:  # write_best_hap_race_pairs, impute.py:79-99
-                    text = (self._hap_name(row["a"]) + ";" + self._pop_name(row["popa"], plan) + "," +
-                            self._hap_name(row["b"]) + ";" + self._pop_name(row["popb"], plan))
+                    text = (self._hap_name(row["a"], plan) + ";" + self._pop_name(row["popa"], plan) + "," +
+                            self._hap_name(row["b"], plan) + ";" + self._pop_name(row["popb"], plan))
                 else:
-                    text = self._hap_name(row["a"]) + "+" + self._hap_name(row["b"])
+                    text = self._hap_name(row["a"], plan) + "+" + self._hap_name(row["b"], plan)
             else:
                 text = self._pop_name(row["a"], plan) + "," + self._pop_name(row["b"], plan)
             fh.append(sid + "," + text + "," + str(prob) + "," + str(k) + "\n")

@@ -60,14 +60,19 @@ class Graph(object):
             self.slot_locus[s] = name
         if len(self.full_loci) > nat.MAXL:
             raise NotImplementedError("more than %d loci" % nat.MAXL)
-        # Candidate names are built from the subject's alleles in sorted STRING order
-        # (impute.py:271) while graph names are in loci_map index order; they only ever match when
-        # the two orders agree.  This build requires that.
-        by_name = sorted(self.locus_slot, key=lambda n: n + "*")
-        if [self.locus_slot[n] for n in by_name] != sorted(self.locus_slot.values()):
-            raise NotImplementedError(
-                "loci_map order differs from the alphabetical locus order; the reference finds no "
-                "haplotypes in that configuration and this build refuses it")
+        # Candidate names are built from the subject's alleles in sorted STRING order (impute.py:271) while graph names are
+        # in loci_map index order (generate_neo4j_multi_hpf.py:59-68).  Where the two orders differ for a set of loci -- a
+        # loci_map that is not alphabetical, such as the reference's own default A 1, B 3, C 2 -- a name built from a
+        # subject's alleles over that set never equals a graph name, and the reference's look-ups miss; so do the device's
+        # (bit m of label_order_bad: label mask m is such a set; csrc/grim_dev.h graph_lookup_subject).
+        self.label_order_bad = 0
+        for m in range(1, 1 << len(self.full_loci)):
+            slots = [s for s in range(len(self.full_loci)) if (m >> s) & 1]
+            names = [self.slot_locus[s] for s in slots]
+            if None in names:
+                continue
+            if sorted(names, key=lambda n: n + "*") != names:
+                self.label_order_bad |= 1 << m
         # one allele dictionary (C++ side of the library) shared by loader, tokenizer and formatter
         self.adict = nat.AlleleDict(self.slot_locus)
         self.arrays = None
@@ -93,16 +98,42 @@ class Graph(object):
         (argument names as in networkx_graph.py:42).  Parsed and indexed by the library's C++ loader
         (grim_hostgraph_load_csv); `_build_graph_python` is the same thing in numpy, kept as the
         cross-check in tests/."""
+        self._check_labels(nodesFile)
         self.arrays = nat.load_graph_csv(self.adict, self.full_loci, nodesFile, edgesFile, allEdgesFile)
+        self.arrays["label_order_bad"] = self.label_order_bad
         self.n_graph_alleles = [self.adict.count(s) for s in range(len(self.full_loci))]
         self._dev = {}
         return self
+
+    def _check_labels(self, nodesFile, rows=2000):
+        """The label column of nodes.csv is written with the loci_map the graph was GENERATED with
+        (generate_neo4j_multi_hpf.py:419-430); this build derives labels from the alleles under the loci_map of the
+        configuration at hand.  When the two maps differ (a graph made with A 1, B 2, C 3 read under the reference's default
+        A 1, B 3, C 2, say) the reference keeps the file's labels next to its own index arithmetic and answers something in
+        between; that mixture is not reproduced -- refuse instead of answering differently."""
+        with open(nodesFile) as fh:
+            rd = csv.reader(fh)
+            next(rd, None)
+            for k, row in enumerate(rd):
+                if k >= rows:
+                    break
+                if len(row) < 3:
+                    continue
+                try:
+                    want = "".join(sorted(self.full_loci[self.locus_slot[a.split("*")[0]]] for a in row[1].split("~")))
+                except KeyError:
+                    continue
+                if want != row[2]:
+                    raise NotImplementedError(
+                        "nodes.csv labels haplotype %r as %r, the configuration's loci_map makes it %r: the graph was generated with "
+                        "another loci_map than the one in use" % (row[1], row[2], want))
 
     def build_graph_from_hpf(self, hpf_file, populations, cutoffs, loci_map, csv_paths=None):
         """hpf.csv -> this graph, generator and loader back to back inside the library (grim_hostgraph_from_hpf):
         what graph_freqs() + build_graph() produce, without the four CSVs in between.  csv_paths = optional
         (nodes, edges, top_links, info_node) to write them as well."""
         self.arrays = nat.graph_from_hpf(self.adict, self.full_loci, hpf_file, populations, cutoffs, loci_map, csv_paths)
+        self.arrays["label_order_bad"] = self.label_order_bad
         self.n_graph_alleles = [self.adict.count(s) for s in range(len(self.full_loci))]
         self._dev = {}
         return self
@@ -199,7 +230,7 @@ class Graph(object):
             "node_key": node_key, "node_mask": node_mask, "freq": freq,
             "a_start": a_start, "a_nbr": a_nbr,
             "b_conn": b_conn, "b_start": b_start, "b_nbr": b_nbr,
-            "lab_start": lab_start, "lab_nodes": lab_order,
+            "lab_start": lab_start, "lab_nodes": lab_order, "label_order_bad": self.label_order_bad,
         }
         self.n_graph_alleles = [self.adict.count(s) for s in range(nl)]
         self._dev = {}

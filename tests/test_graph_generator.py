@@ -16,7 +16,7 @@ def _md5(path, sort_lines=False):
     return hashlib.md5(data).hexdigest()
 
 
-@pytest.mark.parametrize("name", ["cau", "pop4"])
+@pytest.mark.parametrize("name", ["cau", "pop4", "cau_bc", "pop4_bc"])
 def test_generated_csv_identical_to_reference(name):
     work = harness.ensure_graph(name)
     info = json.load(open(os.path.join(harness.GOLD, "graphs", name, "graph_info.json")))

@@ -63,9 +63,14 @@ def main():
     rows = synth.read_freqs(synth.CAU_FREQS)
     t0 = time.time()
     for rd in range(rounds):
-        gname = str(rng.choice(["cau", "pop4", "pop9"], p=[0.45, 0.4, 0.15]))
+        graphs = os.environ.get("GRIM_FUZZ_GRAPHS")  # e.g. "cau_bc,pop4_bc": only these (equal weights)
+        if graphs:
+            gname = str(rng.choice(graphs.split(",")))
+        else:
+            gname = str(rng.choice(["cau", "pop4", "pop9", "cau_bc", "pop4_bc"], p=[0.4, 0.35, 0.13, 0.06, 0.06]))
         pops = harness.POPS[gname]
         conf = harness.base_conf(pops)
+        conf.update(harness.GRAPH_OVERRIDES.get(gname, {}))  # (a loci_map that is not alphabetical)
         conf["UNK_priors"] = "MR" if rng.random() < 0.5 else "SR"
         conf["number_of_options_threshold"] = int(rng.choice([5, 40, 300, 5000, 100000]))
         conf["max_haplotypes_number_in_phase"] = int(rng.choice([1, 3, 20, 100, 128]))

@@ -23,6 +23,12 @@ for p in (PKG, os.path.join(ROOT, "oracle"), HERE):
 POPS = {"cau": ["CAU"], "pop4": ["CAU", "AFA", "HIS", "API"],
         # nine populations: CAU plus eight synthesised on the fly (seed 9); oracle-checked only, no golden files
         "pop9": ["CAU", "AFA", "HIS", "API", "NAM", "MENA", "SAS", "EAS", "OCE"]}
+# graphs whose configuration differs from the minimal conf's: a loci_map whose index order is not the alphabetical locus order
+# (the reference's own default map, B = 3 and C = 2)
+GRAPH_OVERRIDES = {"cau_bc": {"loci_map": {"A": 1, "B": 3, "C": 2, "DQB1": 4, "DRB1": 5}},
+                   "pop4_bc": {"loci_map": {"A": 1, "B": 3, "C": 2, "DQB1": 4, "DRB1": 5}}}
+POPS["cau_bc"] = POPS["cau"]
+POPS["pop4_bc"] = POPS["pop4"]
 OUT_FILES = {"umug": "don.umug", "umug_pops": "don.umug.pops", "pmug": "don.pmug", "pmug_pops": "don.pmug.pops",
              "miss": "don.miss", "problem": "don.problem"}
 
@@ -59,6 +65,7 @@ def ensure_graph(name):
             synth.write_freqs(os.path.join(work, "data", "freqs", p + ".freqs.gz"),
                               synth.synth_population(synth.read_freqs(synth.CAU_FREQS), extra_rng, drop=0.5))
     conf = base_conf(POPS[name])
+    conf.update(GRAPH_OVERRIDES.get(name, {}))
     with open(os.path.join(work, "graph_conf.json"), "w") as fh:
         json.dump(conf, fh)
     cwd = os.getcwd()

@@ -102,7 +102,10 @@ def md5(path, sort_lines=False):
     return hashlib.md5(data).hexdigest()
 
 
-def build_graph(name, pops):
+LOCI_MAP_BC = {"A": 1, "B": 3, "C": 2, "DQB1": 4, "DRB1": 5}  # the reference's own default (run_impute_def.py:102-103): B and C swapped
+
+
+def build_graph(name, pops, loci_map=None):
     """Run the reference's produce_hpf + graph_freqs in SCRATCH/work/<name>."""
     from graph_generation.generate_hpf import produce_hpf
     from grim import grim
@@ -113,6 +116,8 @@ def build_graph(name, pops):
     for p in pops:
         shutil.copy(os.path.join(GOLD, "data", "freqs", p + ".freqs.gz"), os.path.join(work, "data", "freqs"))
     conf = dict(BASE_CONF, populations=list(pops))
+    if loci_map:
+        conf["loci_map"] = dict(loci_map)
     with open(os.path.join(work, "graph_conf.json"), "w") as fh:
         json.dump(conf, fh, indent=1)
     cwd = os.getcwd()
@@ -192,6 +197,8 @@ def run_scenario(name, work, pops, lines, overrides=None, hap_pop_pair=False, bi
 
     conf = dict(BASE_CONF, populations=list(pops))
     conf.update(overrides or {})
+    for k in [k for k, v in conf.items() if v is None]:  # an override of None removes the key (the reference's default applies)
+        del conf[k]
     if bin_masks is not None:
         conf["bin_imputation_in_file"] = "data/subjects/bin.json"
         with open(os.path.join(work, "data", "subjects", "bin.json"), "w") as fh:
@@ -355,6 +362,23 @@ def main():
     run_scenario("cau_eps0_haps", w1, ["CAU"], eps_lines, {"epsilon": 0.0, "output_MUUG": False})
     run_scenario("cau_epsneg_muug", w1, ["CAU"], eps_lines, {"epsilon": -1e-3, "output_haplotypes": False})
     run_scenario("cau_eps0_noplanb", w1, ["CAU"], eps_lines, {"epsilon": 0, "planb": False})
+    # a loci_map whose index order is not the alphabetical locus order -- the reference's own default map, B = 3 and C = 2 --
+    # used for graph generation and imputation alike: graph names are A~C~B~DQB1~DRB1, a subject's candidate names are its
+    # alleles in sorted order (impute.py:271), so cartesian candidates that hold both B and C never match; label-scan
+    # candidates (graph order) do
+    wbc = build_graph("cau_bc", ["CAU"], LOCI_MAP_BC)
+    w4bc = build_graph("pop4_bc", POP4, LOCI_MAP_BC)
+    bc = {"loci_map": LOCI_MAP_BC}
+    run_scenario("bc_cau_mixed", wbc, ["CAU"], synth.SubjectGen(cau, 31).mixed(200) + synth.edge_cases("CAU"), bc)
+    run_scenario("bc_cau_scan30", wbc, ["CAU"], synth.SubjectGen(cau, 32).mixed(150, amb=0.7, miss=0.1, recomb=0.5),
+                 dict(bc, number_of_options_threshold=30))
+    run_scenario("bc_pop4_mixed", w4bc, POP4, synth.SubjectGen(cau, 33, pops=POP4).mixed(200) + synth.plan_c_cases("HIS"),
+                 dict(bc, UNK_priors="MR"))
+    # the same graph, and a conf WITHOUT a loci_map: run_impute_def.py:102-103 supplies this very map
+    run_scenario("bc_cau_default_map", wbc, ["CAU"], synth.SubjectGen(cau, 35).mixed(120, amb=0.4, miss=0.3, recomb=0.4) + synth.plan_c_cases("CAU"),
+                 {"loci_map": None})
+    run_scenario("bc_pop4_scan8", w4bc, POP4, synth.SubjectGen(cau, 34, pops=POP4).mixed(120, amb=0.7, miss=0.2, recomb=0.5),
+                 dict(bc, UNK_priors="MR", number_of_options_threshold=8))
 
 
 if __name__ == "__main__":
