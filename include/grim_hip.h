@@ -118,6 +118,8 @@ typedef struct {
   uint32_t n_pop_results;  /* number_of_pop_results          */
   uint8_t out_muug, out_haps, planb, em_mr;
   uint8_t em;              /* impute_file(em=True): the phased pass never falls back to Plan C (impute.py:1649) */
+  uint8_t save_mode;       /* save_space_mode: open_option_ keeps the 10 largest entries of either operand before the cross
+                              product (impute.py:1048-1059) */
   uint8_t eps_nonpositive; /* conf epsilon <= 0: call_comp_phase_prob never runs a pass and returns its "NaN" sentinel
                               (impute.py:1663-1665); the writers raise on it, so every subject that has phases ends as its
                               raw line in .problem (formatter rule; the ladder is empty) */

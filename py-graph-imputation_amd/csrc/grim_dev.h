@@ -21,6 +21,8 @@
 #define GRIM_VALID 0x8000000000000000ull
 #define GRIM_SIDES (2 * GRIM_MAXPH)
 #define GRIM_COMP_CAP 8192  // >= 2 * GRIM_SIDES * GRIM_TOPCAP (64 KB: stays in the L2; a 512 KB table per workgroup did not)
+#define GRIM_SAVE_KEEP 10   // entries save_space_mode keeps of either operand of a block join (impute.py:1041)
+#define GRIM_SAVE_CAP (GRIM_SAVE_KEEP * GRIM_SAVE_KEEP)
 #define GRIM_RTOK_CAP 12288 // u16 tokens per slot: 3 versions of up to 4096 alleles per subject
 
 // ---- graph as the kernels see it --------------------------------------------------------------
@@ -66,6 +68,7 @@ struct SlotLayout {
   uint64_t comp;                       // plan-B/C canonical haplotype table: open-addressing keys [GRIM_COMP_CAP]
   uint64_t proj_k, proj_p;             // plan-B label-scan projections: per-wave hash set [GRIM_NWAVE][proj_cap]
   uint64_t rtok;                       // the subject's allele lists: original + the two reduced versions [GRIM_RTOK_CAP]
+  uint64_t save;                       // save_space_mode: per wave two buffers of GRIM_SAVE_CAP joined entries (key + P frequencies)
   uint64_t stride;                     // bytes per slot
 };
 

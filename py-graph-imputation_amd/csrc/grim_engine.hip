@@ -694,6 +694,7 @@ static void batch_init_params(grim_batch *b, const grim_graph *g, const grim_par
   L.proj_k = take(8ull * GRIM_NWAVE * A.proj_cap);
   L.proj_p = take(4ull * GRIM_NWAVE * A.proj_cap);
   L.rtok = take(2ull * GRIM_RTOK_CAP);
+  L.save = take(p->save_mode ? 8ull * GRIM_NWAVE * 2 * GRIM_SAVE_CAP * (P + 1) : 0);
   L.stride = align256(o);
   b->timing = env_int("GRIM_TIMING", 0) != 0;
   A.flags = (env_int("GRIM_TABLES_HBM", 0) ? GRIM_F_TABLES_HBM : 0u) | (env_int("GRIM_NO_NODUP", 0) ? GRIM_F_NO_NODUP : 0u);

@@ -106,6 +106,7 @@ struct Slot {
   uint64_t *proj_k;
   uint32_t *proj_p;
   uint16_t *rtok;
+  double *save;
 };
 
 __device__ __forceinline__ Slot make_slot(const DevArgs &A, uint32_t slot_idx) {
@@ -136,6 +137,7 @@ __device__ __forceinline__ Slot make_slot(const DevArgs &A, uint32_t slot_idx) {
   s.proj_k = (uint64_t *)(b + A.lay.proj_k);
   s.proj_p = (uint32_t *)(b + A.lay.proj_p);
   s.rtok = (uint16_t *)(b + A.lay.rtok);
+  s.save = (double *)(b + A.lay.save);
   return s;
 }
 

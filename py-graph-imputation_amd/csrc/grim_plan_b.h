@@ -240,6 +240,146 @@ __device__ inline bool side_absent(const DevArgs &A, WgShared &sh, const Slot &S
   return st.nrun > 0;
 }
 
+
+// ---- save_space_mode (impute.py:1048-1059) -----------------------------------------------------------------------------
+// Before two dicts are joined, either of them that holds more than 10 entries is cut down to 10: the entries are sorted
+// by the SUM of their frequency vector, ascending and stable, and deleted from the front until ten are left -- so the ten
+// largest stay, of equal sums the later ones, in their original order.  save_select finds them among n entries whose value
+// any lane can compute; every lane ends with the same list (ascending entry numbers).
+template <typename F>
+__device__ inline uint32_t save_select(uint32_t n, F val, uint32_t (&keep)[GRIM_SAVE_KEEP]) {
+  const int lane = lane_id();
+  if (n <= GRIM_SAVE_KEEP) {
+    for (uint32_t k = 0; k < GRIM_SAVE_KEEP; ++k) keep[k] = k;
+    return n;
+  }
+  // pick after pick in the order "larger sum first, of equal sums the later entry first"
+  double pv = 0.0;
+  uint32_t pi = 0;
+  for (uint32_t r = 0; r < GRIM_SAVE_KEEP; ++r) {
+    double bv = 0.0;
+    uint32_t bi = GRIM_NONE;
+    for (uint32_t i = lane; i < n; i += 64) {
+      const double v = val(i);
+      const bool after_prev = r == 0 || v < pv || (v == pv && i < pi);        // not picked yet
+      const bool better = bi == GRIM_NONE || v > bv || (v == bv && i > bi);
+      if (after_prev && better) {
+        bv = v;
+        bi = i;
+      }
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+      const double ov = __shfl_xor(bv, d);
+      const uint32_t oi = (uint32_t)__shfl_xor((int)bi, d);
+      if (oi != GRIM_NONE && (bi == GRIM_NONE || ov > bv || (ov == bv && oi > bi))) {
+        bv = ov;
+        bi = oi;
+      }
+    }
+    pv = bv;
+    pi = bi;
+    keep[r] = bi;
+  }
+  // back into the dict's own order
+  for (int a = 1; a < GRIM_SAVE_KEEP; ++a) {
+    const uint32_t x = keep[a];
+    int b = a;
+    while (b > 0 && keep[b - 1] > x) {
+      keep[b] = keep[b - 1];
+      --b;
+    }
+    keep[b] = x;
+  }
+  return GRIM_SAVE_KEEP;
+}
+
+// sum(list) of a node's frequency vector as Python adds it: 0 + f[0] + f[1] + ...
+__device__ __forceinline__ double freq_sum(const DevGraph &g, uint32_t node) {
+  double s = 0.0;
+  for (uint32_t j = 0; j < g.P; ++j) s = s + g.freq[(uint64_t)node * g.P + j];
+  return s;
+}
+
+// The block cross product of a Plan_B_Matrix row under save_space_mode: acc = block 0; for every further block: acc cut to
+// 10, the block cut to 10, acc = their join (acc outer, per population (a * b) * 1e-4, all-zero combinations dropped)
+// (find_option_freq + open_option_, impute.py:1072-1115, 1041-1069).  The entries of the last join go through the top-K.
+__device__ inline void blocks_save(const DevArgs &A, const Slot &S, const double *prior, WaveTop &L, TopState &st, const uint32_t *const *setp,
+                                   const uint32_t *setn, int nb) {
+  const DevGraph &g = A.g;
+  const int lane = lane_id();
+  const int P = g.P;
+  const uint64_t per = (uint64_t)GRIM_SAVE_CAP * (P + 1);
+  double *buf[2] = {S.save + (uint64_t)wave_id() * 2 * per, S.save + (uint64_t)wave_id() * 2 * per + per};
+  // an entry of a buffer: P frequencies, then its 60-bit key (as a double-sized word)
+  auto key_of = [&](double *b, uint32_t e) -> uint64_t * { return (uint64_t *)(b + (uint64_t)e * (P + 1) + P); };
+  auto vec_of = [&](double *b, uint32_t e) -> double * { return b + (uint64_t)e * (P + 1); };
+  uint32_t keep[GRIM_SAVE_KEEP];
+  // acc := block 0, cut to ten (the cut happens when block 1 is joined: the same thing, nb >= 2)
+  uint32_t na = save_select(setn[0], [&](uint32_t i) { return freq_sum(g, setp[0][i]); }, keep);
+  int cur = 0;
+  for (uint32_t e = lane; e < na; e += 64) {
+    const uint32_t nd = setp[0][keep[e]];
+    for (int j = 0; j < P; ++j) vec_of(buf[cur], e)[j] = g.freq[(uint64_t)nd * P + j];
+    *key_of(buf[cur], e) = g.node_key[nd];
+  }
+  __threadfence_block();
+  for (int b = 1; b < nb; ++b) {
+    if (na > GRIM_SAVE_KEEP) {  // the join so far, cut to ten
+      double *src = buf[cur];
+      uint32_t k2[GRIM_SAVE_KEEP];
+      const uint32_t n2 = save_select(na, [&](uint32_t i) {
+        double s = 0.0;
+        for (int j = 0; j < P; ++j) s = s + vec_of(src, i)[j];
+        return s;
+      }, k2);
+      double *dst = buf[cur ^ 1];
+      for (uint32_t e = lane; e < n2; e += 64) {
+        for (int j = 0; j < P; ++j) vec_of(dst, e)[j] = vec_of(src, k2[e])[j];
+        *key_of(dst, e) = *key_of(src, k2[e]);
+      }
+      __threadfence_block();
+      cur ^= 1;
+      na = n2;
+    }
+    const uint32_t nk = save_select(setn[b], [&](uint32_t i) { return freq_sum(g, setp[b][i]); }, keep);
+    double *src = buf[cur], *dst = buf[cur ^ 1];
+    uint32_t cnt = 0;
+    const uint32_t total = na * nk;  // <= 100
+    for (uint32_t c0 = 0; c0 < total; c0 += 64) {
+      const uint32_t c = c0 + lane;
+      bool on = false;
+      uint32_t e1 = 0, nd = 0;
+      if (c < total) {
+        e1 = c / nk;
+        nd = setp[b][keep[c - e1 * nk]];
+        for (int j = 0; j < P; ++j) on |= vec_of(src, e1)[j] * g.freq[(uint64_t)nd * P + j] * GRIM_FACTOR_JOIN > 0.0;  // max(list_prob) > 0
+      }
+      const uint64_t m = __ballot(on);
+      if (on) {
+        const uint32_t pos = cnt + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        for (int j = 0; j < P; ++j) vec_of(dst, pos)[j] = vec_of(src, e1)[j] * g.freq[(uint64_t)nd * P + j] * GRIM_FACTOR_JOIN;
+        *key_of(dst, pos) = *key_of(src, e1) | g.node_key[nd];
+      }
+      cnt += (uint32_t)__popcll(m);
+    }
+    __threadfence_block();
+    cur ^= 1;
+    na = cnt;
+    if (na == 0) return;
+  }
+  double *fin = buf[cur];
+  for (uint32_t c0 = 0; c0 < na; c0 += 64) {
+    const uint32_t c = c0 + lane;
+    const bool valid = c < na;
+    const uint64_t key = valid ? *key_of(fin, c) : 0ull;
+    for (int j = 0; j < P; ++j) {
+      const double p = valid ? vec_of(fin, c)[j] : 0.0;
+      const uint64_t tie = (((uint64_t)c * (uint64_t)P + (uint64_t)j) << 8) | (uint64_t)j;
+      top_push(L, st, valid && p > 0.0, p, p * prior[j * P + j], tie, 0, key);
+    }
+  }
+}
+
 // A Plan_B_Matrix row with several blocks (impute.py:1072-1115): per block the set of graph nodes
 // reachable from the typed part of the candidates (or, for a block without any typed locus that is
 // not the first one, every node of the block's label), then the cross product, first block most
@@ -409,7 +549,9 @@ __device__ inline bool side_blocks(const DevArgs &A, WgShared &sh, const Slot &S
     }
   }
   __threadfence_block();
-  if (ok) {
+  if (ok && A.prm.save_mode && nb >= 2) {
+    blocks_save(A, S, prior, L, st, setp, setn, nb);
+  } else if (ok) {
     uint64_t total = 1;
 #pragma unroll
     for (int b = 0; b < GRIM_MAXL; ++b)
@@ -466,6 +608,51 @@ __device__ __forceinline__ double pop_sum(const DevGraph &g, uint32_t node) {  /
 // comp_hap_prob_plan_c: per candidate the product of its alleles' population-summed frequencies
 // ((s0*s1)*1e-4)*s2)*1e-4.., unknown alleles kept in the name and paid for with
 // factor_missing_data ** count, then joined with every node of the label of the untyped loci.
+// one cartesian candidate of a Plan-C side: the product of its alleles' population-summed frequencies (impute.py:1264-1311);
+// false: the candidate yields nothing (no allele of it known to the graph, or the product fell to zero)
+__device__ __forceinline__ bool plan_c_candidate(const DevArgs &A, const SideSpec &sp, const uint16_t *tok, uint32_t c, double &value, uint64_t &key) {
+  const DevGraph &g = A.g;
+  uint32_t rem = c;
+  uint32_t al[GRIM_MAXL];
+#pragma unroll
+  for (int l = GRIM_MAXL - 1; l >= 0; --l) {
+    al[l] = 0;
+    if (l < sp.n) {
+      uint32_t d = rem % sp.cn[l];
+      rem /= sp.cn[l];
+      al[l] = tok[sp.to[l] + d];
+    }
+  }
+  bool have = false, dead = false;
+  int n_abs = 0;
+  double cur = 0.0;
+  key = 0;
+#pragma unroll
+  for (int l = 0; l < GRIM_MAXL; ++l) {
+    if (l < sp.n && !dead) {
+      uint64_t k1 = (uint64_t)(al[l] + 1u) << (GRIM_ABITS * sp.sl[l]);
+      key |= k1;
+      uint32_t node = graph_lookup(g, k1);
+      if (node == GRIM_NONE) {
+        ++n_abs;
+      } else {
+        double s = pop_sum(g, node);
+        if (!have) {
+          cur = s;
+          have = true;
+        } else {
+          cur = cur * s * GRIM_FACTOR_JOIN;
+          if (!(cur > 0.0)) dead = true;
+        }
+      }
+    }
+  }
+  if (!have || dead) return false;
+  if (n_abs) cur = cur * A.prm.factor_missing_pow[n_abs];
+  value = cur;
+  return true;
+}
+
 __device__ inline bool side_plan_c(const DevArgs &A, WgShared &sh, const Slot &S, const double *prior, WaveTop &L,
                                    const SideSpec &sp, const uint16_t *tok, int row) {
   const DevGraph &g = A.g;
@@ -475,6 +662,56 @@ __device__ inline bool side_plan_c(const DevArgs &A, WgShared &sh, const Slot &S
   st.nrun = 0; st.nbuf = 0; st.K = (int)A.prm.top_n; st.full = false; st.ge = false; st.thr = 0;
   const uint32_t miss = g.full_mask & ~sp.typed_mask;
   const uint32_t r0 = miss ? g.lab_start[miss] : 0, rn = miss ? (g.lab_start[miss + 1] - g.lab_start[miss]) : 1;
+  if (A.prm.save_mode && miss && rn > 0) {
+    // save_space_mode: the join with the nodes of the untyped loci's label goes through open_option_ like every join, so
+    // the candidates' dict and the label's dict are both cut to their ten largest entries first (impute.py:1048-1059; a
+    // candidate that yields nothing is not in the dict)
+    uint32_t kc[GRIM_SAVE_KEEP], kr[GRIM_SAVE_KEEP];
+    // (entries = the candidates that yield something, in candidate order: number them first)
+    uint32_t n_ok = 0;
+    uint32_t *okidx = S.bset + (uint64_t)wave_id() * GRIM_MAXL * A.bset_cap;  // this wave's block-set area: free in Plan C
+    const uint32_t okcap = GRIM_MAXL * A.bset_cap;
+    for (uint32_t c0 = 0; c0 < sp.ncand; c0 += 64) {
+      const uint32_t c = c0 + lane;
+      double v;
+      uint64_t k;
+      const bool on = c < sp.ncand && plan_c_candidate(A, sp, tok, c, v, k);
+      const uint64_t m = __ballot(on);
+      if (on) {
+        const uint32_t pos = n_ok + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (pos < okcap) okidx[pos] = c;
+      }
+      n_ok += (uint32_t)__popcll(m);
+    }
+    __threadfence_block();
+    if (n_ok > okcap) n_ok = okcap;  // (cannot happen: bset_cap >= the biggest label, candidates of a Plan-C side are few)
+    const uint32_t nc = save_select(n_ok, [&](uint32_t i) {
+      double v = 0.0;
+      uint64_t k;
+      plan_c_candidate(A, sp, tok, okidx[i], v, k);
+      return v;
+    }, kc);
+    const uint32_t nr = save_select(rn, [&](uint32_t i) { return pop_sum(g, g.lab_nodes[r0 + i]); }, kr);
+    const uint32_t total = nc * nr;
+    for (uint32_t i0 = 0; i0 < total; i0 += 64) {
+      const uint32_t i = i0 + lane;
+      const bool valid = i < total;
+      double p = 0.0;
+      uint64_t key = 0;
+      if (valid) {
+        const uint32_t e1 = i / nr, e2 = i - e1 * nr;
+        double v = 0.0;
+        plan_c_candidate(A, sp, tok, okidx[kc[e1]], v, key);
+        const uint32_t rn_node = g.lab_nodes[r0 + kr[e2]];
+        p = v * pop_sum(g, rn_node) * GRIM_FACTOR_JOIN;
+        key |= g.node_key[rn_node];
+      }
+      const uint64_t tie = (((uint64_t)i * (uint64_t)P) << 8);
+      top_push(L, st, valid && p > 0.0, p, p * prior[0], tie, 0, key);
+    }
+    store_top<true>(S, sh, L, st, row);
+    return st.nrun > 0;
+  }
   const uint64_t total = (uint64_t)sp.ncand * rn;
   for (uint64_t i0 = 0; i0 < total; i0 += 64) {
     uint64_t i = i0 + lane;
@@ -483,42 +720,8 @@ __device__ inline bool side_plan_c(const DevArgs &A, WgShared &sh, const Slot &S
     uint64_t key = 0;
     if (valid) {
       uint32_t c = (uint32_t)(i / rn), r = (uint32_t)(i % rn);
-      uint32_t rem = c;
-      uint32_t al[GRIM_MAXL];
-#pragma unroll
-      for (int l = GRIM_MAXL - 1; l >= 0; --l) {
-        al[l] = 0;
-        if (l < sp.n) {
-          uint32_t d = rem % sp.cn[l];
-          rem /= sp.cn[l];
-          al[l] = tok[sp.to[l] + d];
-        }
-      }
-      bool have = false, dead = false;
-      int n_abs = 0;
       double cur = 0.0;
-#pragma unroll
-      for (int l = 0; l < GRIM_MAXL; ++l) {
-        if (l < sp.n && !dead) {
-          uint64_t k1 = (uint64_t)(al[l] + 1u) << (GRIM_ABITS * sp.sl[l]);
-          key |= k1;
-          uint32_t node = graph_lookup(g, k1);
-          if (node == GRIM_NONE) {
-            ++n_abs;
-          } else {
-            double s = pop_sum(g, node);
-            if (!have) {
-              cur = s;
-              have = true;
-            } else {
-              cur = cur * s * GRIM_FACTOR_JOIN;
-              if (!(cur > 0.0)) dead = true;
-            }
-          }
-        }
-      }
-      if (have && !dead) {
-        if (n_abs) cur = cur * A.prm.factor_missing_pow[n_abs];
+      if (plan_c_candidate(A, sp, tok, c, cur, key)) {
         if (miss) {
           uint32_t rn_node = g.lab_nodes[r0 + r];
           cur = cur * pop_sum(g, rn_node) * GRIM_FACTOR_JOIN;

@@ -39,7 +39,7 @@ class Params(C.Structure):
         ("ladder", C.c_double * MAXLADDER), ("n_ladder", C.c_int32), ("top_n", C.c_uint32),
         ("opt_threshold", C.c_uint64), ("n_results", C.c_uint32), ("n_pop_results", C.c_uint32),
         ("out_muug", C.c_uint8), ("out_haps", C.c_uint8), ("planb", C.c_uint8), ("em_mr", C.c_uint8), ("em", C.c_uint8),
-        ("eps_nonpositive", C.c_uint8),
+        ("save_mode", C.c_uint8), ("eps_nonpositive", C.c_uint8),
         ("pop_rank", C.c_uint8 * MAXPOP), ("factor_missing_pow", C.c_double * (MAXL + 1)),
         ("planb_rows", C.c_uint8), ("planb_nblk", C.c_uint8 * MAXROWS),
         ("planb_blk", (C.c_uint8 * MAXL) * MAXROWS),

@@ -102,8 +102,6 @@ class Imputation(object):
         self.index_dict = dict(config["loci_map"])
         if config.get("nodes_for_plan_A"):
             raise NotImplementedError("Plan_A_Matrix is not supported by this build")
-        if config.get("save_mode"):
-            raise NotImplementedError("save_space_mode is not supported by this build")
         if count_by_prob is None:  # impute.py:205-212
             self.count_by_prob = np.ones(P)
             if config["use_pops_count_file"]:
@@ -271,6 +269,7 @@ class Imputation(object):
         p.em = 1 if em else 0
         p.em_mr = 1 if em_mr else 0
         p.eps_nonpositive = 0 if config["epsilon"] > 0 else 1
+        p.save_mode = 1 if config.get("save_mode") else 0
         order = sorted(range(len(self.populations)), key=lambda i: self.populations[i])
         for rank, i in enumerate(order):
             p.pop_rank[i] = rank

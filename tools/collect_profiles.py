@@ -5,7 +5,7 @@ wrote them, one summary line per (kernel, counter) of every --pmc pass, and the 
 import collections, csv, glob, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 for w in ("config2", "config3", "config4", "config5"):

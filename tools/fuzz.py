@@ -82,6 +82,8 @@ def main():
         conf["output_MUUG"] = out != 1
         conf["output_haplotypes"] = out != 0
         conf["factor_missing_data"] = float(rng.choice([0.01, 0.0001]))
+        if rng.random() < (0.5 if os.environ.get("GRIM_FUZZ_SAVE") else 0.1):
+            conf["save_space_mode"] = True  # open_option_ cuts either operand to its ten largest entries (impute.py:1048-1059)
         pr = {"alpha": 0.4999999, "eta": 0, "beta": 1e-7, "gamma": 1e-7, "delta": 0.4999999}
         if rng.random() < 0.3:
             pr = {"alpha": float(rng.random()), "eta": float(rng.random() * 0.1), "beta": float(rng.random() * 0.2),
@@ -108,8 +110,9 @@ def main():
         skipped = [sid for _, sid, _ in imp.unsupported]
         exp2 = harness.drop_subjects(exp, skipped)
         bad = [k for k in exp2 if exp2[k] != got[k]]
-        print("round %3d %-4s thr=%-6d top=%-3d planb=%d out=%d em=%d bin=%d n=%-3d unsupported=%d %s  [%.0fs]" % (
-            rd, gname, conf["number_of_options_threshold"], conf["max_haplotypes_number_in_phase"], conf["planb"], out, em, bool(binf), n,
+        print("round %3d %-4s thr=%-6d top=%-3d planb=%d out=%d em=%d bin=%d save=%d n=%-3d unsupported=%d %s  [%.0fs]" % (
+            rd, gname, conf["number_of_options_threshold"], conf["max_haplotypes_number_in_phase"], conf["planb"], out, em, bool(binf),
+            bool(conf.get("save_space_mode")), n,
             len(skipped), "OK" if not bad else "DIFF " + str(bad), time.time() - t0), flush=True)
         if bad:
             os.makedirs(os.path.join(harness.ROOT, "gpurun_out"), exist_ok=True)

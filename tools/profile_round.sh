@@ -4,12 +4,12 @@
 # graph x 256 high-ambiguity subjects): kernel-trace stats of `bench.py --workload W`, and FETCH_SIZE / WRITE_SIZE in
 # SEPARATE --pmc passes (MI355X_MICROARCH.md, HBM section); SQ counters for config 2.  Summaries land in gpurun_out/prof_<tag>/.
 set -e
-TAG=${1:-r2}
+TAG=${1:-r3}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="--no-cpu-baseline --no-file"
+B="--no-cpu-baseline --no-file --min-seconds 0"
 run() {  # name, rocprof options, bench options
   rocprofv3 $2 --output-format csv -d $O/$1 -o r -- python3 $R/bench.py $3 > $O/$1.log 2>&1
 }
