@@ -21,6 +21,9 @@
 #include <sys/stat.h>
 #include <sys/types.h>
 #include <unistd.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include <algorithm>
 #include <atomic>
@@ -67,6 +70,41 @@ struct StreamRaces : RaceResolver {  // race pair -> prior matrix, shared by eve
   }
 };
 
+// a chunk's text: a growable byte buffer that can be enlarged WITHOUT touching the new bytes (std::string::resize would
+// zero a megabyte per chunk just to have it overwritten)
+struct TextBuf {
+  char *p = nullptr;
+  size_t n = 0, cap = 0;
+  TextBuf() {}
+  TextBuf(const TextBuf &) = delete;
+  TextBuf &operator=(const TextBuf &) = delete;
+  ~TextBuf() { free(p); }
+  const char *data() const { return p; }
+  char *data() { return p; }
+  size_t size() const { return n; }
+  bool empty() const { return n == 0; }
+  char back() const { return p[n - 1]; }
+  void clear() { n = 0; }
+  void reserve(size_t want) {
+    if (want <= cap) return;
+    size_t c = cap ? cap : (1u << 16);
+    while (c < want) c *= 2;
+    char *q = (char *)realloc(p, c);
+    if (!q) throw std::bad_alloc();
+    p = q;
+    cap = c;
+  }
+  void resize(size_t want) {  // new bytes are NOT initialised
+    reserve(want);
+    n = want;
+  }
+  void append(const char *src, size_t k) {
+    reserve(n + k);
+    memcpy(p + n, src, k);
+    n += k;
+  }
+};
+
 enum { CH_FREE = 0, CH_FILLING, CH_TOKENIZING, CH_TOKENIZED, CH_RUN_DONE, CH_DEVICE_DONE, CH_FORMATTED, CH_COMMITTED, CH_WRITTEN };
 
 struct Chunk {
@@ -78,7 +116,7 @@ struct Chunk {
   int slot_no = 0;
   grim_batch *batch = nullptr;
   uint64_t index = 0, first_line = 0;
-  std::string text;
+  TextBuf text;
   uint32_t n_lines = 0;
   std::vector<uint64_t> mark_off;  // byte offset of line k * granule
   // ranges
@@ -147,6 +185,23 @@ struct grim_stream {
   std::atomic<bool> failed{false};
   std::string err;
   std::vector<std::thread> workers;
+  // the reader's copy helpers: the caller's bytes are cold memory and one thread copies them at 8-10 GB/s -- slower than
+  // every other stage once GL parsing is on the device -- so a chunk's worth of input is copied by several threads at once
+  struct CopyJob {
+    const char *src = nullptr;
+    char *dst = nullptr;
+    size_t n = 0;
+    std::vector<uint32_t> nl;  // out: offsets (inside the piece) of the piece's line ends
+    uint32_t n_nl = 0;
+  };
+  std::vector<std::thread> copiers;
+  std::vector<CopyJob> copy_jobs;  // one slot per helper, plus one for the reader's own piece
+  std::mutex copy_mu;
+  std::condition_variable cv_copyjob;
+  uint64_t copy_gen = 0;           // bumped when the slots hold new jobs
+  std::atomic<int> copy_left{0};
+  bool copy_stop = false;
+  uint32_t avg_line = 128;         // bytes per line of the last chunk: how much to copy before counting
   std::thread dev_thread, copy_thread, fetch_thread;
   std::deque<Chunk *> copy_q, fetch_q;
   std::condition_variable cv_copy, cv_fetch;
@@ -261,7 +316,7 @@ static void run_tokenize(grim_stream *s, Chunk *c, uint32_t r) {
 // brings the results over on the copy stream and hands the chunk to the formatter.  A chunk whose results overflow a pool
 // is run again by the copy thread, synchronously: the pair pool grown to what the run asked for, else in halves (a single
 // subject always fits: the row pool is never smaller than one subject's worst case).
-static std::atomic<uint64_t> g_dbg_ns[8];  // [4] reader: scan + copy + dispatch, [5] reader: waiting for a free chunk slot, [6] next_records: waiting  // GRIM_DEBUG_STREAM: staging / load + launch (device thread), wait + stage 2 / fetch (copy thread)
+static std::atomic<uint64_t> g_dbg_ns[12];  // [4] reader: scan + copy + dispatch, [5] reader: waiting for a free chunk slot, [6] next_records: waiting  // GRIM_DEBUG_STREAM: staging / load + launch (device thread), wait + stage 2 / fetch (copy thread)
 
 struct PartStats {  // what a part's run adds to the stream's statistics (applied under the lock by the caller)
   double kernel_ms[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -719,6 +774,7 @@ static void run_write(grim_stream *s, Chunk *c, uint32_t r) {
 static void worker_loop(grim_stream *s) {
   for (;;) {
     Task t;
+    bool more = false;
     {
       std::unique_lock<std::mutex> lk(s->mu);
       for (;;) {
@@ -735,10 +791,64 @@ static void worker_loop(grim_stream *s) {
         }
         s->cv_work.wait(lk);
       }
+      more = !s->q_hi.empty() || !s->q_lo.empty();
     }
+    if (more) s->cv_work.notify_one();
     if (t.type == 0) run_tokenize(s, t.c, t.r);
     else if (t.type == 1) run_format(s, t.c, t.r);
     else run_write(s, t.c, t.r);
+  }
+}
+
+// copies a piece and notes where its line ends are (offsets inside the piece), so that the reader does not have to look at
+// the bytes again
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) static uint32_t copy_and_mark_avx2(char *dst, const char *src, size_t n, uint32_t *nl) {
+  const __m256i nlv = _mm256_set1_epi8('\n');
+  uint32_t k = 0;
+  size_t i = 0;
+  for (; i + 32 <= n; i += 32) {
+    const __m256i v = _mm256_loadu_si256((const __m256i *)(src + i));
+    _mm256_storeu_si256((__m256i *)(dst + i), v);
+    for (uint32_t m = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v, nlv)); m; m &= m - 1) nl[k++] = (uint32_t)i + (uint32_t)__builtin_ctz(m);
+  }
+  for (; i < n; ++i) {
+    dst[i] = src[i];
+    if (src[i] == '\n') nl[k++] = (uint32_t)i;
+  }
+  return k;
+}
+#endif
+static uint32_t copy_and_mark(char *dst, const char *src, size_t n, uint32_t *nl) {
+#if defined(__x86_64__)
+  static const bool avx2 = __builtin_cpu_supports("avx2");
+  if (avx2) return copy_and_mark_avx2(dst, src, n, nl);
+#endif
+  uint32_t k = 0;
+  for (size_t i = 0; i < n; ++i) {
+    dst[i] = src[i];
+    if (src[i] == '\n') nl[k++] = (uint32_t)i;
+  }
+  return k;
+}
+
+// a copy helper of the reader (see grim_stream::CopyJob): sleeps until the reader posts jobs, copies its slot's piece
+static void copier_loop(grim_stream *s, size_t k) {
+  uint64_t seen = 0;
+  for (;;) {
+    grim_stream::CopyJob *job = &s->copy_jobs[k];
+    size_t n = 0;
+    {
+      std::unique_lock<std::mutex> lk(s->copy_mu);
+      s->cv_copyjob.wait(lk, [&] { return s->copy_stop || s->copy_gen != seen; });
+      if (s->copy_stop) return;
+      seen = s->copy_gen;
+      n = job->n;
+    }
+    if (n) {  // (the slot is this helper's until it reports back: the reader waits for copy_left)
+      job->n_nl = copy_and_mark(job->dst, job->src, n, job->nl.data());
+      s->copy_left.fetch_sub(1, std::memory_order_release);
+    }
   }
 }
 
@@ -802,7 +912,8 @@ static int dispatch(grim_stream *s, Chunk *c) {
   c->state = CH_TOKENIZING;
   c->pending.store((int)R);
   for (uint32_t r = 0; r < R; ++r) s->q_lo.push_back(Task{0, c, r});
-  s->cv_work.notify_all();
+  s->cv_work.notify_one();  // (a worker that takes a task wakes the next one while tasks are left: waking all thirty from
+                            // here cost the reader 50 us per chunk)
   return 0;
 }
 
@@ -836,7 +947,6 @@ static uint32_t scan_lines_scalar(const LineScan &L, const char *p, uint64_t len
   return got;
 }
 #if defined(__x86_64__)
-#include <immintrin.h>
 __attribute__((target("avx2,popcnt"))) static uint32_t scan_lines_avx2(const LineScan &L, const char *p, uint64_t len, uint32_t want, uint32_t have,
                                                                         uint64_t base, uint64_t *used) {
   const __m256i nlv = _mm256_set1_epi8('\n');
@@ -977,24 +1087,81 @@ extern "C" int grim_stream_write(grim_stream *s, const char *text, uint64_t len)
     g_dbg_ns[5] += (uint64_t)(secs(tr0, tr1) * 1e9);
     Chunk *c = s->filling;
     // take whole lines until the chunk is full; a partial last line stays open (the next call continues it)
-    // Copy a block first, count its lines in the COPY: the caller's bytes are cold (a file's pages, a buffer just
-    // filled), the copy is in this core's cache -- counting in the source and copying afterwards read the cold bytes twice
-    // and cost 123 us per 10 000-line chunk, the slowest stage once GL parsing was on the device.  What a block holds
-    // beyond the chunk's last line is dropped again and goes to the next chunk.
+    // Copy first, count the lines in the COPY: the caller's bytes are cold (a file's pages, a buffer just filled), the copy
+    // is in cache.  A big input is copied a chunk's worth at a time -- as many bytes as the chunk will probably need, going
+    // by the last chunk's line length -- by this thread and its helpers together; what the copy holds beyond the chunk's last
+    // line is dropped again and goes to the next chunk, what it lacks comes with the next turn of the loop.
     const uint32_t want = s->chunk_lines - c->n_lines;
     const uint64_t base = c->text.size();
-    const uint64_t blk = std::min<uint64_t>(len - a, 64u << 10);
-    c->text.append(text + a, blk);
-    const LineScan L{s->granule, s->chunk_lines, &c->mark_off};
+    const uint64_t remaining = len - a;
+    uint64_t blk;
     uint64_t used = 0;
-    const uint32_t got = scan_lines(L, c->text.data() + base, blk, want, c->n_lines, base, &used);
-    c->text.resize(base + used);
+    uint32_t got = 0;
+    if (remaining >= (256u << 10) && !s->copiers.empty()) {
+      blk = std::min<uint64_t>(remaining, (uint64_t)want * s->avg_line + 4096);
+      c->text.resize(base + blk);
+      const size_t nh = s->copiers.size(), parts = nh + 1;
+      const size_t per = ((blk / parts) + 63) & ~(size_t)63;
+      grim_stream::CopyJob &mine = s->copy_jobs[nh];  // the reader's own piece: the first one
+      {
+        std::lock_guard<std::mutex> lk(s->copy_mu);
+        int jobs = 0;
+        for (size_t k = 0; k < nh; ++k) {
+          const size_t o = std::min<size_t>(blk, (k + 1) * per), e = std::min<size_t>(blk, (k + 2) * per);
+          grim_stream::CopyJob &j = s->copy_jobs[k];
+          j.src = text + a + o;
+          j.dst = c->text.data() + base + o;
+          j.n = e - o;
+          j.n_nl = 0;
+          if (j.nl.size() < j.n + 64) j.nl.resize(j.n + 64);
+          if (e > o) ++jobs;
+        }
+        s->copy_left.store(jobs);
+        ++s->copy_gen;
+      }
+      s->cv_copyjob.notify_all();
+      mine.n = std::min<size_t>(blk, per);
+      if (mine.nl.size() < mine.n + 64) mine.nl.resize(mine.n + 64);
+      mine.n_nl = copy_and_mark(c->text.data() + base, text + a, mine.n, mine.nl.data());
+      while (s->copy_left.load(std::memory_order_acquire) > 0) std::this_thread::yield();
+      const auto tr2 = Clock::now();
+      g_dbg_ns[8] += (uint64_t)(secs(tr1, tr2) * 1e9);
+      // the pieces in order: the chunk ends behind its `want`-th line end; every granule-th line start is a mark
+      used = blk;
+      bool full = false;
+      for (size_t q = 0; q < parts && !full; ++q) {
+        const grim_stream::CopyJob &j = q == 0 ? mine : s->copy_jobs[q - 1];
+        const uint64_t po = q == 0 ? 0 : std::min<size_t>(blk, q * per);
+        const uint32_t take = std::min<uint32_t>(j.n_nl, want - got);
+        // marks: line ends number `ln` (1-based in the chunk) with ln % granule == 0
+        uint32_t ln = c->n_lines + got;
+        uint32_t first = s->granule - ln % s->granule;  // the first of this piece's line ends that is a multiple
+        for (uint32_t i = first; i <= take; i += s->granule)
+          if (ln + i < s->chunk_lines) c->mark_off.push_back(base + po + j.nl[i - 1] + 1);
+        got += take;
+        if (got == want) {
+          used = po + j.nl[take - 1] + 1;
+          full = true;
+        }
+      }
+      c->text.resize(base + used);
+      g_dbg_ns[9] += (uint64_t)(secs(tr2, Clock::now()) * 1e9);
+    } else {
+      blk = std::min<uint64_t>(remaining, 64u << 10);
+      c->text.append(text + a, blk);
+      const LineScan L{s->granule, s->chunk_lines, &c->mark_off};
+      got = scan_lines(L, c->text.data() + base, blk, want, c->n_lines, base, &used);
+      c->text.resize(base + used);
+    }
     const uint64_t b = a + used;
     c->n_lines += got;
     a = b;
     if (c->n_lines >= s->chunk_lines) {
       s->filling = nullptr;
+      s->avg_line = (uint32_t)std::max<uint64_t>(16, c->text.size() / c->n_lines + 1);
+      const auto td0 = Clock::now();
       if (dispatch(s, c) != 0) return -1;
+      g_dbg_ns[7] += (uint64_t)(secs(td0, Clock::now()) * 1e9);
     }
     g_dbg_ns[4] += (uint64_t)(secs(tr1, Clock::now()) * 1e9);
   }
@@ -1346,6 +1513,14 @@ extern "C" grim_stream *grim_stream_open(grim_ctx *ctx, const grim_graph *g, con
   s->dev_thread = std::thread(device_loop, s);
   s->copy_thread = std::thread(copy_loop, s);
   s->fetch_thread = std::thread(fetch_loop, s);
+  {
+    // copy helpers of the reader: up to three, never more than the stream's share of the host's cores leaves room for
+    const char *e = getenv("GRIM_COPY_THREADS");
+    size_t nc = e ? (size_t)atoi(e) : (s->n_threads >= 8 ? 3u : s->n_threads >= 4 ? 1u : 0u);
+    if (nc > 7) nc = 7;
+    s->copy_jobs.resize(nc + 1);
+    for (size_t k = 0; k < nc; ++k) s->copiers.emplace_back(copier_loop, s, k);
+  }
   return s;
 }
 
@@ -1353,8 +1528,8 @@ extern "C" void grim_stream_free(grim_stream *s) {
   if (!s) return;
   if (getenv("GRIM_DEBUG_STREAM"))
     fprintf(stderr, "grim stream: device thread ms: staging %.3f load %.3f | copy thread ms: wait + stage 2 %.3f fetch %.3f | reader ms: work %.3f "
-            "waiting for a slot %.3f | consumer waiting %.3f over %llu chunks\n", g_dbg_ns[0] / 1e6, g_dbg_ns[1] / 1e6, g_dbg_ns[2] / 1e6,
-            g_dbg_ns[3] / 1e6, g_dbg_ns[4] / 1e6, g_dbg_ns[5] / 1e6, g_dbg_ns[6] / 1e6, (unsigned long long)s->st.chunks);
+            "(copy %.3f scan %.3f dispatch %.3f) waiting for a slot %.3f | consumer waiting %.3f over %llu chunks\n", g_dbg_ns[0] / 1e6, g_dbg_ns[1] / 1e6, g_dbg_ns[2] / 1e6,
+            g_dbg_ns[3] / 1e6, g_dbg_ns[4] / 1e6, g_dbg_ns[8] / 1e6, g_dbg_ns[9] / 1e6, g_dbg_ns[7] / 1e6, g_dbg_ns[5] / 1e6, g_dbg_ns[6] / 1e6, (unsigned long long)s->st.chunks);
   {
     std::lock_guard<std::mutex> lk(s->mu);
     s->stop = true;
@@ -1364,6 +1539,12 @@ extern "C" void grim_stream_free(grim_stream *s) {
     s->cv_fetch.notify_all();
     s->cv_slot.notify_all();
   }
+  {
+    std::lock_guard<std::mutex> lk(s->copy_mu);
+    s->copy_stop = true;
+  }
+  s->cv_copyjob.notify_all();
+  for (auto &t : s->copiers) t.join();
   for (auto &t : s->workers) t.join();
   if (s->dev_thread.joinable()) s->dev_thread.join();
   if (s->copy_thread.joinable()) s->copy_thread.join();
