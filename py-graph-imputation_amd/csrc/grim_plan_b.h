@@ -572,15 +572,27 @@ __device__ inline bool side_blocks(const DevArgs &A, WgShared &sh, const Slot &S
           key |= g.node_key[nd[b]];
         }
       }
-      for (int j = 0; j < P; ++j) {
-        double acc = g.freq[(uint64_t)nd[0] * P + j];
+      // four populations per step, every block's frequency loaded before the first product: top_push's LDS fences would
+      // otherwise put a memory round trip between one population and the next (the cross product is the bulk of Plan B)
+      for (int j0 = 0; j0 < P; j0 += 4) {
+        double fv[GRIM_MAXL][4];
 #pragma unroll
-        for (int b = 1; b < GRIM_MAXL; ++b)
-          if (b < nb) acc = acc * g.freq[(uint64_t)nd[b] * P + j] * GRIM_FACTOR_JOIN;
-        bool act = valid && acc > 0.0;
-        uint64_t tie = ((c * (uint64_t)P + (uint64_t)j) << 8) | (uint64_t)j;
-        // (a row of ONE block is answered by one look-up: graph names, not joined keys)
-        top_push(L, st, act, acc, acc * prior[j * P + j], tie, 0, (nb == 1 && g.order_bad) ? key | (1ull << GRIM_KEY_GRAPH_ORDER) : key);
+        for (int b = 0; b < GRIM_MAXL; ++b)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) fv[b][q] = (b < nb && j0 + q < P) ? g.freq[(uint64_t)nd[b] * P + j0 + q] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int j = j0 + q;
+          if (j >= P) break;
+          double acc = fv[0][q];
+#pragma unroll
+          for (int b = 1; b < GRIM_MAXL; ++b)
+            if (b < nb) acc = acc * fv[b][q] * GRIM_FACTOR_JOIN;
+          bool act = valid && acc > 0.0;
+          uint64_t tie = ((c * (uint64_t)P + (uint64_t)j) << 8) | (uint64_t)j;
+          // (a row of ONE block is answered by one look-up: graph names, not joined keys)
+          top_push(L, st, act, acc, acc * prior[j * P + j], tie, 0, (nb == 1 && g.order_bad) ? key | (1ull << GRIM_KEY_GRAPH_ORDER) : key);
+        }
       }
     }
   }

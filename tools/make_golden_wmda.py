@@ -72,7 +72,7 @@ def main():
     buf = io.StringIO(open(os.path.join(ref_work, "ref_stdout.txt")).read())
     print("reference: graph load + %d subjects in %.0f s" % (n, time.time() - t1), flush=True)
     os.makedirs(OUT, exist_ok=True)
-    shutil.copy(os.path.join(ref_work, "conf.json"), os.path.join(OUT, "conf.json"))
+    shutil.copy(os.path.join(ref_work, "conf.json"), os.path.join(OUT, "reference_conf.json"))  # not "conf.json": harness.scenarios() lists directories holding one
     shutil.copy(os.path.join(ref_work, "data", "subjects", "input.csv"), os.path.join(OUT, "input.csv"))
     for f in FILES:
         p = os.path.join(ref_work, "output", f)
