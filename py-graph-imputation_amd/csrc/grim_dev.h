@@ -84,12 +84,13 @@ struct DevArgs {
   uint32_t *queue;        // [0] general work counter [1] row head [2] plan-B list length [3] plan-B work counter
                           // [4] one-wave kernel work counter [5] its hand-over count [6] heavy plan-B subjects
                           // [7] its heavier hand-overs [8] pair pool head [9] / [10] work items of the one-wave /
-                          // workgroup table kernel [11] / [12] their work counters  (GRIM_NQ words)
+                          // bigger-item table kernels  (GRIM_NQ words; the rest is listed at GRIM_NQ)
   grim_subject_result *res;
   grim_row *rows;
   uint32_t *row_head;
   uint32_t row_cap;
   uint8_t *scratch;
+  uint32_t *wctr;               // work counters of the table kernels, GRIM_NSLICE per kernel, a 128-byte line each (slice_next)
   SlotLayout lay;
   uint32_t pair_cap, tab_cap, bset_cap, proj_cap;
   uint32_t *small_ctr;           // half-wave kernel: per wave {probes, frequency vectors}, plain stores; summed on request
@@ -120,8 +121,10 @@ struct DevArgs {
 };
 #define GRIM_F_NO_NODUP 2u       // DevArgs.flags (GRIM_NO_NODUP=1): the pair passes always run their dedup (test switch)
 #define GRIM_NQ 24               // u32 words of `queue` (the run state block is counters + queue):
-                                 // [13] bucket-start slots used [14] work units [15] their work counter
-                                 // [16] / [17] work counters of the split / merge kernel
+                                 // [13] bucket-start slots used [14] work units [15] units done by earlier launches of the run
+                                 // [12] items the workgroup split kernel took [21] the workgroup merge kernel [22] of those, with an
+                                 // overflowed bucket [23] their largest pair count  (diagnostics, GRIM_DEBUG_CLASSES=1)
+                                 // (the table kernels' own work counters are DevArgs.wctr)
 
 #ifndef GRIM_HEAVY_LOCI
 #define GRIM_HEAVY_LOCI 3
@@ -211,6 +214,36 @@ __device__ __forceinline__ uint64_t f64_ord(double x) {
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+// ---- work lists shared out through SLICED counters ----------------------------------------------------------------------
+// An atomic on ONE address costs ~12 ns whoever issues it, so a list of 13 000 items handed out one at a time through a
+// single counter to 4 000 waves is 0.2 ms of queueing -- each wave waits for all the others' turns.  The list is cut into
+// GRIM_NSLICE stretches with a counter each (own cache line); a wave starts at the stretch blockIdx.x picks and moves on
+// to the next one when a stretch is used up (so the tail is still shared by everybody).
+#define GRIM_NSLICE 16
+#define GRIM_SLICE_STRIDE 32  // u32 words between counters
+enum { GRIM_WL_T1 = 0, GRIM_WL_SPLIT_WAVE, GRIM_WL_MERGE_WAVE, GRIM_WL_SPLIT, GRIM_WL_MERGE, GRIM_WL_N };
+#define GRIM_WCTR_WORDS (GRIM_WL_N * GRIM_NSLICE * GRIM_SLICE_STRIDE)
+struct SliceWalk {
+  uint32_t s, tried;
+};
+// next item of a list of n for this WAVE (all lanes get the same answer), GRIM_NONE: the list is done
+__device__ __forceinline__ uint32_t slice_next(uint32_t *wctr, int list, uint32_t n, SliceWalk &sw) {
+  const uint32_t per = (n + GRIM_NSLICE - 1) / GRIM_NSLICE;
+  uint32_t *ctr = wctr + (uint32_t)list * GRIM_NSLICE * GRIM_SLICE_STRIDE;
+  while (sw.tried < GRIM_NSLICE) {
+    const uint32_t lo = sw.s * per, hi = lo + per < n ? lo + per : n;
+    if (lo < hi) {
+      uint32_t i = 0;
+      if (lane_id() == 0) i = atomicAdd(&ctr[sw.s * GRIM_SLICE_STRIDE], 1u);
+      i = __shfl(i, 0);
+      if (i < hi - lo) return lo + i;
+    }
+    sw.s = (sw.s + 1) % GRIM_NSLICE;
+    sw.tried++;
+  }
+  return GRIM_NONE;
+}
 
 // value of lane j (j wave-uniform): v_readlane, not the LDS-crossbar ds_bpermute that __shfl emits
 // for a run-time index

@@ -252,6 +252,7 @@ struct grim_ctx {
   // per batch cost more than the kernels)
   void *scratch;
   uint64_t scratch_bytes;
+  uint32_t *wctr;           // the table kernels' sliced work counters (grim_dev.h: slice_next), zeroed in front of every use
   // capacity batches a finished stream handed back: the next stream on this context takes them instead of
   // allocating (and pinning) a few hundred MB per slot again
   std::vector<grim_batch *> spare;
@@ -373,6 +374,16 @@ extern "C" grim_ctx *grim_create(int device_id) {
   c->n_cu = 256;
   c->scratch = nullptr;
   c->scratch_bytes = 0;
+  c->wctr = nullptr;
+  if (hipMalloc((void **)&c->wctr, 4 * GRIM_WCTR_WORDS) != hipSuccess) {
+    (void)hipGetLastError();
+    g_err = "grim_create: cannot allocate the work counters";
+    hipStreamDestroy(c->stream);
+    hipStreamDestroy(c->copy_stream);
+    hipStreamDestroy(c->up_stream);
+    delete c;
+    return nullptr;
+  }
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->n_cu = prop.multiProcessorCount;
   return c;
 }
@@ -385,6 +396,7 @@ extern "C" void grim_destroy(grim_ctx *c) {
   for (grim_batch *b : c->spare) batch_destroy(b);
   c->spare.clear();
   if (c->scratch) hipFree(c->scratch);
+  if (c->wctr) hipFree(c->wctr);
   hipStreamDestroy(c->stream);
   if (c->copy_stream) hipStreamDestroy(c->copy_stream);
   if (c->up_stream) hipStreamDestroy(c->up_stream);
@@ -1083,6 +1095,7 @@ static int bind_scratch(grim_batch *b) {
     c->scratch_bytes = b->scratch_need;
   }
   b->a.scratch = (uint8_t *)c->scratch;
+  b->a.wctr = c->wctr;
   return 0;
 }
 
@@ -1098,16 +1111,37 @@ static void enqueue_tables(grim_batch *b, hipEvent_t start, hipEvent_t stop) {
   if (g2 > b->n_slots) g2 = b->n_slots;  // one scratch slot per workgroup
   if (g1 == 0) g1 = 1;
   if (g2 == 0) g2 = 1;
-  const uint32_t g3 = (uint32_t)c->n_cu * (160u * 1024u / (uint32_t)sizeof(WaveTab<TAB_NB>) > 32u ? 32u : 160u * 1024u / (uint32_t)sizeof(WaveTab<TAB_NB>));  // resident waves of the bucket kernel
+  // resident waves of the bucket kernel (registers or LDS, whichever binds): its units are dealt round robin over the grid, a
+  // block that had to wait for a free slot would run its share after everybody else's
+  static int bucket_per_cu = 0;
+  if (bucket_per_cu == 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, grim_tables_bucket_kernel, 64, 0) != hipSuccess || nb <= 0) {
+      (void)hipGetLastError();
+      nb = 8;
+    }
+    bucket_per_cu = nb > 32 ? 32 : nb;
+  }
+  const uint32_t g3 = (uint32_t)c->n_cu * (uint32_t)bucket_per_cu;
+  // items of up to TW_MAXN pairs: a wave each, twelve split waves (LDS) / sixteen merge waves (registers) per CU
+  uint32_t g4 = (uint32_t)c->n_cu * (160u * 1024u / (uint32_t)sizeof(SplitWave)), g5 = (uint32_t)c->n_cu * 16u;
+  if (g4 > cand) g4 = cand;
+  if (g5 > cand) g5 = cand;
+  if (g4 == 0) g4 = 1;
+  if (g5 == 0) g5 = 1;
+  (void)hipMemsetAsync(c->wctr, 0, 4 * GRIM_WCTR_WORDS, c->stream);
   if (start && stop) {
     hipExtLaunchKernelGGL(grim_tables_wave_kernel, dim3(g1), dim3(64), 0, c->stream, start, nullptr, 0, A);
-    hipLaunchKernelGGL(grim_tables_split_kernel, dim3(g2), dim3(GRIM_WG), 0, c->stream, A);
-    hipLaunchKernelGGL(grim_tables_bucket_kernel, dim3(g3), dim3(64), 0, c->stream, A);
-    hipExtLaunchKernelGGL(grim_tables_merge_kernel, dim3(g2), dim3(GRIM_WG), 0, c->stream, nullptr, stop, 0, A);
   } else {
     hipLaunchKernelGGL(grim_tables_wave_kernel, dim3(g1), dim3(64), 0, c->stream, A);
-    hipLaunchKernelGGL(grim_tables_split_kernel, dim3(g2), dim3(GRIM_WG), 0, c->stream, A);
-    hipLaunchKernelGGL(grim_tables_bucket_kernel, dim3(g3), dim3(64), 0, c->stream, A);
+  }
+  hipLaunchKernelGGL(grim_tables_split_wave_kernel, dim3(g4), dim3(64), 0, c->stream, A);
+  hipLaunchKernelGGL(grim_tables_split_kernel, dim3(g2), dim3(GRIM_WG), 0, c->stream, A);
+  hipLaunchKernelGGL(grim_tables_bucket_kernel, dim3(g3), dim3(64), 0, c->stream, A);
+  hipLaunchKernelGGL(grim_tables_merge_wave_kernel, dim3(g5), dim3(64), 0, c->stream, A);
+  if (start && stop) {
+    hipExtLaunchKernelGGL(grim_tables_merge_kernel, dim3(g2), dim3(GRIM_WG), 0, c->stream, nullptr, stop, 0, A);
+  } else {
     hipLaunchKernelGGL(grim_tables_merge_kernel, dim3(g2), dim3(GRIM_WG), 0, c->stream, A);
   }
 }
@@ -1313,8 +1347,9 @@ int engine_batch_wait(grim_batch *b) {
   }
   static const int dbg_classes = env_int("GRIM_DEBUG_CLASSES", 0);
   if (dbg_classes)
-    fprintf(stderr, "grim classes: small %u medium %u general %u | medium->general %u (+%u heavier), to plan B %u (+%u heavy) | table items %u one-wave, %u bigger (%u work units), %u pair records | stage 1 %s\n",
-            b->n_small, b->n_medium, b->n_general, head[5], head[7], head[2], head[6], head[9], head[10], head[14], head[8], b->graph_state == 1 ? "replayed as a hipGraph" : "launched directly");
+    fprintf(stderr, "grim classes: small %u medium %u general %u | medium->general %u (+%u heavier), to plan B %u (+%u heavy) | table items %u one-wave, %u bigger (%u work units), %u pair records; workgroup merge: %u items (%u with an overflowed bucket), up to %u pairs; workgroup split: %u items | stage 1 %s\n",
+            b->n_small, b->n_medium, b->n_general, head[5], head[7], head[2], head[6], head[9], head[10], head[14], head[8], head[21], head[22], head[23], head[12],
+            b->graph_state == 1 ? "replayed as a hipGraph" : "launched directly");
   memcpy(b->counters, b->hstate, 64);
   b->small_ctr_pending = b->n_small + b->n_dev_lines > 0;
   for (int sh = 0; sh < 64; ++sh)
@@ -1326,9 +1361,9 @@ int engine_batch_wait(grim_batch *b) {
   fprintf(stderr, "grim stamps (us):");
   for (int k = 0; k < 16; ++k) fprintf(stderr, " [%d]%.0f", k, b->hstate[GRIM_STAMP_BASE + k] / 100.0);
   fprintf(stderr, "\n");
-  static const char *hname[8] = {"0 opening (0 side by side, 1 shared scan)", "1 us in sides by alleles", "2 subjects by alleles",
-                                 "3 subjects by accepted pairs", "4 subjects by scored pairs", "5 subjects by top-list entries",
-                                 "6 accepted pairs by accepted pairs", "7 us per subject by accepted pairs"};
+  static const char *hname[8] = {"0", "1", "2", "3 workgroup-merge items by pairs", "4 workgroup-split items by pairs",
+                                 "5 workgroup-split us by pairs", "6 workgroup-merge items by genotype groups",
+                                 "7 workgroup-merge us by pairs"};
   for (int h = 0; h < 8; ++h) {
     fprintf(stderr, "grim hist %s:", hname[h]);
     for (int k = 0; k < 24; ++k) fprintf(stderr, " %llu", b->hstate[GRIM_HIST_BASE + 24 * h + k]);

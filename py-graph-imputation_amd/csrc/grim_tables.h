@@ -30,7 +30,7 @@ struct WaveTab {
   uint64_t klo[N], khi[N]; // group keys
   uint32_t tab[2 * N];     // hash slots: the local pair that represents the group; afterwards the group sums (double[N])
   uint32_t skey[N];        // first pair (record index) of the group local pair i represents
-  uint32_t uidx[N];        // pair number (record index inside the work item) of local pair i, increasing
+  double cp[64 + 1];       // the probabilities of the chunk in hand, by lane; [64] = 0.0
   uint16_t rs[N + 2];      // run j -> its representative
 };
 struct WaveTabT1 : WaveTab<TAB_N> {
@@ -94,16 +94,19 @@ __device__ __forceinline__ uint64_t tab_hash(uint64_t lo, uint64_t hi) {
 }
 
 // ---- one wave groups n <= N pairs --------------------------------------------------------------------------------------
-// In: W.uidx[0..n) = the pairs' numbers IN INCREASING ORDER (n <= N <= 256), rec = the work item's records.  Out: the number
-// of groups ("runs", in no particular order); run j: first pair W.skey[W.rs[j]] & UM (the smallest number in the group = first
-// seen), sum ((double *)W.tab)[j] = its probabilities added in pair order (impute.py:497-543: the reference's dict updates).
+// In: the n <= N <= 256 pairs IN INCREASING ORDER of their numbers (registers, see below).  Out: the number of groups ("runs",
+// in no particular order); run j: first pair W.skey[W.rs[j]] & UM (the smallest number in the group = first seen), sum
+// ((double *)W.tab)[j] = its probabilities added in pair order (impute.py:497-543: the reference's dict updates).
 // 64 pairs at a time, in order: find-or-insert of the pair's key into an LDS hash table whose slot names the group's
 // representative (the pair that claimed it); the lanes of a chunk that share a representative are found with ballots over
-// the representative's bits; round r adds the r-th of them to the group's sum -- so a sum receives its terms in lane = pair
-// order, one chunk after the other, without sorting anything.  (Until round 2's last day this was a bitonic sort of
-// (slot, pair) per bucket followed by run sums: 36 LDS compare-exchange stages for 256 keys.)
+// the representative's bits, and the first of them adds the chunk's members to the group's sum one after the other -- so a
+// sum receives its terms in lane = pair order, one chunk after the other, without sorting anything.  (Until round 2's last
+// day this was a bitonic sort of (slot, pair) per bucket followed by run sums: 36 LDS compare-exchange stages for 256 keys.)
+// The records come in REGISTERS (R[c], U[c]: record and pair number of local pair 64 c + lane), loaded by the caller in one
+// go before anything else happens: a chunk-by-chunk gather inside the loop put a memory round trip in front of every chunk.
 template <int N>
-__device__ inline uint32_t wave_group_pairs(WaveTab<N> &W, int kind, int P, const PairRec *rec, uint32_t n) {
+__device__ inline uint32_t wave_group_pairs(WaveTab<N> &W, int kind, int P, const PairRec (&R)[N / 64], const uint32_t (&U)[N / 64],
+                                            uint32_t n) {
   const int lane = lane_id();
   const uint64_t lt = (1ull << lane) - 1ull;
   for (int i = lane; i < 2 * N; i += 64) W.tab[i] = GRIM_NONE;
@@ -111,18 +114,22 @@ __device__ inline uint32_t wave_group_pairs(WaveTab<N> &W, int kind, int P, cons
     W.prob[i] = 0.0;          // sum of the group pair i represents
     W.skey[i] = GRIM_NONE;    // ... and its first pair
   }
+  if (lane == 0) W.cp[64] = 0.0;
   WAVE_SYNC();
   volatile uint32_t *tab = W.tab;
   uint32_t nruns = 0;
-  for (uint32_t c0 = 0; c0 < n; c0 += 64) {
+#pragma unroll
+  for (int c = 0; c < N / 64; ++c) {
+    const uint32_t c0 = 64u * (uint32_t)c;
+    if (c0 >= n) break;
     const uint32_t i = c0 + lane;
     const bool act = i < n;
     uint32_t rep = 0, u = 0;
     double p = 0.0;
     uint64_t lo = 0, hi = 0;
     if (act) {
-      u = W.uidx[i];
-      const PairRec r = rec[u];
+      u = U[c];
+      const PairRec r = R[c];
       p = r.prob;
       tab_key(kind, P, r, lo, hi);
       W.klo[i] = lo;
@@ -159,11 +166,32 @@ __device__ inline uint32_t wave_group_pairs(WaveTab<N> &W, int kind, int P, cons
       same &= sbit ? m : ~m;
     }
     const uint32_t pos = (uint32_t)__popcll(same & lt);
-    if (act && pos == 0 && W.skey[rep] == GRIM_NONE) W.skey[rep] = u;  // chunks and lanes come in pair order
-    for (uint32_t r = 0; __ballot(act && pos >= r) != 0; ++r) {
-      if (act && pos == r) W.prob[rep] = W.prob[rep] + p;
-      WAVE_SYNC();
+    // The group's members in this chunk join its sum in lane = pair order.  Its FIRST lane does that for all of them, from
+    // the chunk's probabilities in LDS, four loads in flight per step: a bucket holds a handful of big groups as a rule (the
+    // 16 population pairs x 2 phases of one genotype), and a round per member -- an LDS read-add-write each, as this was
+    // until round 3 -- made the chunk's time the size of its biggest group times the LDS latency.
+    W.cp[lane] = p;
+    WAVE_SYNC();
+    if (act && pos == 0) {
+      if (W.skey[rep] == GRIM_NONE) W.skey[rep] = u;  // chunks and lanes come in pair order
+      double acc = W.prob[rep];
+      uint64_t m = same;
+      while (m) {
+        int b4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          b4[q] = m ? __builtin_ctzll(m) : 64;  // [64] holds 0.0: x + 0.0 == x for the positive sums here
+          m &= m - 1;                           // (0 stays 0)
+        }
+        const double p0 = W.cp[b4[0]], p1 = W.cp[b4[1]], p2 = W.cp[b4[2]], p3 = W.cp[b4[3]];
+        acc = acc + p0;
+        acc = acc + p1;
+        acc = acc + p2;
+        acc = acc + p3;
+      }
+      W.prob[rep] = acc;
     }
+    WAVE_SYNC();
     const uint64_t cm = __ballot(claimed);
     if (claimed) W.rs[nruns + (uint32_t)__popcll(cm & lt)] = (uint16_t)i;
     nruns += (uint32_t)__popcll(cm);
@@ -178,15 +206,18 @@ __device__ inline uint32_t wave_group_pairs(WaveTab<N> &W, int kind, int P, cons
 // population pairs of n <= N pairs (few groups, many members each: rounds would serialise): one LANE per cell walks the
 // pairs in order.  Same outputs as wave_group_pairs.
 template <int N>
-__device__ inline uint32_t wave_group_cells(WaveTab<N> &W, int P, const PairRec *rec, uint32_t n) {
+__device__ inline uint32_t wave_group_cells(WaveTab<N> &W, int P, const PairRec (&R)[N / 64], uint32_t n) {
   const int lane = lane_id();
   const uint64_t lt = (1ull << lane) - 1ull;
   uint16_t *cellid = (uint16_t *)W.klo;
-  for (uint32_t i = lane; i < n; i += 64) {
-    const PairRec r = rec[W.uidx[i]];
-    const uint32_t a = ENT_POP(r.e1), b = ENT_POP(r.e2);
-    cellid[i] = (uint16_t)((a < b ? a : b) * (uint32_t)P + (a < b ? b : a));
-    W.prob[i] = r.prob;
+#pragma unroll
+  for (int c = 0; c < N / 64; ++c) {
+    const uint32_t i = 64u * (uint32_t)c + lane;
+    if (i < n) {
+      const uint32_t a = ENT_POP(R[c].e1), b = ENT_POP(R[c].e2);
+      cellid[i] = (uint16_t)((a < b ? a : b) * (uint32_t)P + (a < b ? b : a));
+      W.prob[i] = R[c].prob;
+    }
   }
   WAVE_SYNC();
   double *gsum = (double *)W.tab;
@@ -198,7 +229,7 @@ __device__ inline uint32_t wave_group_cells(WaveTab<N> &W, int P, const PairRec 
     uint32_t first = GRIM_NONE;
     for (uint32_t i = 0; i < n; ++i)
       if (cellid[i] == cell) {
-        if (first == GRIM_NONE) first = W.uidx[i];
+        if (first == GRIM_NONE) first = i;  // (the one-wave kernel's pairs are numbered 0..n-1)
         s = s + W.prob[i];
       }
     const uint64_t m = __ballot(first != GRIM_NONE);
@@ -237,11 +268,16 @@ __device__ inline void tables_wave(const DevArgs &A, WaveTabT1 &W, const TabWork
   constexpr uint32_t UM = (1u << TAB_SH) - 1u;
   grim_subject_result *out = A.res + w.si;
   const double *gsum = (const double *)W.tab;
-  for (uint32_t i = lane; i < n; i += 64) W.uidx[i] = i;
-  WAVE_SYNC();
+  PairRec R[TAB_N / 64];  // the item's records, once for the three groupings
+  uint32_t U[TAB_N / 64];
+#pragma unroll
+  for (int c = 0; c < TAB_N / 64; ++c) {
+    U[c] = 64u * (uint32_t)c + lane;
+    if (U[c] < n) R[c] = rec[U[c]];
+  }
   // ---- population pairs (both pops files share the sums) -------------------------------------------------------------
   {
-    const uint32_t nq = wave_group_cells(W, P, rec, n);
+    const uint32_t nq = wave_group_cells(W, P, R, n);
     for (uint32_t j = lane; j < nq; j += 64) W.hd[j] = (uint16_t)(W.skey[W.rs[j]] & UM);
     WAVE_SYNC();
     for (int t = 0; t < 2; ++t) {
@@ -285,7 +321,7 @@ __device__ inline void tables_wave(const DevArgs &A, WaveTabT1 &W, const TabWork
       if (own) {
         ng = n;
       } else {
-        ng = wave_group_pairs(W, t == 0 ? 0 : 1, P, rec, n);
+        ng = wave_group_pairs(W, t == 0 ? 0 : 1, P, R, U, n);
         for (uint32_t j = lane; j < ng; j += 64) W.hd[j] = (uint16_t)(W.skey[W.rs[j]] & UM);
         WAVE_SYNC();
       }
@@ -328,22 +364,14 @@ __global__ __launch_bounds__(64) void grim_tables_wave_kernel(DevArgs A) {
   __shared__ WaveTabT1 W;
   const uint32_t n_items = A.queue[9];  // written by the kernels before this one in the stream
   RowBlock rb = {0, 0, GRIM_ROW_GRAB};
-  // one item per visit to the work counter: an item keeps a wave busy for 50-150 us (the kernel is instruction-issue bound,
-  // 14 waves share a CU's four SIMDs), so the counter's ~12 ns per atomic is noise and the tail stays one item long
-  constexpr uint32_t CH = 1;
+  // one item per visit to the (sliced) work counters: the tail stays one item long
+  SliceWalk sw = {blockIdx.x % GRIM_NSLICE, 0};
   for (;;) {
-    uint32_t w0 = 0;
-    if (lane_id() == 0) w0 = atomicAdd(A.queue + 11, CH);
-    w0 = __shfl(w0, 0);
-    if (w0 >= n_items) break;
-    const uint32_t w1 = w0 + CH < n_items ? w0 + CH : n_items;
-    for (uint32_t w = w0; w < w1; ++w) {
-      const TabWork item = A.t1_list[w];
-      tables_wave(A, W, item, rb);
-    }
+    const uint32_t w = slice_next(A.wctr, GRIM_WL_T1, n_items, sw);
+    if (w == GRIM_NONE) break;
+    const TabWork item = A.t1_list[w];
+    tables_wave(A, W, item, rb);
   }
-  // a later launch (after Plan B) continues behind this one's items: the counter must not run past the list
-  if (lane_id() == 0) atomicMin(A.queue + 11, n_items);
 }
 
 // ---- the workgroup kernel ----------------------------------------------------------------------------------------------
@@ -774,24 +802,6 @@ __device__ inline void tab_split_table(const DevArgs &A, TabShared &sh, const Sl
   }
   uint32_t nb = 1;
   while (nb * TAB_DIV < nU && nb < TAB_MAXB) nb <<= 1;
-  for (uint32_t b = tid; b <= nb; b += GRIM_WG) sh.bcnt[b] = 0;
-  if (tid == 0) {
-    uint32_t base = atomicAdd(A.queue + 13, nb + 1), ubase = atomicAdd(A.queue + 14, nb);
-    if (base + nb + 1 > A.tboff_cap || ubase + nb > A.tunits_cap) {
-      atomicExch(&A.counters[4], 1ull);  // reported like a row-pool overflow: the caller splits the batch
-      base = ubase = GRIM_NONE;
-    }
-    sh.bc[4] = base;
-    sh.bc[5] = ubase;
-    TabAux &x = A.taux[item];
-    x.boff[t] = base;
-    x.nb[t] = base == GRIM_NONE ? 0 : nb;
-    x.ng[t] = 0;
-    x.overflow[t] = 0;
-  }
-  __syncthreads();
-  const uint32_t base = sh.bc[4], ubase = sh.bc[5];
-  if (base == GRIM_NONE) return;
   // STABLE deal: wave w owns the w-th quarter of the item's pairs and keeps its own count / cursor per bucket, so a
   // bucket receives its pairs in increasing pair number -- the bucket kernel then adds a group's probabilities in the
   // reference's order without sorting.
@@ -805,26 +815,77 @@ __device__ inline void tab_split_table(const DevArgs &A, TabShared &sh, const Sl
   }
   __syncthreads();
   const uint32_t u0 = wv * q, u1 = u0 + q < nU ? u0 + q : nU;
-  for (uint32_t u = u0 + lane; u < u1; u += 64) {
-    uint64_t lo, hi;
-    tab_key(kind, P, rec[u], lo, hi);
-    const uint32_t b = (uint32_t)(tab_hash(lo, hi) >> 40) & (nb - 1);  // high bits: the waves' slot hash uses the low ones
-    S.svb[u] = b;
-    const uint32_t k = wv * nb + b;
-    atomicAdd((uint32_t *)wc + (k >> 1), 1u << (16 * (k & 1)));  // q < 65536: a half never carries into its neighbour
-  }
-  __syncthreads();
-  // bucket sizes; per-wave counts become cursors relative to the bucket's start
-  for (uint32_t b2 = tid; b2 < nb; b2 += GRIM_WG) {
-    uint32_t run = 0;
-    for (int w2 = 0; w2 < GRIM_NWAVE; ++w2) {
-      const uint32_t c = wc[w2 * nb + b2];
-      wc[w2 * nb + b2] = (uint16_t)run;
-      run += c;
+  for (uint32_t ub = u0 + lane; ub < u1; ub += 4 * 64) {  // four records in flight per lane (the stores below may alias them
+    PairRec r4[4];                                         // for all the compiler knows: it would not hoist the loads itself)
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4)
+      if (ub + 64 * k4 < u1) r4[k4] = rec[ub + 64 * k4];
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+      const uint32_t u = ub + 64 * k4;
+      if (u >= u1) break;
+      uint64_t lo, hi;
+      tab_key(kind, P, r4[k4], lo, hi);
+      const uint32_t h12 = (uint32_t)(tab_hash(lo, hi) >> 40) & (TAB_MAXB - 1);  // high bits: the waves' slot hash uses the low ones
+      S.svb[u] = h12;  // the bucket is its low bits, however many buckets there are in the end
+      const uint32_t k = wv * nb + (h12 & (nb - 1));
+      atomicAdd((uint32_t *)wc + (k >> 1), 1u << (16 * (k & 1)));  // q < 65536: a half never carries into its neighbour
     }
-    sh.bcnt[b2] = run;
   }
   __syncthreads();
+  // bucket sizes; per-wave counts become cursors relative to the bucket's start.  A bucket beyond a wave's arena (TAB_NB
+  // pairs: big groups gather -- 16 population pairs x 2 phases of one genotype) would send the whole table down the HBM
+  // path of the merge kernel, a millisecond for the items that have them: the deal is repeated with twice the buckets
+  // instead, up to three times (the bucket numbers are the low bits of what S.svb holds: no record is read again).
+  for (int attempt = 0;; ++attempt) {
+    if (tid == 0) sh.bc[6] = 0;
+    __syncthreads();
+    uint32_t big = 0;
+    for (uint32_t b2 = tid; b2 < nb; b2 += GRIM_WG) {
+      uint32_t run = 0;
+      for (int w2 = 0; w2 < GRIM_NWAVE; ++w2) {
+        const uint32_t c = wc[w2 * nb + b2];
+        wc[w2 * nb + b2] = (uint16_t)run;
+        run += c;
+      }
+      sh.bcnt[b2] = run;
+      big |= run > TAB_NB ? 1u : 0u;
+    }
+    if (big) sh.bc[6] = 1;
+    __syncthreads();
+    const bool again = sh.bc[6] != 0 && attempt < 3 && nb < TAB_MAXB;
+    __syncthreads();
+    if (!again) break;
+    nb <<= 1;
+    {
+      uint32_t *wz = (uint32_t *)wc;
+      for (uint32_t k = tid; k < (GRIM_NWAVE * nb + 1) / 2; k += GRIM_WG) wz[k] = 0;
+    }
+    __syncthreads();
+    for (uint32_t u = u0 + lane; u < u1; u += 64) {
+      const uint32_t k = wv * nb + (S.svb[u] & (nb - 1));
+      atomicAdd((uint32_t *)wc + (k >> 1), 1u << (16 * (k & 1)));
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    uint32_t base = atomicAdd(A.queue + 13, nb + 1), ubase = atomicAdd(A.queue + 14, nb);
+    if (base + nb + 1 > A.tboff_cap || ubase + nb > A.tunits_cap) {
+      atomicExch(&A.counters[4], 1ull);  // reported like a row-pool overflow: the caller splits the batch
+      base = ubase = GRIM_NONE;
+    }
+    sh.bc[4] = base;
+    sh.bc[5] = ubase;
+    TabAux &x = A.taux[item];
+    x.boff[t] = base;
+    x.nb[t] = base == GRIM_NONE ? 0 : nb;
+    x.ng[t] = 0;
+    x.overflow[t] = 0;
+    sh.bcnt[nb] = 0;
+  }
+  __syncthreads();
+  const uint32_t base = sh.bc[4], ubase = sh.bc[5];
+  if (base == GRIM_NONE) return;
   {  // exclusive scan in place: bcnt[b] = first position of bucket b
     const uint32_t per = (nb + GRIM_WG - 1) / GRIM_WG;
     uint32_t b0 = tid * per, b1 = b0 + per;
@@ -862,7 +923,7 @@ __device__ inline void tab_split_table(const DevArgs &A, TabShared &sh, const Sl
     for (int k = 0; k < 4; ++k) {
       const uint32_t u = c0 + k * 64 + lane;
       act[k] = u < u1;
-      bk[k] = act[k] ? S.svb[u] : 0u;
+      bk[k] = act[k] ? S.svb[u] & (nb - 1) : 0u;
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) same[k] = __ballot(act[k]);
@@ -937,13 +998,24 @@ __device__ inline void tab_split_pops(const DevArgs &A, TabShared &sh, const Slo
     }
     __syncthreads();
     const uint32_t u0 = wv * q, u1 = u0 + q < nU ? u0 + q : nU;
-    for (uint32_t u = u0 + lane; u < u1; u += 64) {
-      const PairRec r = rec[u];
-      const uint32_t a = ENT_POP(r.e1), b = ENT_POP(r.e2);
-      const uint32_t cell = (a < b ? a : b) * (uint32_t)P + (a < b ? b : a);
-      S.svb[u] = cell;
-      const uint32_t k = wv * nc + cell;
-      atomicAdd((uint32_t *)wc + (k >> 1), 1u << (16 * (k & 1)));
+    for (uint32_t ub = u0 + lane; ub < u1; ub += 4 * 64) {
+      uint32_t ea[4], eb[4];
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4)
+        if (ub + 64 * k4 < u1) {
+          ea[k4] = rec[ub + 64 * k4].e1;
+          eb[k4] = rec[ub + 64 * k4].e2;
+        }
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        const uint32_t u = ub + 64 * k4;
+        if (u >= u1) break;
+        const uint32_t a = ENT_POP(ea[k4]), b = ENT_POP(eb[k4]);
+        const uint32_t cell = (a < b ? a : b) * (uint32_t)P + (a < b ? b : a);
+        S.svb[u] = cell;
+        const uint32_t k = wv * nc + cell;
+        atomicAdd((uint32_t *)wc + (k >> 1), 1u << (16 * (k & 1)));
+      }
     }
     __syncthreads();
     // (a cell holds most of an item's pairs as a rule: the cursors need 32 bits, unlike a bucket's)
@@ -1068,6 +1140,422 @@ __device__ inline void tab_split_pops(const DevArgs &A, TabShared &sh, const Slo
   __syncthreads();
 }
 
+// ---- work items of up to TW_MAXN pairs: a WAVE splits them, a wave merges them ----------------------------------------
+// Nine in ten of the bigger work items of the mixed workloads hold a few hundred to a few thousand pairs: a workgroup
+// spends its time on them in barriers (a dozen per table) with three of its four waves idle in the serial stretches, and a
+// CU holds three such workgroups.  One wave per item needs no barrier, the three partitions (cells, genotype buckets,
+// haplotype-pair buckets) share ONE sweep that computes keys and one that deals the pairs out, and a CU holds twelve
+// items.  Same bucket function, same stable deal, same units as tab_split_table / tab_split_pops -- the bucket kernel
+// and either merge kernel cannot tell which split kernel an item went through.
+#define TW_MAXN 4096u   // pairs of an item a wave splits
+#define TW_MAXB 64u     // ... into at most this many buckets per table (a lane each)
+#define TW_MAXC 64u     // population cells (P <= 8)
+#define TW_MAXG 1024u   // groups the merge wave holds in registers at a time (16 per lane)
+#define TW_MERGE_MAXG 16384u  // groups per table of an item the merge wave takes (in batches of TW_MAXG)
+static_assert(TW_MAXN / TAB_DIV <= TW_MAXB && TW_MAXB <= 256, "a wave-split item's buckets; the pairs' 8 hash bits");
+static_assert(TW_MAXB <= 64 && TW_MAXC <= 64, "one lane per bucket / cell");
+
+struct SplitWave {
+  uint8_t bk[2][TW_MAXN];  // eight hash bits of pair u's key in the genotype / haplotype-pair table: the bucket is the low ones
+  uint8_t cell[TW_MAXN];   // its population cell
+  uint32_t st[2][TW_MAXB + 1], cur[2][TW_MAXB];  // bucket starts (counts shifted by one before the scan), cursors
+  uint32_t cst[TW_MAXC + 1], ccur[TW_MAXC];
+};
+
+__device__ __forceinline__ bool tw_split_item(const DevArgs &A, const TabWork &w) {
+  return w.n <= TW_MAXN && (uint32_t)(A.g.P * A.g.P) <= TW_MAXC && !(A.flags & GRIM_F_TABLES_HBM);
+}
+// the merge wave takes an item -- whichever kernel split it -- when every table it has to rank was split, kept to its
+// buckets, and has few enough groups and rows
+__device__ __forceinline__ bool tw_merge_item(const DevArgs &A, const TabWork &w, const TabAux &x) {
+  if ((uint32_t)(A.g.P * A.g.P) > TW_MAXC || (A.flags & GRIM_F_TABLES_HBM) || x.cell_base == GRIM_NONE) return false;
+  for (int t = 0; t < 2; ++t) {
+    if (!((w.mask >> t) & 1u)) continue;
+    const bool on = t == 0 ? A.prm.out_muug : A.prm.out_haps;
+    if (!(t == 0 || on)) continue;
+    if (x.nb[t] == 0 || x.overflow[t] || x.ng[t] > TW_MERGE_MAXG) return false;
+    if (on && (x.ng[t] < A.prm.n_results ? x.ng[t] : A.prm.n_results) > 64u) return false;
+  }
+  return true;
+}
+
+// lanes of the chunk with my id (ids below 2^nbits), as a mask
+__device__ __forceinline__ uint64_t tw_same(bool act, uint32_t id, int nbits) {
+  uint64_t same = __ballot(act);
+  for (int bit = 0; bit < nbits; ++bit) {
+    const bool sbit = (id >> bit) & 1u;
+    const uint64_t m = __ballot(act && sbit);
+    same &= sbit ? m : ~m;
+  }
+  return same;
+}
+
+__device__ inline void split_wave(const DevArgs &A, SplitWave &W, const TabWork &w, uint32_t item) {
+  const int lane = lane_id();
+  const uint64_t lt = (1ull << lane) - 1ull;
+  const int P = A.g.P;
+  const uint32_t ncell = (uint32_t)(P * P);
+  const PairRec *rec = A.ppool + w.off;
+  const uint32_t nU = w.n;
+  TabAux &x = A.taux[item];
+  bool split[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int kind = t == 0 ? 0 : (A.prm.em_mr ? 2 : 1);
+    const bool active = ((w.mask >> t) & 1u) && !(t == 1 && !A.prm.out_haps);
+    split[t] = active && !(kind == 2 || (kind == 1 && P == 1));
+    if (active && !split[t] && lane == 0) x.nb[t] = 0;  // every pair its own group: nothing to split (the workgroup merge kernel's)
+  }
+  uint32_t nb0 = 1;
+  while (nb0 * TAB_DIV < nU && nb0 < TW_MAXB) nb0 <<= 1;
+  uint32_t nbt[2] = {nb0, nb0};  // buckets per table (a table whose buckets overflow gets more, see below)
+  int cbits = 0;
+  while ((1u << cbits) < ncell) ++cbits;
+  // ---- sweep 1: cell and buckets of every pair, counts ---------------------------------------------------------------
+  W.st[0][lane] = W.st[1][lane] = 0;
+  W.cst[lane] = 0;
+  if (lane == 0) W.cst[TW_MAXC] = W.st[0][TW_MAXB] = W.st[1][TW_MAXB] = 0;
+  W.cur[0][lane] = W.cur[1][lane] = 0;
+  W.ccur[lane] = 0;
+  WAVE_SYNC();
+  for (uint32_t ub = lane; ub < nU; ub += 4 * 64) {  // four records in flight per lane
+    PairRec r4[4];
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4)
+      if (ub + 64 * k4 < nU) r4[k4] = rec[ub + 64 * k4];
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+      const uint32_t u = ub + 64 * k4;
+      if (u >= nU) break;
+      const PairRec &r = r4[k4];
+      const uint32_t a = ENT_POP(r.e1), b = ENT_POP(r.e2);
+      const uint32_t cell = (a < b ? a : b) * (uint32_t)P + (a < b ? b : a);
+      W.cell[u] = (uint8_t)cell;
+      atomicAdd(&W.cst[cell + 1], 1u);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if (!split[t]) continue;
+        uint64_t lo, hi;
+        tab_key(t, P, r, lo, hi);  // kind 0 for the genotype table, kind 1 for the haplotype-pair table
+        const uint32_t h8 = (uint32_t)(tab_hash(lo, hi) >> 40) & 255u;
+        W.bk[t][u] = (uint8_t)h8;
+        atomicAdd(&W.st[t][(h8 & (nb0 - 1)) + 1], 1u);
+      }
+    }
+  }
+  WAVE_SYNC();
+  // ---- starts; bucket-start slots and work units of the whole item in one go -----------------------------------------
+  uint32_t big[2] = {0, 0};
+  const uint32_t ccount = W.cst[lane + 1];  // lane = cell
+  const uint32_t cincl = wave_incl_scan(ccount);
+  uint32_t bcount[2] = {0, 0};
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    if (!split[t]) continue;
+    for (;;) {
+      bcount[t] = lane < (int)nbt[t] ? W.st[t][lane + 1] : 0u;
+      big[t] = __ballot(bcount[t] > TAB_NB) != 0 ? 1u : 0u;
+      if (!big[t] || nbt[t] >= TW_MAXB) break;
+      // a bucket beyond the bucket kernel's arena (big groups gather): twice the buckets, counted again from the hash bits
+      nbt[t] <<= 1;
+      WAVE_SYNC();
+      W.st[t][lane + 1] = 0;
+      WAVE_SYNC();
+      for (uint32_t u = lane; u < nU; u += 64) atomicAdd(&W.st[t][(W.bk[t][u] & (nbt[t] - 1)) + 1], 1u);
+      WAVE_SYNC();
+    }
+    const uint32_t incl = wave_incl_scan(bcount[t]);
+    WAVE_SYNC();
+    if (lane < (int)nbt[t]) W.st[t][lane + 1] = incl;
+  }
+  WAVE_SYNC();
+  W.cst[lane + 1] = cincl;
+  WAVE_SYNC();
+  const uint64_t cell_m = __ballot(lane < (int)ncell && ccount > 0);
+  const uint32_t n_tab = (split[0] ? 1u : 0u) + (split[1] ? 1u : 0u);
+  const uint32_t nb_all = (split[0] ? nbt[0] : 0u) + (split[1] ? nbt[1] : 0u);
+  const uint32_t need_off = ncell + 1 + nb_all + n_tab, need_units = nb_all + (uint32_t)__popcll(cell_m);
+  uint32_t base = 0, ubase = 0;
+  if (lane == 0) {
+    base = atomicAdd(A.queue + 13, need_off);
+    ubase = atomicAdd(A.queue + 14, need_units);
+    if (base + need_off > A.tboff_cap || ubase + need_units > A.tunits_cap) {
+      atomicExch(&A.counters[4], 1ull);  // reported like a row-pool overflow: the caller splits the batch
+      base = GRIM_NONE;
+    }
+    x.cell_base = base;
+  }
+  base = __shfl(base, 0);
+  ubase = __shfl(ubase, 0);
+  if (base == GRIM_NONE) {
+    if (lane == 0) {
+      if (split[0]) x.nb[0] = 0;
+      if (split[1]) x.nb[1] = 0;
+    }
+    return;
+  }
+  uint32_t tb_base[2] = {GRIM_NONE, GRIM_NONE}, tu_base[2] = {0, 0};
+  {
+    uint32_t ob = base + ncell + 1, ou = ubase;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      if (!split[t]) continue;
+      tb_base[t] = ob;
+      tu_base[t] = ou;
+      ob += nbt[t] + 1;
+      ou += nbt[t];
+      if (lane == 0) {
+        x.boff[t] = tb_base[t];
+        x.nb[t] = nbt[t];
+        x.ng[t] = 0;
+        x.overflow[t] = big[t];
+        A.tboff[tb_base[t] + nbt[t]] = nU;
+      }
+      if (lane < (int)nbt[t]) A.tboff[tb_base[t] + lane] = W.st[t][lane];
+    }
+    // population cells: starts, empty records, a unit per non-empty cell
+    if (lane < (int)ncell) {
+      A.tboff[base + lane] = W.cst[lane];
+      CellRec cr;
+      cr.sum = 0.0;
+      cr.first = GRIM_NONE;
+      cr.pad = 0;
+      A.tcell[base + lane] = cr;
+    }
+    if (lane == 0) A.tboff[base + ncell] = nU;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      if (!split[t] || lane >= (int)nbt[t]) continue;
+      TabUnit un;
+      un.item = item;
+      un.tb = ((uint32_t)t << 28) | (uint32_t)lane;
+      un.off = w.off;
+      un.lo = W.st[t][lane];
+      un.n = bcount[t];
+      un.pad[0] = un.pad[1] = un.pad[2] = 0;
+      A.tunits[tu_base[t] + lane] = un;
+    }
+    if ((cell_m >> lane) & 1ull) {
+      TabUnit un;
+      un.item = item;
+      un.tb = (2u << 28) | (uint32_t)lane;
+      un.off = w.off;
+      un.lo = W.cst[lane];
+      un.n = ccount;
+      un.pad[0] = un.pad[1] = un.pad[2] = 0;
+      A.tunits[ou + (uint32_t)__popcll(cell_m & lt)] = un;
+    }
+  }
+  int nbits[2] = {0, 0};
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+    while ((1u << nbits[t]) < nbt[t]) ++nbits[t];
+  // ---- sweep 2: the stable deal, chunk after chunk in pair order ------------------------------------------------------
+  uint32_t *order = A.psort + 2ull * A.tstride + w.off;
+  double *pp = A.pprob + w.off;
+  uint32_t *dst0 = A.psort + w.off, *dst1 = A.psort + (uint64_t)A.tstride + w.off;
+  for (uint32_t cb = 0; cb < nU; cb += 4 * 64) {
+   double pr4[4];
+#pragma unroll
+   for (int k4 = 0; k4 < 4; ++k4) pr4[k4] = cb + 64 * k4 + lane < nU ? rec[cb + 64 * k4 + lane].prob : 0.0;
+#pragma unroll
+   for (int k4 = 0; k4 < 4; ++k4) {
+    const uint32_t c0 = cb + 64 * k4;
+    if (c0 >= nU) break;
+    const uint32_t u = c0 + lane;
+    const bool act = u < nU;
+    const double pr = pr4[k4];
+    if (ncell > 1) {
+      const uint32_t id = act ? W.cell[u] : 0u;
+      const uint64_t same = tw_same(act, id, cbits);
+      if (act) {
+        const uint32_t rank = (uint32_t)__popcll(same & lt), cnt = (uint32_t)__popcll(same);
+        const uint32_t cur = W.ccur[id];
+        const uint32_t pos = W.cst[id] + cur + rank;
+        if (pos < nU) {
+          order[pos] = u;
+          pp[pos] = pr;
+        }
+        if (rank + 1 == cnt) W.ccur[id] = cur + cnt;
+      }
+    } else if (act) {
+      order[u] = u;
+      pp[u] = pr;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      if (!split[t]) continue;
+      const uint32_t id = act ? W.bk[t][u] & (nbt[t] - 1) : 0u;
+      const uint64_t same = tw_same(act, id, nbits[t]);
+      if (act) {
+        const uint32_t rank = (uint32_t)__popcll(same & lt), cnt = (uint32_t)__popcll(same);
+        const uint32_t cur = W.cur[t][id];
+        const uint32_t pos = W.st[t][id] + cur + rank;
+        if (pos < nU) (t == 0 ? dst0 : dst1)[pos] = u;
+        if (rank + 1 == cnt) W.cur[t][id] = cur + cnt;
+      }
+    }
+    WAVE_SYNC();
+   }
+  }
+}
+
+__global__ __launch_bounds__(64) void grim_tables_split_wave_kernel(DevArgs A) {
+  __shared__ SplitWave W;
+  const uint32_t n_items = A.queue[10];
+  SliceWalk sw = {blockIdx.x % GRIM_NSLICE, 0};
+  for (;;) {
+    const uint32_t item = slice_next(A.wctr, GRIM_WL_SPLIT_WAVE, n_items, sw);
+    if (item == GRIM_NONE) break;
+    const TabWork w = A.t2_list[item];
+    if (!tw_split_item(A, w)) continue;  // the workgroup split kernel's
+    split_wave(A, W, w, item);
+    WAVE_SYNC();
+  }
+}
+
+// merge of an item the wave split: cells ranked across the lanes; a table's groups (<= TW_MAXG, any order) sit 16 to a
+// lane in registers and the rows wanted are picked best first -- round r takes the best group after round r-1's in the
+// order (sum descending, first pair ascending), the order tab_rank_grp ranks by.
+__device__ inline void merge_wave(const DevArgs &A, const TabWork &w, const TabAux &x, RowBlock &rb) {
+  const int lane = lane_id();
+  const int P = A.g.P;
+  const uint32_t ncell = (uint32_t)(P * P);
+  const PairRec *rec = A.ppool + w.off;
+  const uint32_t mask = w.mask;
+  grim_subject_result *out = A.res + w.si;
+  {
+    CellRec me;
+    me.sum = 0.0;
+    me.first = GRIM_NONE;
+    if (lane < (int)ncell) me = A.tcell[x.cell_base + lane];
+    const bool has = me.first != GRIM_NONE;
+    const uint32_t nq = (uint32_t)__popcll(__ballot(has));
+    uint32_t rank = 0;
+    for (uint32_t c2 = 0; c2 < ncell; ++c2) {
+      const double os = __shfl(me.sum, (int)c2);
+      const uint32_t of = __shfl(me.first, (int)c2);
+      if (of != GRIM_NONE && (int)c2 != lane && (os > me.sum || (os == me.sum && of < me.first))) ++rank;
+    }
+    const uint32_t nrow = nq < A.prm.n_pop_results ? nq : A.prm.n_pop_results;
+    for (int t = 0; t < 2; ++t) {
+      if (!((mask >> t) & 1u)) continue;
+      const int table = t == 0 ? GRIM_T_UMUG_POPS : GRIM_T_PMUG_POPS;
+      const bool on = t == 0 ? A.prm.out_muug : A.prm.out_haps;
+      uint32_t want = nrow;
+      if (t == 1 && A.prm.em_mr) want = nq < 1 ? nq : 1;
+      if (!on) want = 0;
+      const uint32_t off = wave_alloc_rows(A, rb, want);
+      if (lane == 0) {
+        out->row_off[table] = off == GRIM_NONE ? 0 : off;
+        out->n_rows[table] = off == GRIM_NONE ? 0 : want;
+      }
+      if (off == GRIM_NONE || want == 0 || !has || rank >= want) continue;
+      const PairRec pr = rec[me.first];
+      uint32_t a = ENT_POP(pr.e1), b = ENT_POP(pr.e2);
+      if (t == 0 && A.prm.pop_rank[a] > A.prm.pop_rank[b]) {
+        const uint32_t y = a;
+        a = b;
+        b = y;
+      }
+      grim_row r;
+      r.a = a; r.b = b; r.prob = me.sum; r.popa = a; r.popb = b;
+      A.rows[off + rank] = r;
+    }
+  }
+  for (int t = 0; t < 2; ++t) {
+    if (!((mask >> t) & 1u)) continue;
+    const int table = t == 0 ? GRIM_T_UMUG : GRIM_T_PMUG;
+    const bool on = t == 0 ? A.prm.out_muug : A.prm.out_haps;
+    uint32_t ng = 0, want = 0;
+    if (t == 0 || on) {
+      ng = x.ng[t];
+      want = on ? (ng < A.prm.n_results ? ng : A.prm.n_results) : 0;
+    }
+    const uint32_t off = wave_alloc_rows(A, rb, want);
+    if (lane == 0) {
+      if (t == 0) out->n_genotypes = ng;
+      out->row_off[table] = off == GRIM_NONE ? 0 : off;
+      out->n_rows[table] = off == GRIM_NONE ? 0 : want;
+    }
+    if (off == GRIM_NONE || want == 0) continue;
+    const GrpRec *grp = A.pgrp + (uint64_t)t * A.tstride + w.off;
+    constexpr int PER = (int)(TW_MAXG / 64);
+    // lane r keeps the r-th best group seen so far (ws, wh); a batch of TW_MAXG groups at a time joins them and the best
+    // `want` of the union are picked again
+    double ws = -1.0;
+    uint32_t wh = GRIM_NONE;
+    for (uint32_t g0 = 0; g0 < ng; g0 += TW_MAXG) {
+      double s[PER + 1];
+      uint32_t h[PER + 1];
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        const uint32_t g = g0 + (uint32_t)lane + 64u * (uint32_t)k;
+        s[k] = -1.0;  // below every sum
+        h[k] = GRIM_NONE;
+        if (g < ng) {
+          const GrpRec r = grp[g];
+          s[k] = r.sum;
+          h[k] = r.head;
+        }
+      }
+      s[PER] = ws;  // the best of the batches before
+      h[PER] = wh;
+      double prev_s = 0.0;
+      uint32_t prev_h = 0;
+      for (uint32_t r = 0; r < want; ++r) {
+        double bs = -2.0;
+        uint32_t bh = GRIM_NONE;
+#pragma unroll
+        for (int k = 0; k <= PER; ++k) {
+          const bool after = r == 0 || s[k] < prev_s || (s[k] == prev_s && h[k] > prev_h);
+          const bool better = s[k] >= 0.0 && after && (s[k] > bs || (s[k] == bs && h[k] < bh));
+          bs = better ? s[k] : bs;
+          bh = better ? h[k] : bh;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+          const double os = __shfl_xor(bs, d);
+          const uint32_t oh = __shfl_xor(bh, d);
+          const bool take = os > bs || (os == bs && oh < bh);
+          bs = take ? os : bs;
+          bh = take ? oh : bh;
+        }
+        prev_s = bs;
+        prev_h = bh;
+        if (lane == (int)r) {
+          ws = bs;
+          wh = bh;
+        }
+      }
+    }
+    if (lane < (int)want) {
+      const PairRec pr = rec[wh];
+      grim_row row;
+      row.a = pr.k1;
+      row.b = pr.k2;
+      row.prob = ws;
+      row.popa = ENT_POP(pr.e1);
+      row.popb = ENT_POP(pr.e2);
+      A.rows[off + lane] = row;
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void grim_tables_merge_wave_kernel(DevArgs A) {
+  const uint32_t n_items = A.queue[10];
+  RowBlock rb = {0, 0, GRIM_ROW_GRAB};
+  SliceWalk sw = {blockIdx.x % GRIM_NSLICE, 0};
+  for (;;) {
+    const uint32_t item = slice_next(A.wctr, GRIM_WL_MERGE_WAVE, n_items, sw);
+    if (item == GRIM_NONE) break;
+    const TabWork w = A.t2_list[item];
+    const TabAux x = A.taux[item];
+    if (!tw_merge_item(A, w, x)) continue;  // the workgroup merge kernel's
+    merge_wave(A, w, x, rb);
+  }
+}
+
 #ifndef GRIM_TAB_WG_PER_CU
 #define GRIM_TAB_WG_PER_CU 3
 #endif
@@ -1088,15 +1576,23 @@ __global__ __launch_bounds__(GRIM_WG, GRIM_TAB_WG_PER_CU) void grim_tables_split
     sh.wcnt = arena.wcnt;
   }
   __syncthreads();
+  SliceWalk sw = {blockIdx.x % GRIM_NSLICE, 0};  // (wave 0's: the others follow what it finds)
   for (;;) {
-    if (tid == 0) sh.bc[3] = atomicAdd(A.queue + 16, 1u);
+    if (tid < 64) {
+      const uint32_t nx = slice_next(A.wctr, GRIM_WL_SPLIT, n_items, sw);
+      if (tid == 0) sh.bc[3] = nx;
+    }
     __syncthreads();
     const uint32_t item = sh.bc[3];
     __syncthreads();
-    if (item >= n_items) break;
+    if (item == GRIM_NONE) break;
     if (tid < (int)(sizeof(TabWork) / 4)) ((uint32_t *)&sh.work)[tid] = ((const uint32_t *)&A.t2_list[item])[tid];
     __syncthreads();
     const TabWork w = sh.work;
+    if (tw_split_item(A, w)) continue;  // grim_tables_split_wave_kernel's
+    const unsigned long long t_item = STAMP_NOW();
+    (void)t_item;
+    if (tid == 0) atomicAdd(A.queue + 12, 1u);  // (GRIM_DEBUG_CLASSES=1 prints it)
     tab_split_pops(A, sh, S, w, item);
     for (int t = 0; t < 2; ++t) {
       if (!((w.mask >> t) & 1u)) continue;
@@ -1109,8 +1605,9 @@ __global__ __launch_bounds__(GRIM_WG, GRIM_TAB_WG_PER_CU) void grim_tables_split
       tab_split_table(A, sh, S, w, item, t, kind);
     }
     __syncthreads();
+    HIST(4, w.n, 1);
+    HIST(5, w.n, (STAMP_NOW() - t_item) / 100);
   }
-  if (tid == 0) atomicMin(A.queue + 16, n_items);  // a later launch continues behind this one's items
 }
 
 // second kernel: one wave = one work unit at a time.  The units are dealt to the waves round robin: a shared work
@@ -1128,34 +1625,66 @@ __global__ __launch_bounds__(64) void grim_tables_bucket_kernel(DevArgs A) {
   const uint32_t nwg = gridDim.x, q8 = nwg / 8, r8 = nwg % 8, xcd = blockIdx.x % 8;
   const uint32_t vid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + blockIdx.x / 8;
   // The chain unit header -> pair numbers -> records -> (grouping) -> group counter -> group records is a row of dependent
-  // memory round trips; the NEXT unit's header and pair numbers are fetched while this unit's group counter is on its way.
-  uint32_t k = A.queue[15] + vid;
-  TabUnit un;
-  uint32_t pre[TAB_NB / 64];  // the unit's pair numbers, lane + 64 i
-  auto fetch = [&](uint32_t kk, TabUnit &u, uint32_t (&idx)[TAB_NB / 64]) {
-    u.n = 0;
-    u.tb = 0;
-    if (kk < n_units) {
-      u = A.tunits[kk];
-      if ((u.tb >> 28) < 2 && u.n <= TAB_NB) {
-        const uint32_t *src = A.psort + (uint64_t)(u.tb >> 28) * A.tstride + u.off + u.lo;
-#pragma unroll
-        for (int i = 0; i < TAB_NB / 64; ++i) idx[i] = (uint32_t)(lane + 64 * i) < u.n ? src[lane + 64 * i] : 0u;
-      }
-    }
+  // memory round trips, and a unit is small (~80 pairs): taken one after the other they ARE the kernel's time.  So the loop is
+  // a software pipeline over this wave's units i = 0, 1, ...: while unit i is grouped in LDS, the records of unit i+1, the
+  // pair numbers of unit i+2 and the header of unit i+3 are on their way, and the groups of unit i-1 are written -- its
+  // place in the table's group list (an atomic on the item's counter) was asked for a unit ago.
+  constexpr int NC = TAB_NB / 64;
+  const uint32_t k0 = A.queue[15] + vid;
+  auto load_hdr = [&](uint32_t kk, TabUnit &u) {
+    u.item = 0; u.tb = 0; u.off = 0; u.lo = 0; u.n = 0;
+    if (kk < n_units) u = A.tunits[kk];
   };
-  fetch(k, un, pre);
-  while (k < n_units) {
+  auto is_bucket = [&](const TabUnit &u) { return (u.tb >> 28) < 2 && u.n > 0 && u.n <= TAB_NB; };
+  auto load_idx = [&](const TabUnit &u, uint32_t (&idx)[NC]) {
+    if (!is_bucket(u)) return;
+    const uint32_t *src = A.psort + (uint64_t)(u.tb >> 28) * A.tstride + u.off + u.lo;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) idx[i] = (uint32_t)(lane + 64 * i) < u.n ? src[lane + 64 * i] : 0u;
+  };
+  auto load_rec = [&](const TabUnit &u, const uint32_t (&idx)[NC], PairRec (&R)[NC]) {
+    if (!is_bucket(u)) return;
+    const PairRec *rec = A.ppool + u.off;
+#pragma unroll
+    for (int i = 0; i < NC; ++i)
+      if ((uint32_t)(lane + 64 * i) < u.n) R[i] = rec[idx[i]];
+  };
+  TabUnit un, un1, un2, un3;
+  uint32_t idx[NC] = {}, idx1[NC] = {}, idx2[NC] = {};
+  PairRec R[NC], R1[NC];
+  load_hdr(k0, un);
+  load_hdr(k0 + nwg, un1);
+  load_hdr(k0 + 2 * nwg, un2);
+  load_idx(un, idx);
+  load_idx(un1, idx1);
+  load_rec(un, idx, R);
+  // groups of the unit before, waiting for their place: sums and first pairs, 64 j + lane
+  double ps[NC];
+  uint32_t ph[NC];
+  uint32_t p_n = 0, p_g0 = 0;
+  GrpRec *p_dst = nullptr;
+  for (uint32_t k = k0; k < n_units; k += nwg) {
+    load_rec(un1, idx1, R1);
+    load_idx(un2, idx2);
+    load_hdr(k + 3 * nwg, un3);
+    if (p_n) {  // the unit before: its place has arrived
+#pragma unroll
+      for (int i = 0; i < NC; ++i) {
+        const uint32_t j = (uint32_t)(lane + 64 * i);
+        if (j < p_n) {
+          GrpRec gr;
+          gr.sum = ps[i];
+          gr.head = ph[i];
+          gr.pad = 0;
+          p_dst[p_g0 + j] = gr;
+        }
+      }
+      p_n = 0;
+    }
     TabAux &x = A.taux[un.item];
     const uint32_t t = un.tb >> 28, n = un.n;
-    TabUnit nxt;
-    uint32_t npre[TAB_NB / 64];
     if (n == 0) {
-      k += nwg;
-      fetch(k, un, pre);
-      continue;
-    }
-    if (t == 2) {  // a population cell: the left-to-right sum of its probabilities
+    } else if (t == 2) {  // a population cell: the left-to-right sum of its probabilities
       const double s = wave_chain(A.pprob + un.off + un.lo, n);
       if (lane == 0) {
         CellRec cr;
@@ -1164,39 +1693,48 @@ __global__ __launch_bounds__(64) void grim_tables_bucket_kernel(DevArgs A) {
         cr.pad = 0;
         A.tcell[x.cell_base + (un.tb & 0x0FFFFFFFu)] = cr;
       }
-      k += nwg;
-      fetch(k, un, pre);
-      continue;
-    }
-    if (n > TAB_NB) {  // a bucket the arena cannot hold: the merge kernel takes the HBM path for this table
+    } else if (n > TAB_NB) {  // a bucket the arena cannot hold: the merge kernel takes the HBM path for this table
       if (lane == 0) atomicExch(&x.overflow[t], 1u);
-      k += nwg;
-      fetch(k, un, pre);
-      continue;
-    }
+    } else {
+      const uint32_t nruns = wave_group_pairs(W, t == 0 ? 0 : 1, P, R, idx, n);
+      uint32_t g0 = 0;
+      if (lane == 0) g0 = atomicAdd(&x.ng[t], nruns);
+      const double *gs = (const double *)W.tab;
 #pragma unroll
-    for (int i = 0; i < TAB_NB / 64; ++i)
-      if ((uint32_t)(lane + 64 * i) < n) W.uidx[lane + 64 * i] = pre[i];
-    WAVE_SYNC();
-    const uint32_t nruns = wave_group_pairs(W, t == 0 ? 0 : 1, P, A.ppool + un.off, n);
-    uint32_t g0 = 0;
-    if (lane == 0) g0 = atomicAdd(&x.ng[t], nruns);
-    fetch(k + nwg, nxt, npre);  // in flight together with the counter
-    g0 = __shfl(g0, 0);
-    const double *gs = (const double *)W.tab;
-    GrpRec *dst = A.pgrp + (uint64_t)t * A.tstride + un.off + g0;
-    for (uint32_t j = lane; j < nruns; j += 64) {
-      GrpRec gr;
-      gr.sum = gs[j];
-      gr.head = W.skey[W.rs[j]] & UM;
-      gr.pad = 0;
-      dst[j] = gr;
+      for (int i = 0; i < NC; ++i) {
+        const uint32_t j = (uint32_t)(lane + 64 * i);
+        if (j < nruns) {
+          ps[i] = gs[j];
+          ph[i] = W.skey[W.rs[j]] & UM;
+        }
+      }
+      WAVE_SYNC();
+      p_n = nruns;
+      p_g0 = __shfl(g0, 0);
+      p_dst = A.pgrp + (uint64_t)t * A.tstride + un.off;
     }
-    WAVE_SYNC();
-    k += nwg;
-    un = nxt;
+    un = un1;
+    un1 = un2;
+    un2 = un3;
 #pragma unroll
-    for (int i = 0; i < TAB_NB / 64; ++i) pre[i] = npre[i];
+    for (int i = 0; i < NC; ++i) {
+      idx[i] = idx1[i];
+      idx1[i] = idx2[i];
+      R[i] = R1[i];
+    }
+  }
+  if (p_n) {
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      const uint32_t j = (uint32_t)(lane + 64 * i);
+      if (j < p_n) {
+        GrpRec gr;
+        gr.sum = ps[i];
+        gr.head = ph[i];
+        gr.pad = 0;
+        p_dst[p_g0 + j] = gr;
+      }
+    }
   }
 }
 
@@ -1277,6 +1815,7 @@ __device__ inline bool tab_rank_grp(const DevArgs &A, TabShared &sh, const Slot 
   for (int shift = 52; shift >= 28 && !resolved; shift -= 12) {
     for (int i = tid; i < 4096; i += GRIM_WG) h12[i] = 0;
     __syncthreads();
+#pragma unroll 4
     for (uint32_t g = tid; g < ng; g += GRIM_WG) {
       const uint64_t k = ~f64_ord(grp[g].sum);
       if ((k & himask) == prefix) atomicAdd(&h12[(uint32_t)(k >> shift) & 4095u], 1u);
@@ -1320,6 +1859,7 @@ __device__ inline bool tab_rank_grp(const DevArgs &A, TabShared &sh, const Slot 
   uint32_t *lg = lh + 1024;                // [1024]
   if (tid == 0) sh.bc[4] = 0;
   __syncthreads();
+#pragma unroll 4
   for (uint32_t g = tid; g < ng; g += GRIM_WG) {
     const GrpRec r = grp[g];
     const uint64_t k = ~f64_ord(r.sum);
@@ -1420,16 +1960,28 @@ __global__ __launch_bounds__(GRIM_WG, GRIM_TAB_WG_PER_CU) void grim_tables_merge
     sh.qcell = arena.qcell;
   }
   __syncthreads();
+  SliceWalk sw = {blockIdx.x % GRIM_NSLICE, 0};  // (wave 0's: the others follow what it finds)
   for (;;) {
-    if (tid == 0) sh.bc[3] = atomicAdd(A.queue + 17, 1u);
+    if (tid < 64) {
+      const uint32_t nx = slice_next(A.wctr, GRIM_WL_MERGE, n_items, sw);
+      if (tid == 0) sh.bc[3] = nx;
+    }
     __syncthreads();
     const uint32_t item = sh.bc[3];
     __syncthreads();
-    if (item >= n_items) break;
+    if (item == GRIM_NONE) break;
     if (tid < (int)(sizeof(TabWork) / 4)) ((uint32_t *)&sh.work)[tid] = ((const uint32_t *)&A.t2_list[item])[tid];
     __syncthreads();
     const TabWork w = sh.work;
     const TabAux x = A.taux[item];
+    if (tw_merge_item(A, w, x)) continue;  // grim_tables_merge_wave_kernel's
+    const unsigned long long t_item = STAMP_NOW();
+    (void)t_item;
+    if (tid == 0) {  // (GRIM_DEBUG_CLASSES=1 prints these)
+      atomicAdd(A.queue + 21, 1u);
+      if (x.overflow[0] | x.overflow[1]) atomicAdd(A.queue + 22, 1u);
+      atomicMax(A.queue + 23, w.n);
+    }
     const PairRec *rec = A.ppool + w.off;
     const uint32_t nU = w.n;
     grim_subject_result *out = A.res + w.si;
@@ -1478,6 +2030,8 @@ __global__ __launch_bounds__(GRIM_WG, GRIM_TAB_WG_PER_CU) void grim_tables_merge
         }
       __syncthreads();
     }
+    HIST(3, nU, 1);
+    HIST(6, x.ng[0], 1);
+    HIST(7, nU, (STAMP_NOW() - t_item) / 100);
   }
-  if (tid == 0) atomicMin(A.queue + 17, n_items);
 }
