@@ -875,6 +875,38 @@ int engine_batch_grow_pool(grim_batch *b, uint64_t max_records) {
   return 1;
 }
 
+// The ROW pool of a batch whose run ran out of rows (not of pairs, buckets or work units): twice as many, up to max_rows.
+// 1: grown -- the caller runs the same subjects again (their inputs are still in the pinned arena); 0: not the row pool, or
+// already at the bound (the caller halves the range).  engine_batch_hint_rows: the same lesson for a sibling batch of the
+// stream before its next load.  Only ever called between runs of the batch.
+static int batch_set_rows(grim_batch *b, uint64_t rows) {
+  const uint64_t old = b->row_limit;
+  b->row_limit = rows;
+  const EnginePlan pl = b->plan;
+  if (!batch_plan(b, pl)) {
+    (void)hipGetLastError();
+    b->row_limit = old;
+    if (!batch_plan(b, pl)) set_err(b->ctx, "grim_batch: device allocation failed while growing the row pool");
+    return 0;
+  }
+  return 1;
+}
+int engine_batch_grow_rows(grim_batch *b, uint64_t max_rows) {
+  if (!b || b->rows_used < b->a.row_cap || b->row_limit >= max_rows) return 0;
+  use_device(b->ctx->device);
+  uint64_t want = b->row_limit * 2;
+  if (want > max_rows) want = max_rows;
+  if (want > 0x7FFFFFF0ull) want = 0x7FFFFFF0ull;
+  if (want <= b->row_limit) return 0;
+  return batch_set_rows(b, want);
+}
+uint64_t engine_batch_row_limit(const grim_batch *b) { return b ? b->row_limit : 0; }
+void engine_batch_hint_rows(grim_batch *b, uint64_t rows) {
+  if (!b || rows <= b->row_limit) return;
+  use_device(b->ctx->device);
+  (void)batch_set_rows(b, rows);
+}
+
 // what a batch learnt about its pair pool (0: the default sizing was enough) / the same lesson for a sibling batch of the
 // same stream, which will see the same kind of chunks: its next load sizes the pool accordingly instead of finding out
 uint64_t engine_batch_pool_want(const grim_batch *b) { return b ? b->pool_want : 0; }
@@ -962,7 +994,9 @@ int engine_batch_load(grim_batch *b, const EngineLoad *ld) {
     if (b->pool_want > R) R = b->pool_want;  // an earlier run of this batch ran out: it said how much it needed
     if (R > 0x7FFFFFF0ull) R = 0x7FFFFFF0ull;
     const uint64_t items = 2ull * ld->n_subj < R / 256 + 1 ? 2ull * ld->n_subj : R / 256 + 1;  // bigger work items at most
-    uint64_t cap_b = R / 8 + (items + 1) * ((uint64_t)P * P + 4), cap_u = R / 8 + items * 64 + 1024;  // buckets hold >= 24 pairs on average, two tables
+    // buckets: a table starts with fewer than n / 64 and the split kernels may re-deal it into twice as many up to three
+    // times (n / 8 at most), two tables
+    uint64_t cap_b = R / 4 + (items + 1) * ((uint64_t)P * P + 4), cap_u = R / 4 + items * 64 + 1024;
     if (cap_b > R + 4096) cap_b = R + 4096;
     uint64_t o = 0;
     auto take = [&](uint64_t bytes) { uint64_t r = o; o = align256(o + bytes); return r; };

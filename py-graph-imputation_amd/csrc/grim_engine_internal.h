@@ -79,3 +79,6 @@ uint32_t engine_graph_order_bad(const grim_graph *g);
 uint64_t engine_batch_pool_want(const grim_batch *b);
 void engine_batch_hint_pool(grim_batch *b, uint64_t records);
 int engine_batch_grow_pool(grim_batch *b, uint64_t max_records);
+int engine_batch_grow_rows(grim_batch *b, uint64_t max_rows);
+uint64_t engine_batch_row_limit(const grim_batch *b);
+void engine_batch_hint_rows(grim_batch *b, uint64_t rows);

@@ -165,6 +165,8 @@ struct grim_stream {
   uint64_t rows_per_chunk = 0;
   grim_devdict *devdict = nullptr;  // device tokenizer: the dictionary on the device (null: every line is tokenised on the host)
   bool dev_tok = false;
+  std::atomic<uint64_t> rows_hint{0};  // row-pool size a chunk of this stream grew to (0: the opening size did)
+  uint64_t rows_max = 0;               // ... and how far it may grow (0: the caller fixed the size)
   std::atomic<uint64_t> pool_hint{0};  // pair-pool records a chunk of this stream needed: every later load starts there
   // input segments (grim_stream_segment): cumulative text bytes at the end of each, known once its chunks are committed
   uint32_t cur_segment = 0;
@@ -345,6 +347,7 @@ static int stage_part(grim_stream *s, Chunk *c, uint32_t lo, uint32_t hi, size_t
     if (c->tr[r].n_tok && c->range_first_line[r] < hi && c->range_first_line[r + 1] > lo) tok_used = c->slab_off[r] + c->tr[r].n_tok;
   const auto tp1 = Clock::now();
   engine_batch_hint_pool(b, s->pool_hint.load());  // what an earlier chunk of this stream had to grow its pair pool to
+  engine_batch_hint_rows(b, s->rows_hint.load());  // ... and its row pool
   int lrc;
   {
     // the race table only grows: a batch that holds fewer matrices than the table has gets all of them again
@@ -459,12 +462,22 @@ static int finish_part(grim_stream *s, Chunk *c, uint32_t lo, uint32_t hi, bool 
   part_stats(s, b, ps);
   if (getenv("GRIM_DEBUG_STREAM") && atoi(getenv("GRIM_DEBUG_STREAM")) > 1)
     fprintf(stderr, "grim stream: chunk %llu lines [%u,%u) small %zu medium %zu general %u -> rc %d, rows %u (pool %llu)\n",
-            (unsigned long long)c->index, lo, hi, rng[1] - rng[0], rng[3] - rng[2], ng, rc, grim_batch_total_rows(b), (unsigned long long)s->rows_per_chunk);
+            (unsigned long long)c->index, lo, hi, rng[1] - rng[0], rng[3] - rng[2], ng, rc, grim_batch_total_rows(b), (unsigned long long)engine_batch_row_limit(b));
   if (rc == -2) {
     // subjects with tens of thousands of accepted pairs: give the table kernels' pair pool what the run asked for (up to
     // 256 M records, 21 GB with the arrays sized by it) and run the same subjects again, before halving the batch
     ++ps.reruns;
     if (engine_batch_grow_pool(b, 256ull << 20)) return device_part_sync(s, c, lo, hi, whole, ps);
+    // the ROWS ran out (subjects that fill their tables: ~40 rows each where the pool opens with 32 per line): twice the pool,
+    // for this slot now and for the others at their next load, up to every subject's worst case -- a stream of such
+    // subjects would otherwise run every chunk three times (whole, then in halves)
+    if (s->rows_max && engine_batch_grow_rows(b, s->rows_max)) {
+      const uint64_t have = engine_batch_row_limit(b);
+      uint64_t cur = s->rows_hint.load();
+      while (have > cur && !s->rows_hint.compare_exchange_weak(cur, have)) {
+      }
+      return device_part_sync(s, c, lo, hi, whole, ps);
+    }
     if (hi - lo <= 1) return -1;  // cannot happen: see grim_stream_open
     const uint32_t mid = lo + (hi - lo) / 2;
     const int r1 = device_part_sync(s, c, lo, mid, false, ps);
@@ -1448,6 +1461,9 @@ extern "C" grim_stream *grim_stream_open(grim_ctx *ctx, const grim_graph *g, con
   if (rows < floor_rows && !(opts->rows_exact && opts->rows_per_chunk)) rows = floor_rows;
   if (rows > 0x7FFFFFF0ull) rows = 0x7FFFFFF0ull;
   s->rows_per_chunk = rows;
+  // the pool grows when a chunk runs out of rows -- unless the caller set its size (a memory bound is a bound; the tests
+  // use it to drive the split-and-rerun path): up to every line's worst case
+  s->rows_max = opts->rows_per_chunk ? 0 : std::max<uint64_t>(rows, std::min<uint64_t>(0x7FFFFFF0ull, floor_rows + per * s->chunk_lines));
   // Device tokenizer: lines without a '/' list are parsed on the GPU when their subjects are the half-wave kernel's (one
   // population, five loci, no phase masks); GRIM_DEVICE_TOKENIZER=0 keeps every line on the host (tests hold the two together)
   {

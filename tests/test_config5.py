@@ -94,3 +94,26 @@ def test_full_size_graph_properties(monkeypatch):
     got4, _, _ = harness.run_product(name, conf, lines, tag="w5h", quiet=True)
     for k in got:
         assert got4[k] == got[k], k
+
+
+def test_row_pool_grows_instead_of_running_every_chunk_three_times(monkeypatch):
+    """Subjects that fill their tables (~40 rows each) against the stream's opening row pool of 32 rows per line: the first
+    chunks overflow, the pool doubles (for the slot at once, for the other slots at their next load) and the later chunks
+    run ONCE -- not whole + two halves each, which is what a 2 048-line config-5 stream did until round 3 (77 ms per step
+    against 34 ms of kernels).  Same bytes as one big chunk whose pool never overflows."""
+    n_haps = 20000
+    wmda_scale.ensure(n_haps)
+    name = wmda_scale.name_of(n_haps)
+    conf = wmda_scale.conf()
+    lines = wmda_scale.subjects(3300, seed=11, n_haps=n_haps)
+    whole, _, imp0 = harness.run_product(name, conf, lines, tag="w5r0", quiet=True)
+    assert imp0.last_stats["reruns"] <= 1  # (the pair pool of the table kernels may have to grow once: counted too)
+    monkeypatch.setenv("GRIM_CHUNK_LINES", "512")
+    monkeypatch.setenv("GRIM_STREAM_DEPTH", "2")
+    got, _, imp = harness.run_product(name, conf, lines, tag="w5r1", quiet=True)
+    for k in whole:
+        assert got[k] == whole[k], k
+    st = imp.last_stats
+    assert st["chunks"] == 7
+    # each of the two slots may grow its row pool once and its pair pool once; without the growth every chunk overflows (>= 7)
+    assert 1 <= st["reruns"] <= 4, st
