@@ -294,8 +294,9 @@ int grim_prior_matrix(const grim_prior_spec *spec, const char *const *pop_names,
  * on `n_threads` host threads plus one device thread.  Output: the six texts, appended to the files named in
  * out_path (parallel pwrite at offsets known from the chunk order) or kept in memory; optionally the per-subject
  * stdout lines of impute_file (text 6); optionally the raw result records of every chunk (grim_stream_next_records).
- * The row pool of a chunk is bounded (rows_per_chunk); a chunk that overflows it is split and its halves are run
- * again, down to single subjects, so no configuration needs a worst-case allocation.
+ * The row pool of a chunk is bounded; a chunk that overflows it is run again -- with twice the pool (up to every line's
+ * worst case) when rows_per_chunk was left at 0, in halves, down to single subjects, when the caller fixed it -- so no
+ * configuration needs a worst-case allocation up front.
  * One stream per grim_ctx at a time; the calling thread may block in grim_stream_write while `depth` chunks are in
  * flight. */
 typedef struct grim_stream grim_stream;
@@ -304,7 +305,7 @@ typedef struct {
   uint32_t depth;           /* chunks in flight; 0 = 4 */
   int32_t n_threads;        /* tokenizer / formatter threads; 0 = grim_default_threads() */
   uint64_t line_offset;     /* global index of the first line (multi-GPU shards keep the reference's line numbers) */
-  uint64_t rows_per_chunk;  /* row pool of one chunk; 0 = 32 rows per line (never less than one subject's worst case) */
+  uint64_t rows_per_chunk;  /* row pool of one chunk; 0 = 32 rows per line to begin with, growing on demand; a value fixes it (never less than one subject's worst case) */
   uint8_t want_text;        /* format the six output texts */
   uint8_t want_log;         /* also text 6: the lines impute_file prints per subject */
   uint8_t want_records;     /* hand every chunk's records to grim_stream_next_records (the caller must drain them) */
