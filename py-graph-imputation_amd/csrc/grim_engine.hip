@@ -154,14 +154,14 @@ __global__ __launch_bounds__(GRIM_WG, GRIM_WG_PER_CU) void grim_plan_a_kernel(De
 
 
 // The half-wave kernel writes a subject's rows at a fixed stride (no atomics on its hot path) into a staging region at
-// the TOP of the row pool; most of that region stays empty (3 + ~1.3 of 13 rows per subject).  This kernel moves the
+// the TOP of the row pool; most of that region stays empty (1 + ~1.3 of 11 rows per subject).  This kernel moves the
 // rows that exist into the bump-allocated part of the pool -- one allocation per wave of 64 subjects -- and re-bases the
-// subjects' row offsets, so that the batch's D2H copy carries 144 instead of 416 bytes of rows per subject.
+// subjects' row offsets, so that the batch's D2H copy carries ~75 instead of 352 bytes of rows per subject.
 __global__ __launch_bounds__(64) void grim_small_compact_kernel(DevArgs A, const uint32_t *order_s, const SmallRec *recs, uint32_t n_small,
                                                                  uint32_t stage_base, uint32_t stride) {
   const uint32_t w = blockIdx.x * 64 + threadIdx.x;
   const int lane = lane_id();
-  // a subject's staged rows are one run: [.umug, .umug.pops, .pmug.pops, its .pmug rows] from stage_base + w * stride
+  // a subject's staged rows are one run: [the row that is its .umug, .umug.pops and .pmug.pops row, its .pmug rows] from stage_base + w * stride
   uint32_t si = 0, cnt = 0;
   uint4 ro = make_uint4(0, 0, 0, 0), nr = make_uint4(0, 0, 0, 0);
   // record w's subject: from the class list (host-tokenised subjects), or from the record itself (device-tokenised

@@ -1011,10 +1011,11 @@ void format_range(const FmtParams &fp, const char *text, const TokRange &tr, con
             out.put('+');
             hap_name(row.b, out, plan);
           }
-        } else {
-          out.put(pop_name((uint32_t)row.a, plan));
+        } else {  // a population-pair row names its pair in popa / popb (a / b repeat it, except in the ONE row that is a
+                  // half-wave subject's genotype row and both its population rows at once: grim_small.h)
+          out.put(pop_name(row.popa, plan));
           out.put(',');
-          out.put(pop_name((uint32_t)row.b, plan));
+          out.put(pop_name(row.popb, plan));
         }
         char *q = out.room(64);
         *q++ = ',';

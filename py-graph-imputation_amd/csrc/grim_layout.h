@@ -49,7 +49,9 @@ struct TabUnit {    // work unit of the bucket kernel: bucket (table 0 / 1) or p
   uint32_t pad[3];
 };                  // 32 bytes
 
-#define GRIM_SMALL_ROWS_FIXED 3  // umug, umug.pops, pmug.pops; then up to 16 pmug rows
+#define GRIM_SMALL_ROWS_FIXED 1  // ONE row {genotype keys, sum of all pairs, populations 0 0} is the subject's .umug row and both its
+                                 // population-pair rows (one population: one genotype, one cell, one sum -- three copies of it
+                                 // were a third of the bytes that cross PCIe per subject); then up to 16 .pmug rows
 
 // subject classes (which kernel opens the subject)
 enum { GRIM_CLS_SMALL = 0, GRIM_CLS_MEDIUM = 1, GRIM_CLS_GENERAL = 2 };

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_a_small_kernel(DevArgs A, c
   if (!live) return;
   // ---- output, by lane role: one row store and one header store serve the whole half ------------------------------
   //   hl  0..15  phase lanes       -> their .pmug row (rank-th of the subject's block)
-  //   hl 16..18                    -> the fixed rows: .umug, .umug.pops, .pmug.pops
+  //   hl 16                        -> the fixed row: .umug, .umug.pops and .pmug.pops in one (GRIM_SMALL_ROWS_FIXED)
   //   hl 19..25                    -> the seven 8-byte pieces of the 56-byte result header
   const uint32_t off = row_base + w * row_stride;
   const bool ok = nU > 0;
@@ -176,11 +176,11 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_a_small_kernel(DevArgs A, c
   {
     const int f = hl - 16;
     const bool phase = hl < 16;
-    const bool wr = ok && (phase ? (acc && rank < n_pm) : (f < 3 && (f < 2 ? A.prm.out_muug != 0 : A.prm.out_haps != 0)));
+    const bool wr = ok && (phase ? (acc && rank < n_pm) : f == 0);
     if (wr) {
       grim_row r;
-      r.a = phase ? mykey : (f == 0 ? ka : 0ull);  // a found node's key is the key that found it
-      r.b = phase ? key2 : (f == 0 ? kb : 0ull);
+      r.a = phase ? mykey : ka;  // a found node's key is the key that found it
+      r.b = phase ? key2 : kb;
       r.prob = phase ? prob : total;
       r.popa = 0;
       r.popb = 0;
@@ -200,8 +200,8 @@ __global__ __launch_bounds__(GRIM_WG) void grim_plan_a_small_kernel(DevArgs A, c
     switch (j) {
       case 0: lo = head; hi = ok ? nU : 0u; break;
       case 1: lo = ok ? 1u : 0u; hi = ok ? off + 0 : 0u; break;
-      case 2: lo = ok ? off + 1 : 0u; hi = ok ? off + GRIM_SMALL_ROWS_FIXED : 0u; break;
-      case 3: lo = ok ? off + 2 : 0u; hi = n_um; break;
+      case 2: lo = ok ? off + 0 : 0u; hi = ok ? off + GRIM_SMALL_ROWS_FIXED : 0u; break;
+      case 3: lo = ok ? off + 0 : 0u; hi = n_um; break;
       case 4: lo = n_up; hi = n_pm; break;
       case 5: lo = n_pp; hi = 0u; break;
       default: lo = (uint32_t)mxb; hi = (uint32_t)(mxb >> 32); break;

@@ -200,7 +200,7 @@ struct grim_stream {
   std::vector<CopyJob> copy_jobs;  // one slot per helper, plus one for the reader's own piece
   std::mutex copy_mu;
   std::condition_variable cv_copyjob;
-  uint64_t copy_gen = 0;           // bumped when the slots hold new jobs
+  std::atomic<uint64_t> copy_gen{0};  // bumped (release) when the slots hold new jobs
   std::atomic<int> copy_left{0};
   bool copy_stop = false;
   uint32_t avg_line = 128;         // bytes per line of the last chunk: how much to copy before counting
@@ -852,10 +852,27 @@ static void copier_loop(grim_stream *s, size_t k) {
     grim_stream::CopyJob *job = &s->copy_jobs[k];
     size_t n = 0;
     {
-      std::unique_lock<std::mutex> lk(s->copy_mu);
-      s->cv_copyjob.wait(lk, [&] { return s->copy_stop || s->copy_gen != seen; });
-      if (s->copy_stop) return;
-      seen = s->copy_gen;
+      // A stream in full flow posts a job every ~80 us, and a thread asleep on a condition variable takes tens of
+      // microseconds to come back -- longer than its piece takes to copy.  So a helper keeps LOOKING for the next job for a
+      // little while (250 us: three chunk periods) before it goes to sleep; an idle stream costs nothing.
+      uint64_t gen = s->copy_gen.load(std::memory_order_acquire);
+      if (gen == seen) {
+        const auto t0 = Clock::now();
+        for (int spin = 0; gen == seen; ++spin) {
+          if ((spin & 63) == 63 && secs(t0, Clock::now()) > 250e-6) break;
+#if defined(__x86_64__)
+          __builtin_ia32_pause();
+#endif
+          gen = s->copy_gen.load(std::memory_order_acquire);
+        }
+      }
+      if (gen == seen) {
+        std::unique_lock<std::mutex> lk(s->copy_mu);
+        s->cv_copyjob.wait(lk, [&] { return s->copy_stop || s->copy_gen.load(std::memory_order_acquire) != seen; });
+        if (s->copy_stop) return;
+        gen = s->copy_gen.load(std::memory_order_acquire);
+      }
+      seen = gen;
       n = job->n;
     }
     if (n) {  // (the slot is this helper's until it reports back: the reader waits for copy_left)
@@ -1130,7 +1147,7 @@ extern "C" int grim_stream_write(grim_stream *s, const char *text, uint64_t len)
           if (e > o) ++jobs;
         }
         s->copy_left.store(jobs);
-        ++s->copy_gen;
+        s->copy_gen.fetch_add(1, std::memory_order_release);  // (the jobs above are visible to a helper that sees the new number)
       }
       s->cv_copyjob.notify_all();
       mine.n = std::min<size_t>(blk, per);

@@ -382,7 +382,7 @@ class Imputation(object):
             for row in rows[r["row_off"][nat.T_UMUG]: r["row_off"][nat.T_UMUG] + r["n_rows"][nat.T_UMUG]]:
                 res_m["Haps"][self._genotype(row["a"], row["b"])] = float(row["prob"])
             for row in rows[r["row_off"][nat.T_UMUG_POPS]: r["row_off"][nat.T_UMUG_POPS] + r["n_rows"][nat.T_UMUG_POPS]]:
-                res_m["Pops"][self._pop_name(row["a"], plan) + "," + self._pop_name(row["b"], plan)] = float(row["prob"])
+                res_m["Pops"][self._pop_name(row["popa"], plan) + "," + self._pop_name(row["popb"], plan)] = float(row["prob"])
         if haps_output:
             plan = int(r["plan_phased"]) or plan
             res_h["MaxProb"] = float(r["max_prob"])
@@ -703,5 +703,5 @@ class Imputation(object):
                 else:
                     text = self._hap_name(row["a"], plan) + "+" + self._hap_name(row["b"], plan)
             else:
-                text = self._pop_name(row["a"], plan) + "," + self._pop_name(row["b"], plan)
+                text = self._pop_name(row["popa"], plan) + "," + self._pop_name(row["popb"], plan)
             fh.append(sid + "," + text + "," + str(prob) + "," + str(k) + "\n")
