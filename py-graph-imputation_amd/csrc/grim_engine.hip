@@ -212,6 +212,24 @@ __global__ __launch_bounds__(64) void grim_small_compact_kernel(DevArgs A, const
   r[6] = ro.w + delta;
 }
 
+// A finished batch's results, device arena -> pinned host memory, by a few workgroups instead of the DMA engine: the
+// engine moves a 1.3 MB block (10 000 config-2 subjects) at ~20 GB/s, which made the D2H copy the slowest stage of the
+// stream (62 us per chunk against 33 us of kernels); sixteen-byte stores from 32 workgroups fill the PCIe link without
+// taking the chip from the kernels of the next batches (the runtime's own blit kernel, which rocprofv3 forces, does take
+// it: the half-wave kernel beside it stretches from 11 to 49 us).  GRIM_EXPORT_KERNEL=0: hipMemcpyAsync as before.
+__global__ __launch_bounds__(256) void grim_export_kernel(uint4 *__restrict__ dst, const uint4 *__restrict__ src, uint64_t n16) {
+  const uint64_t step = (uint64_t)gridDim.x * 256u;
+  uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  for (; i + 3 * step < n16; i += 4 * step) {  // four loads in flight per lane
+    const uint4 a = src[i], b = src[i + step], c = src[i + 2 * step], d = src[i + 3 * step];
+    dst[i] = a;
+    dst[i + step] = b;
+    dst[i + 2 * step] = c;
+    dst[i + 3 * step] = d;
+  }
+  for (; i < n16; i += step) dst[i] = src[i];
+}
+
 // zero the counters and work heads of a batch (one launch instead of several memsets)
 __global__ void grim_reset_kernel(unsigned long long *counters, uint32_t *queue, uint32_t row_head0) {
   for (int i = threadIdx.x; i < GRIM_NCTR; i += blockDim.x) counters[i] = 0;
@@ -1526,7 +1544,16 @@ static int batch_fetch_on(grim_batch *b, uint32_t res_lo, uint32_t res_hi, grim_
   if (whole && b->off_rows - sizeof(grim_subject_result) * (uint64_t)b->n_subj < 4096) {
     // headers and rows are (nearly) back to back: one copy
     const uint64_t bytes = b->rows_used ? b->off_rows + sizeof(grim_row) * (uint64_t)b->rows_used : sizeof(grim_subject_result) * (uint64_t)b->n_subj;
-    if (bytes) HIPCHK(hipMemcpyAsync(b->h_out, b->d_out, bytes, hipMemcpyDeviceToHost, st), c, -1);
+    static const int by_kernel = env_int("GRIM_EXPORT_KERNEL", 1);
+    const uint64_t n16 = (bytes + 15) / 16;  // (both arenas are 256-byte granular: the last sixteen bytes exist)
+    if (bytes && by_kernel && 16 * n16 <= b->h_out_cap && 16 * n16 <= b->out_cap) {
+      uint32_t grid = (uint32_t)((n16 + 1023) / 1024);
+      if (grid > 32) grid = 32;
+      hipLaunchKernelGGL(grim_export_kernel, dim3(grid), dim3(256), 0, st, (uint4 *)b->h_out, (const uint4 *)b->d_out, n16);
+      HIPCHK(hipGetLastError(), c, -1);
+    } else if (bytes) {
+      HIPCHK(hipMemcpyAsync(b->h_out, b->d_out, bytes, hipMemcpyDeviceToHost, st), c, -1);
+    }
     g_moved[1] += bytes;
   } else {
     if (res_hi > res_lo) {
