@@ -197,7 +197,10 @@ struct grim_stream {
     uint32_t n_nl = 0;
   };
   std::vector<std::thread> copiers;
-  std::vector<CopyJob> copy_jobs;  // one slot per helper, plus one for the reader's own piece
+  std::vector<CopyJob> copy_jobs;  // the pieces of the block in hand (COPY_PIECES at most), claimed one by one through copy_next by the
+                                   // reader and its helpers alike: a helper that is late, or that the host took away for a while,
+                                   // copies fewer pieces instead of holding the chunk up with its fixed share
+  std::atomic<uint32_t> copy_next{0}, copy_np{0};
   std::mutex copy_mu;
   std::condition_variable cv_copyjob;
   std::atomic<uint64_t> copy_gen{0};  // bumped (release) when the slots hold new jobs
@@ -845,16 +848,28 @@ static uint32_t copy_and_mark(char *dst, const char *src, size_t n, uint32_t *nl
   return k;
 }
 
-// a copy helper of the reader (see grim_stream::CopyJob): sleeps until the reader posts jobs, copies its slot's piece
-static void copier_loop(grim_stream *s, size_t k) {
+// pieces of the posted block, until none is left (reader and helpers)
+static constexpr size_t COPY_PIECES = 64;
+static void copy_pieces(grim_stream *s) {
+  for (;;) {
+    // (a thread that comes back here from the block before may find the NEXT block posted already: the piece it takes then
+    //  is one of that block's -- everything about a block is written before copy_next goes back to 0)
+    const uint32_t k = s->copy_next.fetch_add(1, std::memory_order_acq_rel);
+    if (k >= s->copy_np.load(std::memory_order_relaxed)) return;
+    grim_stream::CopyJob &job = s->copy_jobs[k];
+    job.n_nl = copy_and_mark(job.dst, job.src, job.n, job.nl.data());
+    s->copy_left.fetch_sub(1, std::memory_order_release);
+  }
+}
+
+// a copy helper of the reader (see grim_stream::CopyJob): waits until the reader posts a block, takes pieces of it
+static void copier_loop(grim_stream *s, size_t) {
   uint64_t seen = 0;
   for (;;) {
-    grim_stream::CopyJob *job = &s->copy_jobs[k];
-    size_t n = 0;
     {
-      // A stream in full flow posts a job every ~80 us, and a thread asleep on a condition variable takes tens of
-      // microseconds to come back -- longer than its piece takes to copy.  So a helper keeps LOOKING for the next job for a
-      // little while (250 us: three chunk periods) before it goes to sleep; an idle stream costs nothing.
+      // A stream in full flow posts a block every ~70 us, and a thread asleep on a condition variable takes tens of
+      // microseconds to come back -- longer than its pieces take to copy.  So a helper keeps LOOKING for the next block for
+      // a little while (250 us: three chunk periods) before it goes to sleep; an idle stream costs nothing.
       uint64_t gen = s->copy_gen.load(std::memory_order_acquire);
       if (gen == seen) {
         const auto t0 = Clock::now();
@@ -873,12 +888,8 @@ static void copier_loop(grim_stream *s, size_t k) {
         gen = s->copy_gen.load(std::memory_order_acquire);
       }
       seen = gen;
-      n = job->n;
     }
-    if (n) {  // (the slot is this helper's until it reports back: the reader waits for copy_left)
-      job->n_nl = copy_and_mark(job->dst, job->src, n, job->nl.data());
-      s->copy_left.fetch_sub(1, std::memory_order_release);
-    }
+    copy_pieces(s);  // (a helper that arrives after the block is done finds no piece: copy_next is past the end)
   }
 }
 
@@ -1130,29 +1141,30 @@ extern "C" int grim_stream_write(grim_stream *s, const char *text, uint64_t len)
     if (remaining >= (256u << 10) && !s->copiers.empty()) {
       blk = std::min<uint64_t>(remaining, (uint64_t)want * s->avg_line + 4096);
       c->text.resize(base + blk);
-      const size_t nh = s->copiers.size(), parts = nh + 1;
+      // pieces of ~48 KB (whole cache lines), at least one per thread
+      const size_t nh = s->copiers.size();
+      size_t parts = std::min<size_t>(COPY_PIECES, std::max<size_t>(nh + 1, (size_t)(blk / (48u << 10))));
       const size_t per = ((blk / parts) + 63) & ~(size_t)63;
-      grim_stream::CopyJob &mine = s->copy_jobs[nh];  // the reader's own piece: the first one
+      parts = (size_t)((blk + per - 1) / per);
       {
         std::lock_guard<std::mutex> lk(s->copy_mu);
-        int jobs = 0;
-        for (size_t k = 0; k < nh; ++k) {
-          const size_t o = std::min<size_t>(blk, (k + 1) * per), e = std::min<size_t>(blk, (k + 2) * per);
+        for (size_t k = 0; k < parts; ++k) {
+          const size_t o = std::min<size_t>(blk, k * per), e = std::min<size_t>(blk, (k + 1) * per);
           grim_stream::CopyJob &j = s->copy_jobs[k];
           j.src = text + a + o;
           j.dst = c->text.data() + base + o;
           j.n = e - o;
           j.n_nl = 0;
           if (j.nl.size() < j.n + 64) j.nl.resize(j.n + 64);
-          if (e > o) ++jobs;
         }
-        s->copy_left.store(jobs);
-        s->copy_gen.fetch_add(1, std::memory_order_release);  // (the jobs above are visible to a helper that sees the new number)
+        s->copy_np.store((uint32_t)parts, std::memory_order_relaxed);
+        s->copy_left.store((int)parts);
+        s->copy_next.store(0, std::memory_order_release);     // from here on pieces can be taken (no piece of the block before is
+                                                              // in flight: copy_left was 0)
+        s->copy_gen.fetch_add(1, std::memory_order_release);  // ... and sleeping / looking helpers learn of the block
       }
       s->cv_copyjob.notify_all();
-      mine.n = std::min<size_t>(blk, per);
-      if (mine.nl.size() < mine.n + 64) mine.nl.resize(mine.n + 64);
-      mine.n_nl = copy_and_mark(c->text.data() + base, text + a, mine.n, mine.nl.data());
+      copy_pieces(s);
       while (s->copy_left.load(std::memory_order_acquire) > 0) std::this_thread::yield();
       const auto tr2 = Clock::now();
       g_dbg_ns[8] += (uint64_t)(secs(tr1, tr2) * 1e9);
@@ -1160,8 +1172,8 @@ extern "C" int grim_stream_write(grim_stream *s, const char *text, uint64_t len)
       used = blk;
       bool full = false;
       for (size_t q = 0; q < parts && !full; ++q) {
-        const grim_stream::CopyJob &j = q == 0 ? mine : s->copy_jobs[q - 1];
-        const uint64_t po = q == 0 ? 0 : std::min<size_t>(blk, q * per);
+        const grim_stream::CopyJob &j = s->copy_jobs[q];
+        const uint64_t po = std::min<size_t>(blk, q * per);
         const uint32_t take = std::min<uint32_t>(j.n_nl, want - got);
         // marks: line ends number `ln` (1-based in the chunk) with ln % granule == 0
         uint32_t ln = c->n_lines + got;
@@ -1553,7 +1565,7 @@ extern "C" grim_stream *grim_stream_open(grim_ctx *ctx, const grim_graph *g, con
     const char *e = getenv("GRIM_COPY_THREADS");
     size_t nc = e ? (size_t)atoi(e) : (s->n_threads >= 24 ? 7u : s->n_threads >= 12 ? 5u : s->n_threads >= 8 ? 3u : s->n_threads >= 4 ? 1u : 0u);
     if (nc > 7) nc = 7;
-    s->copy_jobs.resize(nc + 1);
+    s->copy_jobs.resize(COPY_PIECES);
     for (size_t k = 0; k < nc; ++k) s->copiers.emplace_back(copier_loop, s, k);
   }
   return s;
