@@ -40,9 +40,11 @@ struct WaveTabT1 : WaveTab<TAB_N> {
 #define TAB_NB 256         // pairs per bucket the bucket kernel holds
 #endif
 #ifndef TAB_DIV
-#define TAB_DIV 128u        // a table of n pairs is dealt into the power of two >= n / TAB_DIV buckets (64..128 pairs on average).
-                           // Measured with the sort-free grouping, table kernels per 100 k config-4 subjects: 7.5 ms at 64, 7.3 at 96,
-                           // 6.7 at 128 (a unit's fixed cost -- header, pair numbers, group counter -- weighs more than its pairs)
+#define TAB_DIV 192u        // a table of n pairs is dealt into the power of two >= n / TAB_DIV buckets (96..192 pairs on average; a
+                           // bucket beyond TAB_NB pairs has its table re-dealt into twice as many).  Table kernels per 100 k
+                           // config-4 subjects / 2 048 config-5 subjects with round 3's kernels: 5.53 / -- ms at 96, 5.37-5.56 /
+                           // 15.6 at 128, 5.23-5.49 / 15.0 at 192, 5.33 / 15.5 at 256 (a unit's fixed cost -- header, pair numbers,
+                           // group counter -- against the re-deals of the tables whose buckets overflow)
 #endif
 
 struct TabShared {
