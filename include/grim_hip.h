@@ -168,8 +168,9 @@ enum {
                              output -> raw line in .problem when output_haplotypes is on             */
 };
 
-/* one output row: a/b are 64-bit haplotype keys (genotype and haplotype-pair tables) or
- * population indices (population tables); popa/popb are set for pair rows. */
+/* one output row: a/b are 64-bit haplotype keys (genotype and haplotype-pair tables); popa/popb are the populations of a
+ * haplotype-pair row and NAME the pair of a population-table row (a/b repeat them there -- except in the one row that
+ * serves as a one-population subject's genotype row and both its population rows: read popa/popb). */
 typedef struct {
   uint64_t a, b;
   double prob;
