@@ -31,6 +31,7 @@ struct WaveTab {
   uint32_t tab[2 * N];     // hash slots: the local pair that represents the group; afterwards the group sums (double[N])
   uint32_t skey[N];        // first pair (record index) of the group local pair i represents
   double cp[64 + 1];       // the probabilities of the chunk in hand, by lane; [64] = 0.0
+  unsigned long long gm[N];  // [rep]: the lanes of the chunk in hand whose pair belongs to the group rep stands for (0 between chunks)
   uint16_t rs[N + 2];      // run j -> its representative
 };
 struct WaveTabT1 : WaveTab<TAB_N> {
@@ -115,6 +116,7 @@ __device__ inline uint32_t wave_group_pairs(WaveTab<N> &W, int kind, int P, cons
   for (uint32_t i = lane; i < n; i += 64) {
     W.prob[i] = 0.0;          // sum of the group pair i represents
     W.skey[i] = GRIM_NONE;    // ... and its first pair
+    W.gm[i] = 0ull;
   }
   if (lane == 0) W.cp[64] = 0.0;
   WAVE_SYNC();
@@ -158,15 +160,12 @@ __device__ inline uint32_t wave_group_pairs(WaveTab<N> &W, int kind, int P, cons
         h = (h + 1) & (2 * N - 1);
       }
     }
-    // the lanes of this chunk with my representative (N <= 256: eight bits)
-    uint64_t same = __ballot(act);
-#pragma unroll
-    for (int bit = 0; bit < 8; ++bit) {
-      if ((N >> bit) == 0) break;
-      const bool sbit = (rep >> bit) & 1u;
-      const uint64_t m = __ballot(act && sbit);
-      same &= sbit ? m : ~m;
-    }
+    // the lanes of this chunk with my representative: every lane sets its bit in the representative's mask and reads the
+    // mask back (eight ballots over the representative's bits -- ~80 instructions of a chunk's ~450 -- until round 3's end)
+    if (act) atomicOr(&W.gm[rep], 1ull << lane);
+    WAVE_SYNC();
+    const uint64_t same = act ? W.gm[rep] : 0ull;
+    WAVE_SYNC();
     const uint32_t pos = (uint32_t)__popcll(same & lt);
     // The group's members in this chunk join its sum in lane = pair order.  Its FIRST lane does that for all of them, from
     // the chunk's probabilities in LDS, four loads in flight per step: a bucket holds a handful of big groups as a rule (the
@@ -192,6 +191,7 @@ __device__ inline uint32_t wave_group_pairs(WaveTab<N> &W, int kind, int P, cons
         acc = acc + p3;
       }
       W.prob[rep] = acc;
+      W.gm[rep] = 0ull;  // (every lane of the group has read it)
     }
     WAVE_SYNC();
     const uint64_t cm = __ballot(claimed);
