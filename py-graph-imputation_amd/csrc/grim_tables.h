@@ -791,8 +791,45 @@ __device__ inline void tab_rank(const DevArgs &A, TabShared &sh, const Slot &S, 
 //   grim_tables_bucket_kernel : wave per unit      : groups of a bucket (head, sum) / sum of a cell
 //   grim_tables_merge_kernel  : workgroup per item : first-seen order, ranking, rows
 
+// first kernel, ONE sweep over the item's records for all three partitions (round 3): cell and the twelve hash bits of the
+// genotype / haplotype-pair key of every pair, packed into S.svb[u] = cell << 24 | h(pair key) << 12 | h(genotype key).  The
+// partitions then count and deal from these four bytes instead of each reading the 32-byte records and hashing again.
+__device__ inline void tab_split_ids(const DevArgs &A, const Slot &S, const TabWork &w, bool split0, bool split1) {
+  const int P = A.g.P;
+  const PairRec *rec = A.ppool + w.off;
+  const uint32_t nU = w.n;
+  for (uint32_t ub = threadIdx.x; ub < nU; ub += 4 * GRIM_WG) {  // four records in flight per lane
+    PairRec r4[4];
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4)
+      if (ub + GRIM_WG * k4 < nU) r4[k4] = rec[ub + GRIM_WG * k4];
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+      const uint32_t u = ub + GRIM_WG * k4;
+      if (u >= nU) break;
+      const PairRec &r = r4[k4];
+      const uint32_t a = ENT_POP(r.e1), b = ENT_POP(r.e2);
+      uint32_t id = ((a < b ? a : b) * (uint32_t)P + (a < b ? b : a)) << 24;
+      uint64_t lo, hi;
+      if (split0) {
+        tab_key(0, P, r, lo, hi);
+        id |= (uint32_t)(tab_hash(lo, hi) >> 40) & (TAB_MAXB - 1);
+      }
+      if (split1) {
+        tab_key(1, P, r, lo, hi);
+        id |= ((uint32_t)(tab_hash(lo, hi) >> 40) & (TAB_MAXB - 1)) << 12;
+      }
+      S.svb[u] = id;
+    }
+  }
+  __syncthreads();
+}
+
 // first kernel, one table: bucket of every pair, bucket starts, the pairs dealt out, one work unit per bucket
-__device__ inline void tab_split_table(const DevArgs &A, TabShared &sh, const Slot &S, const TabWork &w, uint32_t item, int t, int kind) {
+// ids_shift >= 0: S.svb[u] holds the packed ids tab_split_ids left (this table's twelve hash bits from bit ids_shift); -1: the
+// key sweep is this function's own
+__device__ inline void tab_split_table(const DevArgs &A, TabShared &sh, const Slot &S, const TabWork &w, uint32_t item, int t, int kind,
+                                       int ids_shift = -1) {
   const int tid = threadIdx.x;
   const int P = A.g.P;
   const PairRec *rec = A.ppool + w.off;
@@ -817,6 +854,14 @@ __device__ inline void tab_split_table(const DevArgs &A, TabShared &sh, const Sl
   }
   __syncthreads();
   const uint32_t u0 = wv * q, u1 = u0 + q < nU ? u0 + q : nU;
+  const int sft = ids_shift < 0 ? 0 : ids_shift;
+  if (ids_shift >= 0) {  // the keys were hashed once for all tables: count from the ids
+#pragma unroll 4
+    for (uint32_t u = u0 + lane; u < u1; u += 64) {
+      const uint32_t k = wv * nb + ((S.svb[u] >> sft) & (nb - 1));
+      atomicAdd((uint32_t *)wc + (k >> 1), 1u << (16 * (k & 1)));
+    }
+  } else
   for (uint32_t ub = u0 + lane; ub < u1; ub += 4 * 64) {  // four records in flight per lane (the stores below may alias them
     PairRec r4[4];                                         // for all the compiler knows: it would not hoist the loads itself)
 #pragma unroll
@@ -865,7 +910,7 @@ __device__ inline void tab_split_table(const DevArgs &A, TabShared &sh, const Sl
     }
     __syncthreads();
     for (uint32_t u = u0 + lane; u < u1; u += 64) {
-      const uint32_t k = wv * nb + (S.svb[u] & (nb - 1));
+      const uint32_t k = wv * nb + ((S.svb[u] >> sft) & (nb - 1));
       atomicAdd((uint32_t *)wc + (k >> 1), 1u << (16 * (k & 1)));
     }
     __syncthreads();
@@ -925,7 +970,7 @@ __device__ inline void tab_split_table(const DevArgs &A, TabShared &sh, const Sl
     for (int k = 0; k < 4; ++k) {
       const uint32_t u = c0 + k * 64 + lane;
       act[k] = u < u1;
-      bk[k] = act[k] ? S.svb[u] & (nb - 1) : 0u;
+      bk[k] = act[k] ? (S.svb[u] >> sft) & (nb - 1) : 0u;
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) same[k] = __ballot(act[k]);
@@ -964,7 +1009,8 @@ __device__ inline void tab_split_table(const DevArgs &A, TabShared &sh, const Sl
 }
 
 // first kernel, population pairs: stable partition by cell, probabilities laid out cell after cell, a unit per cell
-__device__ inline void tab_split_pops(const DevArgs &A, TabShared &sh, const Slot &S, const TabWork &w, uint32_t item) {
+// have_ids: S.svb[u] holds the packed ids tab_split_ids left (the cell in bits 24..31)
+__device__ inline void tab_split_pops(const DevArgs &A, TabShared &sh, const Slot &S, const TabWork &w, uint32_t item, bool have_ids = false) {
   const int tid = threadIdx.x;
   const int P = A.g.P;
   const int ncell = P * P;
@@ -1000,6 +1046,14 @@ __device__ inline void tab_split_pops(const DevArgs &A, TabShared &sh, const Slo
     }
     __syncthreads();
     const uint32_t u0 = wv * q, u1 = u0 + q < nU ? u0 + q : nU;
+    const int sft = have_ids ? 24 : 0;
+    if (have_ids) {
+#pragma unroll 4
+      for (uint32_t u = u0 + lane; u < u1; u += 64) {
+        const uint32_t k = wv * nc + (S.svb[u] >> 24);
+        atomicAdd((uint32_t *)wc + (k >> 1), 1u << (16 * (k & 1)));
+      }
+    } else
     for (uint32_t ub = u0 + lane; ub < u1; ub += 4 * 64) {
       uint32_t ea[4], eb[4];
 #pragma unroll
@@ -1051,7 +1105,7 @@ __device__ inline void tab_split_pops(const DevArgs &A, TabShared &sh, const Slo
       for (int k = 0; k < 4; ++k) {
         const uint32_t u = c0 + k * 64 + lane;
         act[k] = u < u1;
-        ck[k] = act[k] ? S.svb[u] : 0u;
+        ck[k] = act[k] ? S.svb[u] >> sft : 0u;
         pr[k] = act[k] ? rec[u].prob : 0.0;
       }
 #pragma unroll
@@ -1595,16 +1649,23 @@ __global__ __launch_bounds__(GRIM_WG, GRIM_TAB_WG_PER_CU) void grim_tables_split
     const unsigned long long t_item = STAMP_NOW();
     (void)t_item;
     if (tid == 0) atomicAdd(A.queue + 12, 1u);  // (GRIM_DEBUG_CLASSES=1 prints it)
-    tab_split_pops(A, sh, S, w, item);
+    const bool hbm_way = (A.flags & GRIM_F_TABLES_HBM) != 0;
+    const bool split0 = (w.mask & 1u) && !hbm_way;
+    const bool split1 = ((w.mask >> 1) & 1u) && A.prm.out_haps && !(A.prm.em_mr || A.g.P == 1) && !hbm_way;
+    // one key sweep for the three partitions when the ids fit the packed word and every partition deals from LDS counts
+    const uint32_t ncell_u = (uint32_t)(A.g.P * A.g.P);
+    const bool fused = (split0 || split1) && ncell_u > 1 && ncell_u <= 256 && TAB_MAXB <= 4096 && w.n <= GRIM_NWAVE * 65472u;
+    if (fused) tab_split_ids(A, S, w, split0, split1);
+    tab_split_pops(A, sh, S, w, item, fused);
     for (int t = 0; t < 2; ++t) {
       if (!((w.mask >> t) & 1u)) continue;
       if (t == 1 && !A.prm.out_haps) continue;
       const int kind = t == 0 ? 0 : (A.prm.em_mr ? 2 : 1);
-      if (kind == 2 || (kind == 1 && A.g.P == 1) || (A.flags & GRIM_F_TABLES_HBM)) {
+      if (!(t == 0 ? split0 : split1)) {
         if (tid == 0) A.taux[item].nb[t] = 0;  // every pair its own group / HBM path: nothing to split
         continue;
       }
-      tab_split_table(A, sh, S, w, item, t, kind);
+      tab_split_table(A, sh, S, w, item, t, kind, fused ? 12 * t : -1);
     }
     __syncthreads();
     HIST(4, w.n, 1);
