@@ -299,6 +299,22 @@ def main():
             traffic_src = "profiles/" + os.path.basename(pmc_path) + ": (FETCH_SIZE + WRITE_SIZE) KB x 1024 per launch, separate --pmc passes; " \
                           "with FETCH_SIZE doubled (gfx950 wide-read correction): %d" % pmc["hbm_bytes_fetch_doubled"]
 
+    # the committed rocprofv3 kernel stats of this workload (tools/profile_round.sh), every kernel of the stream path: the
+    # cross-check for avg_launch_ms, and the kernels the kernel-only loop above does not run (the tokenizer kernel parses
+    # the GL strings in front of the half-wave kernel and is, at 10 000 lines, the longer of the two; the export kernel
+    # brings the results back on the copy stream)
+    rocprof = None
+    stats_path = os.path.join(ROOT, "profiles", "r3_%s_kernel_stats.csv" % args.workload)
+    if os.path.exists(stats_path) and n_step == dflt_n:
+        import csv
+        rocprof = {"source": "profiles/" + os.path.basename(stats_path) + " (under the profiler the runtime's copies run beside "
+                             "the kernels and stretch the averages; min_us is the undisturbed launch)", "avg_us": {}, "min_us": {}}
+        for r in csv.DictReader(open(stats_path)):
+            k = r["Name"].split("(")[0]
+            if k.startswith("grim_"):
+                rocprof["avg_us"][k] = round(float(r["AverageNs"]) / 1e3, 2)
+                rocprof["min_us"][k] = round(float(r["MinNs"]) / 1e3, 2)
+
     out = None
     if rank == 0:
         total_subjects = world * n_step * args.steps  # per region
@@ -341,6 +357,7 @@ def main():
                 "kernel": names[dom] if whole else "+".join(n for n, v in zip(names, per_kernel) if v > 0),
                 "avg_launch_ms": roof_ms, "algorithmic_bytes_per_launch": algo_bytes,
                 "kernel_ms": dict(zip(names, per_kernel)),
+                "rocprof": rocprof,
             },
         }
         if world == 1 and not args.no_file:
