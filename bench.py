@@ -64,6 +64,25 @@ def make_lines(workload, n, rank, world, rows):
     return synth.SubjectGen(rows, rank).mixed(n)
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` outside a torchrun job: run `python -m torch.distributed.run --nproc-per-node N bench.py
+    <same arguments>` as a child (one rank per GPU), stdout / stderr inherited so rank 0's JSON line comes through, and exit
+    with its code.  (What scripts/runfile_mp.py:109-148 does for the reference: the script forks its own workers.)"""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -92,9 +111,16 @@ def main():
         # use: the untimed steps must touch every slot
         args.warmup = max(args.warmup, 4)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # a plain `python bench.py --gpus N`: start the N ranks as CHILD processes (nothing in this process has touched the
+        # GPU, and it never will), hand their output and exit code on
+        return launch_ranks(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the job has WORLD_SIZE=%d ranks (start it as `python bench.py --gpus N`, or with "
+                 "torchrun --nproc-per-node N bench.py --gpus N)" % (args.gpus, world))
     os.environ["GRIM_QUIET"] = "1"
 
     import __graft_entry__ as ge
@@ -104,10 +130,13 @@ def main():
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # The path has no data-path collective (subjects shard, the graph is replicated): the process group is the control
+        # plane only -- barriers around the timed regions and the max over ranks of their times -- so it is gloo, on CPU
+        # tensors, and torch never opens the GPU beside libgrim_hip.so.  GRIM_BENCH_BACKEND=nccl puts the same calls on RCCL.
         n_dev = torch.cuda.device_count()  # does not initialise the GPU
-        backend = os.environ.get("GRIM_BENCH_BACKEND") or ("nccl" if n_dev > 0 else "gloo")
-        if n_dev > 0:
-            torch.cuda.set_device(local_rank % n_dev)  # ranks > devices only in rehearsals (gloo)
+        backend = os.environ.get("GRIM_BENCH_BACKEND") or "gloo"
+        if backend == "nccl" and n_dev > 0:
+            torch.cuda.set_device(local_rank % n_dev)
         dist.init_process_group(backend=backend)
         if rank == 0:
             ge.build()  # one rank (re)builds the library if it is stale; the others wait
@@ -171,8 +200,14 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    ranks_seen = [{"rank": rank, "device": local_rank % n_dev_all}]
+    if dist is not None:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, ranks_seen[0])
+        ranks_seen = gathered
+
     if args.sharded:
-        return sharded_leg(args, rank, world, dist, work, conf, cfg, graph, lines, gname, desc, n_step, scaling)
+        return sharded_leg(args, rank, world, dist, work, conf, cfg, graph, lines, gname, desc, n_step, scaling, ranks_seen)
 
     # ---- A. headline: host strings -> host records, K steps through one stream ------------------------
     # One timed REGION = exactly --steps steps between two barriers.  A region of config 2 lasts a few milliseconds, far too
@@ -336,7 +371,7 @@ def main():
             "config": {
                 "workload": desc + ("; %d subjects per step and GPU, seed=rank" % n_step if scaling == "weak" else
                                     "; %d subjects per step and GPU" % n_step),
-                "subjects_per_step_per_gpu": n_step, "subjects_with_results_per_step": n_ok_per_step,
+                "subjects_per_step_per_gpu": n_step, "subjects_with_results_per_step": n_ok_per_step, "ranks": ranks_seen,
                 "graph_nodes": int(graph.arrays["n_nodes"]), "populations": P,
                 "timed_region": "host GL strings in memory -> grim_stream (tokenizer threads, pinned staging, H2D, kernels, D2H) -> "
                                 "result records in pinned host memory, read by the caller; %d device batch(es) of %d lines per step, "
@@ -370,11 +405,12 @@ def main():
         dist.destroy_process_group()
 
 
-def sharded_leg(args, rank, world, dist, work, conf, cfg, graph, lines, gname, desc, n_step, scaling):
+def sharded_leg(args, rank, world, dist, work, conf, cfg, graph, lines, gname, desc, n_step, scaling, ranks_seen):
     """--sharded: the product's multi-GPU driver, file -> files.  Every rank calls grim.shard.impute_sharded on the SAME
     conf; chunks of --chunk-lines lines (default 65536) are pulled from the job's store, every rank streams its chunks
-    through one long-lived grim_stream into part files, rank 0 assembles the six outputs with copy_file_range.  A step =
-    the whole file (world x n_step subjects); --steps steps timed one by one, median reported."""
+    through one long-lived grim_stream and writes its pieces straight into the six shared output files at offsets that follow
+    from the chunk sizes published on the store.  A step = the whole file (world x n_step subjects); --steps steps timed one
+    by one, median reported."""
     from grim import shard
 
     all_lines = lines
@@ -421,7 +457,7 @@ def sharded_leg(args, rank, world, dist, work, conf, cfg, graph, lines, gname, d
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": desc + "; --sharded: grim.shard.impute_sharded, subject file on disk -> six merged output files on disk "
                                           "(page cache, no fsync), %d subjects in the file, chunks of %d lines pulled from the job's store" % (len(all_lines), chunk),
-                       "subjects_per_step": len(all_lines), "host_threads_per_rank": int(nat_threads()), "output_bytes": sizes},
+                       "subjects_per_step": len(all_lines), "host_threads_per_rank": int(nat_threads()), "output_bytes": sizes, "ranks": ranks_seen},
         }))
     if dist is not None:
         dist.barrier()

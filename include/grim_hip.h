@@ -239,8 +239,12 @@ const char *grim_dict_name(const grim_dict *d, uint32_t slot, uint32_t id);
 uint32_t grim_dict_count(const grim_dict *d, uint32_t slot);
 
 /* per-line outcome kinds; GRIM_K_UNSUPPORTED: more distinct alleles at one locus of one subject than a key field
- * holds (reported like a GRIM_ST_UNSUPPORTED subject, reason 5) */
-enum { GRIM_K_DEVICE = 0, GRIM_K_PROBLEM_ID = 1, GRIM_K_PROBLEM_RAW = 2, GRIM_K_MISS_NO_DEVICE = 3, GRIM_K_UNSUPPORTED = 4 };
+ * holds (reported like a GRIM_ST_UNSUPPORTED subject, reason 5); GRIM_K_UNSUPPORTED_GL: a GL string that names a locus
+ * twice or mixes loci inside one entry once each side's entries are sorted (reason 8) -- the reference checks no locus
+ * and pairs the entries by index (gl2haps, grim/imputation/impute.py:246-272); such a subject is REPORTED, never
+ * answered differently */
+enum { GRIM_K_DEVICE = 0, GRIM_K_PROBLEM_ID = 1, GRIM_K_PROBLEM_RAW = 2, GRIM_K_MISS_NO_DEVICE = 3, GRIM_K_UNSUPPORTED = 4,
+       GRIM_K_UNSUPPORTED_GL = 5 };
 
 /* text: '\n'-separated input lines ("id,GL[,race1,race2]" or '%'-separated).  The dictionary is only READ:
  * alleles it does not know get ids from grim_dict_count(slot) upwards that are private to the subject that
@@ -312,6 +316,9 @@ typedef struct {
   uint8_t want_records;     /* hand every chunk's records to grim_stream_next_records (the caller must drain them) */
   uint8_t timing;           /* per-kernel HIP events (grim_batch_set_timing) */
   uint8_t rows_exact;       /* take rows_per_chunk as it is (no floor): the caller knows that one subject's rows fit */
+  uint8_t placed;           /* the out_path files are shared with other writers (the ranks of grim/shard.py): opened without
+                             * truncation, and nothing is written until the caller gives a segment its base offsets
+                             * (grim_stream_segment_wait / grim_stream_segment_place) */
   const char *out_path[6];  /* per text: file to create and fill, or NULL = keep in memory (grim_stream_text) */
   /* bin_imputation_in_file phase masks (impute.py:2001-2005, 2030-2032): n_masks ids (NUL-terminated, back to back
    * in mask_ids) and per id the bitmask of positions that keep their side; an id missing from the table sends its
@@ -350,6 +357,12 @@ int grim_stream_write_file(grim_stream *s, const char *path);
 int grim_stream_segment(grim_stream *s, uint64_t next_line_offset);
 uint32_t grim_stream_n_segments(const grim_stream *s);
 int grim_stream_segment_end(const grim_stream *s, uint32_t k, uint64_t out[7]);
+/* Placed output (opts.placed) -- how the ranks of a sharded job write ONE set of output files without a merge copy (what
+ * scripts/runfile_mp.py:143-148 leaves to `cat`): grim_stream_segment_wait blocks until every chunk of the closed segment k
+ * is formatted and gives the bytes of its piece of each text; the caller adds up the pieces before it (other ranks') and
+ * grim_stream_segment_place writes segment k's buffers at those offsets of the shared files (returns when written). */
+int grim_stream_segment_wait(grim_stream *s, uint32_t k, uint64_t sizes[7]);
+int grim_stream_segment_place(grim_stream *s, uint32_t k, const uint64_t base[6]);
 /* byte offsets of every chunk_lines-th line start of a file, the file size last (universal newlines, as
  * grim_stream_write_text; what scripts/runfile_mp.py:113-124 does with `split -l`, without writing the pieces): the number of
  * entries or -1; *out is the library's, released with grim_free */

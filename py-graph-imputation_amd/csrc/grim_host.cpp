@@ -238,7 +238,7 @@ static int tokenise_gl(const DictSnap &D, sv gl, bool planb, Scratch &sc, grim_s
         a = b + 1;
       }
     }
-    if (mixed) goto irregular;
+    if (mixed) goto unsupported_gl;
     {
       const int32_t slot_i = D.find_locus(locus);
       if (slot_i < 0) {
@@ -246,7 +246,7 @@ static int tokenise_gl(const DictSnap &D, sv gl, bool planb, Scratch &sc, grim_s
         continue;
       }
       const uint32_t slot = (uint32_t)slot_i;
-      if ((used >> slot) & 1u) goto irregular;
+      if ((used >> slot) & 1u) goto unsupported_gl;
       used |= 1u << slot;
       sj.slot[npos] = (uint8_t)slot;
       if (ent[0] == ent[1]) sj.pad[0] |= (uint8_t)(1u << k);
@@ -317,6 +317,13 @@ irregular:
   ov.resize(ov_mark);
   ov_pool.resize(pool_mark);
   return K_PROBLEM_RAW;
+unsupported_gl:
+  // a locus named twice, or two loci in one entry (after the per-side sort): the reference has no locus check and goes on
+  // with what gl2haps paired by index (impute.py:246-272) -- rows or a raw line, depending on the plan that answers
+  n_tok = tok_mark;
+  ov.resize(ov_mark);
+  ov_pool.resize(pool_mark);
+  return K_UNSUPPORTED_GL;
 }
 
 // The regular line -- "L*x+L*y^..." with '/' lists, every locus and allele known, parts already in sorted order, no 'g' /
@@ -913,7 +920,7 @@ void format_range(const FmtParams &fp, const char *text, const TokRange &tr, con
     const uint64_t i = first_line + j;
     const sv sid(text + tr.line[j].off, tr.line[j].id_len);
     const int kind = tr.kind[j];
-    if (kind == K_UNSUPPORTED) {
+    if (kind == K_UNSUPPORTED || kind == K_UNSUPPORTED_GL) {
       o.unsupported.push_back((uint32_t)j);
       continue;
     }

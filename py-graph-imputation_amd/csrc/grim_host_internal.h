@@ -126,7 +126,10 @@ struct DictSnap {
 void dict_snapshot(const grim_dict *d, DictSnap &out);
 
 // ---- tokenizer core: a byte range of whole lines -> per-line outcome, subject records, tokens -----------------------
-enum { K_DEV = 0, K_PROBLEM_ID = 1, K_PROBLEM_RAW = 2, K_MISS_NO_DEVICE = 3, K_UNSUPPORTED = 4 };
+// K_UNSUPPORTED: reason 5 (more alleles than a key field holds); K_UNSUPPORTED_GL: reason 8 (a GL string that names a locus
+// twice or mixes loci in one entry: the reference pairs the entries by index after a per-side string sort, impute.py:246-272,
+// and carries on with haplotypes over repeated loci -- not representable in a key, so reported, never silently different)
+enum { K_DEV = 0, K_PROBLEM_ID = 1, K_PROBLEM_RAW = 2, K_MISS_NO_DEVICE = 3, K_UNSUPPORTED = 4, K_UNSUPPORTED_GL = 5 };
 
 struct LineInfo {
   uint64_t off;     // start of the line in the text

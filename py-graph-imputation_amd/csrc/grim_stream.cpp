@@ -172,6 +172,29 @@ struct grim_stream {
   uint32_t cur_segment = 0;
   std::vector<std::array<uint64_t, 7>> seg_end;
   std::vector<uint8_t> seg_set;
+  // placed output (opts.placed, grim/shard.py): the files are shared with the other ranks of a job, so where a segment's
+  // piece of every file begins is only known once the pieces before it -- other ranks' -- have their sizes.  A committed chunk
+  // hands its formatted buffers to its segment and is done; the buffers are written when the caller places the segment.
+  struct SegBuf {
+    int k;
+    char *p;
+    size_t n;
+    uint64_t rel;  // offset inside the segment's piece of file k
+  };
+  struct PlacedWrite {
+    int k;
+    char *p;
+    size_t n;
+    uint64_t off;
+    std::atomic<int> *left;
+  };
+  bool placed = false;
+  std::vector<std::vector<SegBuf>> seg_bufs;
+  std::vector<std::array<uint64_t, 7>> seg_begin;  // cumulative text bytes at the segment's first commit
+  std::vector<uint8_t> seg_begun;
+  std::vector<uint64_t> seg_first_chunk;  // index of the segment's first chunk
+  std::deque<PlacedWrite> q_place;
+  std::condition_variable cv_place;
   std::vector<std::string> stale;  // earlier runs' output files, moved aside at open
   std::thread unlinker;
 
@@ -200,7 +223,11 @@ struct grim_stream {
   std::vector<CopyJob> copy_jobs;  // the pieces of the block in hand (COPY_PIECES at most), claimed one by one through copy_next by the
                                    // reader and its helpers alike: a helper that is late, or that the host took away for a while,
                                    // copies fewer pieces instead of holding the chunk up with its fixed share
-  std::atomic<uint32_t> copy_next{0}, copy_np{0};
+  // A claim is tied to its block: the ticket is (block number << 32 | next piece), the piece count is stored with the same
+  // block number.  A helper whose last fetch_add was an over-claim on block g and that is descheduled before it looks at the
+  // piece count can no longer take its stale index for a piece of block g + 1 (the count's block number differs: the claim
+  // is dropped) -- and a claim (g, k) with k < count(g) keeps copy_left above zero, so block g + 1 cannot be posted under it.
+  std::atomic<uint64_t> copy_ticket{0}, copy_np_gen{0};
   std::mutex copy_mu;
   std::condition_variable cv_copyjob;
   std::atomic<uint64_t> copy_gen{0};  // bumped (release) when the slots hold new jobs
@@ -685,13 +712,23 @@ static void commit_ready(grim_stream *s) {  // mu held: commits every chunk that
     if (!c || c->state != CH_FORMATTED) return;
     const grim_subject_result *res = engine_batch_host(c->batch)->res;
     bool any_file = false;
+    if (c->segment < s->seg_begun.size() && !s->seg_begun[c->segment]) {
+      s->seg_begun[c->segment] = 1;
+      for (int k = 0; k < 7; ++k) s->seg_begin[c->segment][k] = s->file_pos[k];
+    }
     for (uint32_t r = 0; r < c->n_ranges; ++r) {
       FmtRange &F = *c->fr[r];
       for (int k = 0; k < 7; ++k) {
         c->file_off[r][k] = s->file_pos[k];
         s->file_pos[k] += F.t[k].n;
         s->st.text_bytes[k] += F.t[k].n;
-        if (k < 6 && s->fd[k] >= 0) {
+        if (k < 6 && s->fd[k] >= 0 && s->placed) {  // placed output: the buffer waits in its segment for the segment's base
+          if (F.t[k].n) {
+            s->seg_bufs[c->segment].push_back({k, F.t[k].p, F.t[k].n, c->file_off[r][k] - s->seg_begin[c->segment][k]});
+            F.t[k].p = nullptr;
+            F.t[k].n = F.t[k].cap = 0;
+          }
+        } else if (k < 6 && s->fd[k] >= 0) {
           any_file = any_file || F.t[k].n;
         } else if (F.t[k].n) {  // in-memory sink: the buffer changes hands
           s->mem[k].emplace_back(F.t[k].p, F.t[k].n);
@@ -701,7 +738,7 @@ static void commit_ready(grim_stream *s) {  // mu held: commits every chunk that
       }
       for (uint32_t j : F.unsupported) {
         const TokRange &T = c->tr[r];
-        uint32_t reason = 5;
+        uint32_t reason = T.kind[j] == K_UNSUPPORTED_GL ? 8 : 5;
         if (T.kind[j] == K_DEV) reason = res[c->range_first_line[r] + j].reason;
         s->unsupported.push_back({c->first_line + c->range_first_line[r] + j, reason,
                                   std::string(c->text.data() + T.line[j].off, T.line[j].id_len)});
@@ -713,6 +750,7 @@ static void commit_ready(grim_stream *s) {  // mu held: commits every chunk that
     }
     ++s->next_commit;
     c->state = CH_COMMITTED;
+    s->cv_done.notify_all();  // (grim_stream_segment_wait)
     if (s->opt.want_records) s->cv_rec.notify_all();
     if (any_file) {
       c->pending.store((int)c->n_ranges);
@@ -787,14 +825,43 @@ static void run_write(grim_stream *s, Chunk *c, uint32_t r) {
   }
 }
 
+// one buffer of a placed segment: written at its final position, then released
+static void run_placed_write(grim_stream *s, const grim_stream::PlacedWrite &w) {
+  const auto t0 = Clock::now();
+  bool ok = true;
+  size_t done = 0;
+  while (done < w.n) {
+    const ssize_t k = pwrite(s->fd[w.k], w.p + done, w.n - done, (off_t)(w.off + done));
+    if (k < 0) {
+      if (errno == EINTR) continue;
+      ok = false;
+      break;
+    }
+    done += (size_t)k;
+  }
+  const int e = errno;
+  free(w.p);
+  s->wr_ns += (uint64_t)(secs(t0, Clock::now()) * 1e9);
+  std::lock_guard<std::mutex> lk(s->mu);
+  if (!ok) s->fail(std::string("writing an output file failed: ") + strerror(e));
+  if (w.left->fetch_sub(1) == 1) s->cv_place.notify_all();
+}
+
 static void worker_loop(grim_stream *s) {
   for (;;) {
     Task t;
-    bool more = false;
+    grim_stream::PlacedWrite pw{0, nullptr, 0, 0, nullptr};
+    bool more = false, have_pw = false;
     {
       std::unique_lock<std::mutex> lk(s->mu);
       for (;;) {
         if (s->stop) return;
+        if (!s->q_place.empty()) {
+          pw = s->q_place.front();
+          s->q_place.pop_front();
+          have_pw = true;
+          break;
+        }
         if (!s->q_hi.empty()) {
           t = s->q_hi.front();
           s->q_hi.pop_front();
@@ -807,9 +874,13 @@ static void worker_loop(grim_stream *s) {
         }
         s->cv_work.wait(lk);
       }
-      more = !s->q_hi.empty() || !s->q_lo.empty();
+      more = !s->q_hi.empty() || !s->q_lo.empty() || !s->q_place.empty();
     }
     if (more) s->cv_work.notify_one();
+    if (have_pw) {
+      run_placed_write(s, pw);
+      continue;
+    }
     if (t.type == 0) run_tokenize(s, t.c, t.r);
     else if (t.type == 1) run_format(s, t.c, t.r);
     else run_write(s, t.c, t.r);
@@ -853,9 +924,11 @@ static constexpr size_t COPY_PIECES = 64;
 static void copy_pieces(grim_stream *s) {
   for (;;) {
     // (a thread that comes back here from the block before may find the NEXT block posted already: the piece it takes then
-    //  is one of that block's -- everything about a block is written before copy_next goes back to 0)
-    const uint32_t k = s->copy_next.fetch_add(1, std::memory_order_acq_rel);
-    if (k >= s->copy_np.load(std::memory_order_relaxed)) return;
+    //  is one of that block's -- everything about a block is written before the ticket is reset with the block's number)
+    const uint64_t t = s->copy_ticket.fetch_add(1, std::memory_order_acq_rel);
+    const uint64_t ng = s->copy_np_gen.load(std::memory_order_acquire);
+    const uint32_t k = (uint32_t)t;
+    if ((ng >> 32) != (t >> 32) || k >= (uint32_t)ng) return;  // another block's count, or past the end of this one
     grim_stream::CopyJob &job = s->copy_jobs[k];
     job.n_nl = copy_and_mark(job.dst, job.src, job.n, job.nl.data());
     s->copy_left.fetch_sub(1, std::memory_order_release);
@@ -889,7 +962,7 @@ static void copier_loop(grim_stream *s, size_t) {
       }
       seen = gen;
     }
-    copy_pieces(s);  // (a helper that arrives after the block is done finds no piece: copy_next is past the end)
+    copy_pieces(s);  // (a helper that arrives after the block is done finds no piece: the ticket is past the end)
   }
 }
 
@@ -1157,10 +1230,11 @@ extern "C" int grim_stream_write(grim_stream *s, const char *text, uint64_t len)
           j.n_nl = 0;
           if (j.nl.size() < j.n + 64) j.nl.resize(j.n + 64);
         }
-        s->copy_np.store((uint32_t)parts, std::memory_order_relaxed);
+        const uint64_t blk_no = (s->copy_gen.load(std::memory_order_relaxed) + 1) & 0xFFFFFFFFull;  // only this thread writes copy_gen
+        s->copy_np_gen.store(blk_no << 32 | (uint64_t)parts, std::memory_order_release);
         s->copy_left.store((int)parts);
-        s->copy_next.store(0, std::memory_order_release);     // from here on pieces can be taken (no piece of the block before is
-                                                              // in flight: copy_left was 0)
+        s->copy_ticket.store(blk_no << 32, std::memory_order_release);  // from here on pieces can be taken (no piece of the block
+                                                                        // before is in flight: copy_left was 0)
         s->copy_gen.fetch_add(1, std::memory_order_release);  // ... and sleeping / looking helpers learn of the block
       }
       s->cv_copyjob.notify_all();
@@ -1299,6 +1373,49 @@ extern "C" int grim_stream_segment(grim_stream *s, uint64_t next_line_offset) {
   ++s->cur_segment;
   s->seg_end.push_back({{0, 0, 0, 0, 0, 0, 0}});
   s->seg_set.push_back(0);
+  s->seg_begin.push_back({{0, 0, 0, 0, 0, 0, 0}});
+  s->seg_begun.push_back(0);
+  s->seg_bufs.emplace_back();
+  s->seg_first_chunk.push_back(s->next_index);
+  s->cv_done.notify_all();  // the segment before this one is closed
+  return s->failed ? -1 : 0;
+}
+
+// Blocks until every chunk of segment k is committed -- the segment must be closed: a later one opened, or the input
+// finished -- and gives the bytes of its piece of each of the seven texts.
+extern "C" int grim_stream_segment_wait(grim_stream *s, uint32_t k, uint64_t sizes[7]) {
+  if (!s || !sizes) return -1;
+  std::unique_lock<std::mutex> lk(s->mu);
+  for (;;) {
+    if (s->failed || k >= s->seg_end.size()) return -1;
+    const bool closed = k < s->cur_segment || s->input_closed;  // (a chunk still being filled is counted by next_index)
+    const uint64_t end_chunk = k + 1 < s->seg_first_chunk.size() ? s->seg_first_chunk[k + 1] : s->next_index;
+    if (closed && s->next_commit >= end_chunk) break;
+    s->cv_done.wait_for(lk, std::chrono::milliseconds(50));
+  }
+  if (!s->seg_set[k]) {  // a segment without a line
+    for (int t = 0; t < 7; ++t) sizes[t] = 0;
+    return 0;
+  }
+  for (int t = 0; t < 7; ++t) sizes[t] = s->seg_end[k][t] - s->seg_begin[k][t];
+  return 0;
+}
+
+// Placed output: writes segment k's piece of every output file at base[t] (worker threads; returns when the bytes are
+// written).  A segment is placed once, after grim_stream_segment_wait returned for it.
+extern "C" int grim_stream_segment_place(grim_stream *s, uint32_t k, const uint64_t base[6]) {
+  if (!s || !base || !s->placed) return -1;
+  std::atomic<int> left{0};
+  std::unique_lock<std::mutex> lk(s->mu);
+  if (k >= s->seg_bufs.size() || s->failed) return -1;
+  std::vector<grim_stream::SegBuf> bufs;
+  bufs.swap(s->seg_bufs[k]);
+  if (bufs.empty()) return 0;
+  left.store((int)bufs.size());
+  for (const auto &b : bufs) s->q_place.push_back({b.k, b.p, b.n, base[b.k] + b.rel, &left});
+  s->cv_work.notify_all();
+  // (a failed stream's workers still drain the queue: `left` reaches zero either way)
+  s->cv_place.wait(lk, [&] { return left.load() == 0; });
   return s->failed ? -1 : 0;
 }
 
@@ -1316,7 +1433,10 @@ extern "C" int grim_stream_segment_end(const grim_stream *s, uint32_t k, uint64_
 extern "C" int grim_stream_finish(grim_stream *s) {
   if (!s) return -1;
   if (!s->input_closed) {
-    s->input_closed = true;
+    {
+      std::lock_guard<std::mutex> lk(s->mu);  // (grim_stream_segment_wait reads it from another thread)
+      s->input_closed = true;
+    }
     if (close_filling(s) != 0) return -1;
   }
   std::unique_lock<std::mutex> lk(s->mu);
@@ -1442,6 +1562,11 @@ extern "C" grim_stream *grim_stream_open(grim_ctx *ctx, const grim_graph *g, con
   s->next_line = opts->line_offset;
   s->seg_end.push_back({{0, 0, 0, 0, 0, 0, 0}});
   s->seg_set.push_back(0);
+  s->seg_begin.push_back({{0, 0, 0, 0, 0, 0, 0}});
+  s->seg_begun.push_back(0);
+  s->seg_bufs.emplace_back();
+  s->seg_first_chunk.push_back(0);
+  s->placed = opts->placed != 0;
   memset(&s->st, 0, sizeof(s->st));
   dict_snapshot(dict, s->snap);
   s->races.ps.alpha = priors->alpha;
@@ -1531,12 +1656,13 @@ extern "C" grim_stream *grim_stream_open(grim_ctx *ctx, const grim_graph *g, con
   for (int k = 0; k < 6; ++k)
     if (opts->out_path[k]) {
       struct stat sb;
-      if (stat(opts->out_path[k], &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > (1 << 20)) {
+      if (!s->placed && stat(opts->out_path[k], &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > (1 << 20)) {
         const std::string old = std::string(opts->out_path[k]) + ".grim_old." + std::to_string((long)getpid()) + "." + std::to_string(park_no++);
         struct stat so;
         if (lstat(old.c_str(), &so) != 0 && errno == ENOENT && rename(opts->out_path[k], old.c_str()) == 0) parked.emplace_back(old, opts->out_path[k]);
       }
-      s->fd[k] = open(opts->out_path[k], O_WRONLY | O_CREAT | O_TRUNC, 0644);
+      // (placed output: the file is the job's, other ranks write into it too -- whoever made it emptied it)
+      s->fd[k] = open(opts->out_path[k], s->placed ? (O_WRONLY | O_CREAT) : (O_WRONLY | O_CREAT | O_TRUNC), 0644);
       if (s->fd[k] < 0) {
         engine_set_error(ctx, (std::string("grim_stream_open: cannot create ") + opts->out_path[k] + ": " + strerror(errno)).c_str());
         for (int j = 0; j < k; ++j)
@@ -1606,5 +1732,7 @@ extern "C" void grim_stream_free(grim_stream *s) {
     if (s->fd[k] >= 0) close(s->fd[k]);
   for (int k = 0; k < 7; ++k)
     for (auto &b : s->mem[k]) free(b.first);
+  for (auto &v : s->seg_bufs)
+    for (auto &b : v) free(b.p);  // segments that were never placed (a failed job)
   delete s;
 }

@@ -297,7 +297,7 @@ class DeviceBatch:
 # ======================================================================================================
 # host-side helpers of the library (C++: allele dictionary, tokenizer, formatter) -- no GPU needed
 # ======================================================================================================
-K_DEVICE, K_PROBLEM_ID, K_PROBLEM_RAW, K_MISS_NO_DEVICE, K_UNSUPPORTED = 0, 1, 2, 3, 4
+K_DEVICE, K_PROBLEM_ID, K_PROBLEM_RAW, K_MISS_NO_DEVICE, K_UNSUPPORTED, K_UNSUPPORTED_GL = 0, 1, 2, 3, 4, 5
 
 EXPORTS += [
     "grim_dict_create", "grim_dict_free", "grim_dict_set_locus", "grim_dict_intern", "grim_dict_find", "grim_dict_name",
@@ -308,7 +308,7 @@ EXPORTS += [
     "grim_parsed_allele", "grim_prior_matrix", "grim_stream_open", "grim_stream_write", "grim_stream_write_file", "grim_stream_finish",
     "grim_stream_error", "grim_stream_text", "grim_stream_get_stats", "grim_stream_n_unsupported", "grim_stream_unsupported",
     "grim_stream_next_records", "grim_stream_release_records", "grim_stream_free", "grim_stream_write_text",
-    "grim_stream_segment", "grim_stream_n_segments", "grim_stream_segment_end", "grim_default_threads", "grim_chunk_offsets", "grim_free",
+    "grim_stream_segment", "grim_stream_n_segments", "grim_stream_segment_end", "grim_stream_segment_wait", "grim_stream_segment_place", "grim_default_threads", "grim_chunk_offsets", "grim_free",
 ]
 
 
@@ -320,7 +320,7 @@ class PriorSpec(C.Structure):
 class StreamOpts(C.Structure):
     _fields_ = [("chunk_lines", C.c_uint32), ("depth", C.c_uint32), ("n_threads", C.c_int32), ("line_offset", C.c_uint64),
                 ("rows_per_chunk", C.c_uint64), ("want_text", C.c_uint8), ("want_log", C.c_uint8), ("want_records", C.c_uint8),
-                ("timing", C.c_uint8), ("rows_exact", C.c_uint8), ("out_path", C.c_char_p * 6), ("mask_ids", C.c_char_p), ("mask_fixed", C.c_void_p),
+                ("timing", C.c_uint8), ("rows_exact", C.c_uint8), ("placed", C.c_uint8), ("out_path", C.c_char_p * 6), ("mask_ids", C.c_char_p), ("mask_fixed", C.c_void_p),
                 ("n_masks", C.c_uint32)]
 
 
@@ -437,6 +437,10 @@ def host_lib():
     L.grim_stream_n_segments.argtypes = [C.c_void_p]
     L.grim_stream_segment_end.restype = C.c_int
     L.grim_stream_segment_end.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]
+    L.grim_stream_segment_wait.restype = C.c_int
+    L.grim_stream_segment_wait.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]
+    L.grim_stream_segment_place.restype = C.c_int
+    L.grim_stream_segment_place.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]
     L.grim_default_threads.restype = C.c_uint32
     L.grim_chunk_offsets.restype = C.c_int64
     L.grim_chunk_offsets.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(C.POINTER(C.c_uint64))]
@@ -701,7 +705,8 @@ class Stream:
     """grim_stream: the chunked tokenizer -> device -> formatter pipeline (impute_file's loop)."""
 
     def __init__(self, ctx, dgraph, adict, params, ps, pops, out_paths=None, want_text=True, want_log=False, want_records=False,
-                 chunk_lines=0, depth=0, n_threads=0, line_offset=0, rows_per_chunk=0, timing=False, masks=None, rows_exact=False):
+                 chunk_lines=0, depth=0, n_threads=0, line_offset=0, rows_per_chunk=0, timing=False, masks=None, rows_exact=False,
+                 placed=False):
         L = host_lib()
         self.ctx = ctx
         o = StreamOpts()
@@ -715,6 +720,7 @@ class Stream:
         o.want_records = 1 if want_records else 0
         o.timing = 1 if timing else 0
         o.rows_exact = 1 if rows_exact else 0
+        o.placed = 1 if placed else 0
         self._keep = [params, ps]
         if out_paths:
             for k, key in enumerate(TEXT_KEYS):
@@ -757,6 +763,17 @@ class Stream:
             L.grim_stream_segment_end(self.h, k, v)
             out.append([int(x) for x in v])
         return out
+
+    def segment_wait(self, k):
+        """placed output: blocks until the (closed) segment k is formatted; -> bytes of its piece of the seven texts"""
+        v = (C.c_uint64 * 7)()
+        self._check(host_lib().grim_stream_segment_wait(self.h, int(k), v))
+        return [int(x) for x in v]
+
+    def segment_place(self, k, base):
+        """placed output: writes segment k's piece of every output file at base[t]; returns when the bytes are written"""
+        v = (C.c_uint64 * 6)(*[int(x) for x in base])
+        self._check(host_lib().grim_stream_segment_place(self.h, int(k), v))
 
     def write_file(self, path):
         self._check(host_lib().grim_stream_write_file(self.h, os.fsencode(path)))

@@ -21,12 +21,13 @@ import numpy as np
 from .. import _native as nat
 
 # outcome of tokenising one input line
-_DEV, _PROBLEM_ID, _PROBLEM_RAW, _MISS_NO_DEVICE = 0, 1, 2, 3
+_DEV, _PROBLEM_ID, _PROBLEM_RAW, _MISS_NO_DEVICE, _UNSUPPORTED_GL = 0, 1, 2, 3, 5
 
 REASONS = {
     2: "Plan B / Plan C fallback not resolved on the device (internal)",
     3: "Plan C for a subject whose '/'-lists stay above number_of_options_threshold after the most-common-allele reduction",
     5: "more than 4096 alleles in one GL string",
+    8: "a GL string that names a locus twice or mixes loci in one entry (the reference pairs the entries by index, impute.py:246-272)",
 }
 
 
@@ -213,14 +214,14 @@ class Imputation(object):
             alts1, alts2 = side1[k].split("/"), side2[k].split("/")
             loci = {a.split("*")[0] for a in alts1} | {a.split("*")[0] for a in alts2}
             if len(loci) != 1:
-                raise ValueError("irregular GL string: mixed loci in one entry")
+                return _UNSUPPORTED_GL, None  # reason 8: the reference goes on with what gl2haps paired by index
             locus = loci.pop()
             if locus not in g.locus_slot:
                 unknown_locus = True
                 continue
             s = g.locus_slot[locus]
             if s in slots:
-                raise ValueError("irregular GL string: locus given twice")
+                return _UNSUPPORTED_GL, None
             slots.append(s)
             if side1[k] == side2[k]:
                 same |= 1 << k
@@ -368,6 +369,8 @@ class Imputation(object):
             return subject_id, None, None
         res_m = {"MaxProb": 0, "Haps": {}, "Pops": {}}
         res_h = {"Haps": [], "Probs": [], "Pops": []}
+        if kind == _UNSUPPORTED_GL:
+            raise UnsupportedSubjects([(0, subject_id, 8)])
         if kind == _MISS_NO_DEVICE:
             return subject_id, res_m, res_h
         pidx = self._prior_index(race1 or "", race2 or "", priority)
@@ -576,9 +579,10 @@ class Imputation(object):
                 res, rows = self._run_arrays(subj, parsed.tokens(), priors, params)
             else:
                 res, rows = np.zeros(0, dtype=nat.RESULT_DT), np.zeros(0, dtype=nat.ROW_DT)
-            bad_lines = [int(j) for j in range(len(kinds)) if kinds[j] == nat.K_UNSUPPORTED or
+            host_reason = {nat.K_UNSUPPORTED: 5, nat.K_UNSUPPORTED_GL: 8}
+            bad_lines = [int(j) for j in range(len(kinds)) if kinds[j] in host_reason or
                          (kinds[j] == nat.K_DEVICE and res["status"][dev[j]] == nat.ST_UNSUPPORTED)]
-            self.unsupported = [(line_offset + j, parsed.subject_id(j), 5 if kinds[j] == nat.K_UNSUPPORTED else int(res[dev[j]]["reason"]))
+            self.unsupported = [(line_offset + j, parsed.subject_id(j), host_reason[kinds[j]] if kinds[j] in host_reason else int(res[dev[j]]["reason"]))
                                 for j in bad_lines]
             if self.unsupported and self.on_unsupported == "raise":
                 raise UnsupportedSubjects(self.unsupported)
@@ -642,8 +646,9 @@ class Imputation(object):
         else:
             res, rows = np.zeros(0, dtype=nat.RESULT_DT), np.zeros(0, dtype=nat.ROW_DT)
 
-        bad = [(line_offset + i, outcome[i][1], int(res[outcome[i][3]]["reason"])) for i in range(len(outcome))
-               if outcome[i][0] == _DEV and res[outcome[i][3]]["status"] == nat.ST_UNSUPPORTED]
+        bad = [(line_offset + i, outcome[i][1], 8 if outcome[i][0] == _UNSUPPORTED_GL else int(res[outcome[i][3]]["reason"]))
+               for i in range(len(outcome))
+               if outcome[i][0] == _UNSUPPORTED_GL or (outcome[i][0] == _DEV and res[outcome[i][3]]["status"] == nat.ST_UNSUPPORTED)]
         self.unsupported = bad
         if bad and self.on_unsupported == "raise":
             raise UnsupportedSubjects(bad)

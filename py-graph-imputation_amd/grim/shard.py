@@ -7,17 +7,20 @@ per-chunk outputs), with three differences: workers are GPU ranks; chunks are ha
 varies by more than 1000x with its ambiguity, so equal line counts are not equal work -- SURVEY 8e); `.miss/.problem`
 keep the GLOBAL line index (the reference's per-chunk runs restart at 0).
 
-Data path of a rank: ONE long-lived streaming pipeline (grim_stream: tokenizer threads -> device -> formatter threads ->
-ordered pwrite) for the whole job.  A pulled chunk is a byte range of the input file; its raw bytes go to the stream as one
-input SEGMENT (grim_stream_segment carries the chunk's global line index), so chunk k+1 is tokenised while chunk k is on
-the device -- no per-chunk stream, no Python line splitting.  The rank's six outputs are six PART FILES that grow in the
-order the rank pulled its chunks; a manifest records, per chunk, where its piece of every part file ends.  Rank 0 then
-assembles the final files in chunk order with copy_file_range (the kernel moves the bytes; nothing is read back into
-Python).
+Data path of a rank: ONE long-lived streaming pipeline (grim_stream: tokenizer threads -> device -> formatter threads)
+for the whole job.  A pulled chunk is a byte range of the input file; its raw bytes go to the stream as one input SEGMENT
+(grim_stream_segment carries the chunk's global line index), so chunk k+1 is tokenised while chunk k is on the device -- no
+per-chunk stream, no Python line splitting.
+
+Outputs are written ONCE, straight into the six final files, by every rank (no part files, no `cat`): as soon as a chunk
+is formatted its rank publishes the SIZES of its six pieces on the job's store; where chunk c's pieces begin is the sum of
+the sizes of the chunks before it, so only sizes wait for sizes -- a rank's placer thread picks them up and the stream's
+worker threads pwrite the formatted buffers at their final offsets (grim_stream_segment_wait / _place) while the pipeline
+is already busy with later chunks.
 
 The only communication is the control plane: an atomic fetch-add on the job's rendezvous store (the next chunk number),
-the job's unique parts directory name, one barrier at the end, and an error slot per rank so that a rank that fails does
-not leave the others waiting.
+the job's id, six sizes per chunk, one barrier at the end, and an error slot per rank so that a rank that fails does not
+leave the others waiting.
 
 Launch:  torchrun --nproc-per-node N --master-addr 127.0.0.1 your_script.py   ->  impute_sharded(conf)
 (`impute_sharded` joins the job itself -- gloo, control plane only -- when the caller has not initialised
@@ -27,7 +30,9 @@ torch.distributed; alone, without WORLD_SIZE > 1, it runs every chunk in this pr
 import json
 import os
 import pathlib
-import shutil
+import queue
+import threading
+import time
 import traceback
 import uuid
 
@@ -54,6 +59,11 @@ def chunk_offsets(path, chunk_lines):
     from . import _native as nat
 
     return nat.chunk_offsets(path, chunk_lines)
+
+
+class _PeerFailed(RuntimeError):
+    """another rank reported an error while this one was waiting for something of its: this rank stops, the failure is the
+    other rank's"""
 
 
 class _Control:
@@ -103,6 +113,25 @@ class _Control:
             return v
         return self.store.get(key).decode()
 
+    def set(self, key, value):
+        if self.store is not None:
+            self.store.set(key, value)
+
+    def wait_key(self, key, tag, poll=0.0005):
+        """the value of a key some rank will set -- POLLED (a blocking get would hold the store client, and with it this
+        rank's chunk counter, for as long as it waits); raises when a rank has reported an error meanwhile"""
+        last_look = 0.0
+        while True:
+            if self._has(key):
+                return self.store.get(key).decode()
+            now = time.monotonic()
+            if now - last_look > 0.05:
+                last_look = now
+                for r in range(self.world):
+                    if r != self.rank and self._has("grim_err_%s_%d" % (tag, r)):
+                        raise _PeerFailed("rank %d failed while this rank was waiting for %s" % (r, key))
+            time.sleep(poll)
+
     def report_error(self, tag, text):
         if self.store is not None:
             self.store.set("grim_err_%s_%d" % (tag, self.rank), text)
@@ -138,10 +167,37 @@ class _Control:
             return False
 
 
-class _StreamSink:
-    """a rank's data path: one grim_stream for the whole job, a chunk = one input segment, outputs = six part files"""
+class _Placement:
+    """where chunk c's piece of each output file begins: the sum of the sizes of the chunks before it, whoever ran them.
+    Sizes travel through the job's store (one key per chunk, set once); a rank asks in increasing chunk order, so its
+    running prefix only ever moves forward."""
 
-    def __init__(self, imp, config, hap_pop_pair, part_paths, flags):
+    def __init__(self, ctl, tag):
+        self.ctl, self.tag = ctl, tag
+        self.own = {}
+        self.upto, self.prefix = 0, [0] * 6
+
+    def publish(self, c, sizes):
+        sizes = [int(x) for x in sizes[:6]]
+        self.own[c] = sizes
+        self.ctl.set("grim_sz_%s_%d" % (self.tag, c), ",".join(str(x) for x in sizes))
+
+    def base(self, c):
+        while self.upto < c:
+            sz = self.own.get(self.upto)
+            if sz is None:
+                sz = [int(x) for x in self.ctl.wait_key("grim_sz_%s_%d" % (self.tag, self.upto), self.tag).split(",")]
+            self.prefix = [a + b for a, b in zip(self.prefix, sz)]
+            self.upto += 1
+        return list(self.prefix)
+
+
+class _StreamSink:
+    """a rank's data path: one grim_stream for the whole job, a chunk = one input segment.  Alone: the stream appends to the
+    six output files.  In a job: `placement` says where a segment's pieces go in the SHARED files, a placer thread asks for
+    it segment by segment while the main thread keeps feeding."""
+
+    def __init__(self, imp, config, hap_pop_pair, out_paths, flags, placement=None):
         from . import _native as nat
 
         self.nat = nat
@@ -149,32 +205,68 @@ class _StreamSink:
         params = imp._params(config, planb, hap_pop_pair, False)
         ps, keep = nat.prior_spec(config["priority"], imp.unk_priors, imp.count_by_prob)
         ctx = nat.default_context(imp.device)
-        out_paths = {k: part_paths[k] for k in OUTPUT_KEYS if flags[k]}
+        paths = {k: out_paths[k] for k in OUTPUT_KEYS if flags[k]}
         self._keep = (params, ps, keep)
         self.imp = imp
+        self.placement = placement
         self.st = nat.Stream(ctx, imp.netGraph.device(ctx), imp.netGraph.adict, params, ps, imp.populations,
-                             out_paths=out_paths, want_log=False, masks=imp._phase_masks(config))
+                             out_paths=paths, want_log=False, masks=imp._phase_masks(config), placed=placement is not None)
         self.first = True
+        self.seg = 0
+        self.placer_error = None
+        self.todo = queue.Queue()
+        self.placer = None
+        if placement is not None:
+            self.placer = threading.Thread(target=self._place_loop, name="grim-placer", daemon=True)
+            self.placer.start()
 
-    def feed(self, raw, line_offset):
+    def _place_loop(self):
+        try:
+            while True:
+                item = self.todo.get()
+                if item is None:
+                    return
+                c, seg = item
+                sizes = self.st.segment_wait(seg)  # (returns once the segment is closed -- the next feed, or finish -- and formatted)
+                self.placement.publish(c, sizes)
+                self.st.segment_place(seg, self.placement.base(c))
+        except BaseException as e:  # noqa: B902  (handed to the main thread: feed / finish raise it)
+            self.placer_error = e
+
+    def feed(self, raw, line_offset, chunk_no):
+        if self.placer_error is not None:
+            raise self.placer_error
         if not self.first or line_offset:
             self.st.segment(line_offset)  # (the first chunk is segment 0 unless it does not start at line 0)
+            self.seg += 1
         self.first = False
         self.st.write_text(raw)
+        if self.placer is not None:
+            self.todo.put((chunk_no, self.seg))
 
     def finish(self):
-        """-> per fed chunk, cumulative bytes of the six texts at its end"""
         try:
-            self.st.finish()
-            ends = self.st.segment_ends()
+            self.st.finish()  # end of input: the last segment is closed; returns when every chunk is formatted (placed
+            #                   output) resp. written (alone)
+            if self.placer is not None:
+                self.todo.put(None)
+                self.placer.join()
+                self.placer = None
+                if self.placer_error is not None:
+                    raise self.placer_error
             self.imp.unsupported = self.st.unsupported()
         finally:
-            self.st.close()
-        return [e[:6] for e in ends]
+            self.abort()
 
     def abort(self):
         try:
-            self.st.close()
+            if self.placer is not None:
+                self.todo.put(None)
+                self.st.close()  # (fails the waits of the placer thread)
+                self.placer.join(timeout=5)
+                self.placer = None
+            else:
+                self.st.close()
         except Exception:
             pass
 
@@ -182,14 +274,16 @@ class _StreamSink:
 class _ComputeSink:
     """the same layout from an injected per-chunk compute(config, lines, line_offset) -> texts (tests: the oracle)"""
 
-    def __init__(self, compute, config, part_paths, flags):
+    def __init__(self, compute, config, out_paths, flags, placement=None):
         self.compute, self.config = compute, config
-        self.fh = {k: open(part_paths[k], "wb") for k in OUTPUT_KEYS if flags[k]}
-        self.pos = {k: 0 for k in OUTPUT_KEYS}
-        self.ends = [[0] * 6]  # segment 0 (empty until the first chunk without an offset arrives)
-        self.first = True
+        self.placement = placement
+        self.unsupported = []
+        if placement is None:
+            self.fh = {k: open(out_paths[k], "wb") for k in OUTPUT_KEYS if flags[k]}
+        else:
+            self.fd = {k: os.open(out_paths[k], os.O_WRONLY) for k in OUTPUT_KEYS if flags[k]}
 
-    def feed(self, raw, line_offset):
+    def feed(self, raw, line_offset, chunk_no):
         import io
 
         # universal newlines, as the product path's grim_stream_write_text
@@ -198,48 +292,36 @@ class _ComputeSink:
         if text.endswith("\n") or not text:
             lines.pop()  # the text ended with a line end: what follows it is not a line
         texts = self.compute(self.config, lines, line_offset)
+        data = {}
         for k in OUTPUT_KEYS:
-            data = texts.get(k, "")
-            if data and k in self.fh:
-                data = data if isinstance(data, bytes) else data.encode()
-                self.fh[k].write(data)
-                self.pos[k] += len(data)
-        if self.first and not line_offset:
-            self.ends[0] = [self.pos[k] for k in OUTPUT_KEYS]
-        else:
-            self.ends.append([self.pos[k] for k in OUTPUT_KEYS])
-        self.first = False
+            d = texts.get(k, "")
+            data[k] = d if isinstance(d, bytes) else d.encode()
+        if self.placement is None:
+            for k in OUTPUT_KEYS:
+                if data[k] and k in self.fh:
+                    self.fh[k].write(data[k])
+            return
+        self.placement.publish(chunk_no, [len(data[k]) if k in self.fd else 0 for k in OUTPUT_KEYS])
+        base = self.placement.base(chunk_no)
+        for ki, k in enumerate(OUTPUT_KEYS):
+            if data[k] and k in self.fd:
+                os.pwrite(self.fd[k], data[k], base[ki])
 
     def finish(self):
-        for fh in self.fh.values():
-            fh.close()
-        return self.ends
+        self.abort()
 
     def abort(self):
-        for fh in self.fh.values():
+        for fh in getattr(self, "fh", {}).values():
             try:
                 fh.close()
             except Exception:
                 pass
-
-
-def _copy_range(src_fd, dst_fd, off, n, dst_off):
-    """n bytes of src from offset off to dst at offset dst_off: copy_file_range where the kernel offers it (the bytes never
-    enter this process), pread / pwrite otherwise"""
-    while n > 0:
-        try:
-            k = os.copy_file_range(src_fd, dst_fd, n, offset_src=off, offset_dst=dst_off)
-        except (AttributeError, OSError):
-            k = -1
-        if k <= 0:
-            buf = os.pread(src_fd, min(n, 1 << 24), off)
-            if not buf:
-                raise IOError("part file shorter than its manifest says")
-            os.pwrite(dst_fd, buf, dst_off)
-            k = len(buf)
-        off += k
-        dst_off += k
-        n -= k
+        for fd in getattr(self, "fd", {}).values():
+            try:
+                os.close(fd)
+            except Exception:
+                pass
+        self.fh, self.fd = {}, {}
 
 
 def impute_sharded(conf_file, hap_pop_pair=False, graph=None, compute=None, project_dir_graph="",
@@ -247,33 +329,43 @@ def impute_sharded(conf_file, hap_pop_pair=False, graph=None, compute=None, proj
     """Run `impute` across the ranks of the torch.distributed job (or alone if there is none).  `compute(config, lines,
     line_offset) -> texts` can be injected (tests); the default runs the HIP engine on this rank's GPU (LOCAL_RANK) as one
     stream per rank.  Rank 0 returns {key: path of the final file} (the texts themselves with return_texts=True: a test
-    convenience -- the product path never reads its outputs back), the other ranks None; every rank raises when any rank
-    failed."""
+    convenience -- the product path never reads its outputs back) plus "unsupported": the subjects of ALL ranks the device
+    could not take, as (global line, id, reason), when GRIM_ON_UNSUPPORTED=skip let the job go on without them; the other
+    ranks return None.  Every rank raises when any rank failed -- a rank that met unsupported subjects in the default
+    `raise` mode included, exactly as the single-GPU impute_file does."""
     from .run_impute_def import load_config
-    from .imputation.impute import Imputation as _I
+    from .imputation.impute import Imputation as _I, UnsupportedSubjects
 
     ctl = _Control()
     chunk_lines = int(chunk_lines or os.environ.get("GRIM_SHARD_LINES", DEFAULT_CHUNK_LINES))
     names = {key: (path_key, flag) for key, path_key, flag in _I._OUT_FILES}
-    error = None
+    error = peer_failed = None
     sink = None
-    parts_dir = None
-    alone = ctl.world == 1  # nothing to merge: the one rank's part files ARE the outputs
-    # the job's id: unique per call and per job, published by rank 0 -- a parts directory left behind by a run that died
-    # can never be taken for this run's (and the manifests, not a directory listing, say what gets merged)
+    files_announced = False
+    alone = ctl.world == 1  # the one rank's stream appends to the output files: nothing to place
+    # the job's id: unique per call and per job, published by rank 0 (keys of an earlier job on the same store never match)
     tag = ctl.share("grim_job_%d" % _next_call(), lambda: uuid.uuid4().hex[:12])
+    files_key = "grim_files_" + tag
+    config = flags = None
+    n_chunks = 0
+    placement = None if alone else _Placement(ctl, tag)
+    unsupported = []
     try:
         config, out_dir = load_config(conf_file, project_dir_graph, project_dir_in_file)
         in_path = config["imputation_input_file"]
         flags = {k: (names[k][1] is None or bool(config[names[k][1]])) for k in OUTPUT_KEYS}
+        out_paths = {k: config[names[k][0]] for k in OUTPUT_KEYS}
         if ctl.rank == 0:
             pathlib.Path(out_dir).mkdir(parents=False, exist_ok=True)
-        if alone:
-            part_paths = {k: config[names[k][0]] for k in OUTPUT_KEYS}
-        else:
-            parts_dir = os.path.join(out_dir, ".grim_parts_" + tag)
-            pathlib.Path(parts_dir).mkdir(parents=True, exist_ok=True)
-            part_paths = {k: os.path.join(parts_dir, "%s.rank%d" % (k, ctl.rank)) for k in OUTPUT_KEYS}
+            if not alone:
+                # the shared output files: made (emptied) by rank 0 before any rank opens them for its pieces
+                for k in OUTPUT_KEYS:
+                    if flags[k]:
+                        os.close(os.open(out_paths[k], os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644))
+                ctl.set(files_key, "ok")
+                files_announced = True
+        elif ctl.wait_key(files_key, tag) != "ok":
+            raise RuntimeError("impute_sharded: rank 0 could not create the output files")
         offs = chunk_offsets(in_path, chunk_lines)
         n_chunks = len(offs) - 1
         if compute is None:
@@ -284,33 +376,34 @@ def impute_sharded(conf_file, hap_pop_pair=False, graph=None, compute=None, proj
                 graph = Graph(config).build_graph(config["node_file"], config["top_links_file"], config["edges_file"])
             n_dev = max(1, nat.lib().grim_device_count())
             imp = _I(graph, config, device=ctl.local % n_dev)
-            sink = _StreamSink(imp, config, hap_pop_pair, part_paths, flags)
+            sink = _StreamSink(imp, config, hap_pop_pair, out_paths, flags, placement)
         else:
-            sink = _ComputeSink(compute, config, part_paths, flags)
-        mine = []  # chunks this rank pulled, in order
+            imp = None
+            sink = _ComputeSink(compute, config, out_paths, flags, placement)
         with open(in_path, "rb") as fh:
             while True:
                 c = ctl.next_chunk(tag)
                 if c >= n_chunks:
                     break
                 fh.seek(offs[c])
-                sink.feed(fh.read(offs[c + 1] - offs[c]), c * chunk_lines)
-                mine.append(c)
-        ends = sink.finish()
+                sink.feed(fh.read(offs[c + 1] - offs[c]), c * chunk_lines, c)
+        sink.finish()
         sink = None
-        # segment 0 exists even when the first chunk opened a new segment (it did unless it was chunk 0): drop the empty one
-        if len(ends) == len(mine) + 1:
-            ends = ends[1:]
-        if len(ends) != len(mine):
-            raise RuntimeError("internal: %d segments for %d chunks" % (len(ends), len(mine)))
-        if not alone:
-            with open(os.path.join(parts_dir, "manifest.rank%d.json" % ctl.rank), "w") as fh:
-                json.dump({"chunks": mine, "ends": ends}, fh)
+        # subjects the device could not take: the single-GPU path raises unless told to skip them, so does every rank here
+        unsupported = list(imp.unsupported) if imp is not None else []
+        if unsupported and imp.on_unsupported == "raise":
+            raise UnsupportedSubjects(unsupported)
+        ctl.set("grim_unsup_%s_%d" % (tag, ctl.rank), json.dumps(unsupported))
     except BaseException as e:  # the other ranks must not wait for this one forever: report, reach the barrier, raise
-        error = e
         if sink is not None:
             sink.abort()
-        ctl.report_error(tag, "%s: %s\n%s" % (type(e).__name__, e, traceback.format_exc()))
+        if isinstance(e, _PeerFailed):
+            peer_failed = e  # not this rank's failure: the barrier's error list names the rank whose it is
+        else:
+            error = e
+            ctl.report_error(tag, "%s: %s\n%s" % (type(e).__name__, e, traceback.format_exc()))
+        if ctl.rank == 0 and not alone and not files_announced:
+            ctl.set(files_key, "failed")
     failed = ctl.barrier_and_errors(tag)
     result = None
     try:
@@ -318,50 +411,19 @@ def impute_sharded(conf_file, hap_pop_pair=False, graph=None, compute=None, proj
             raise error
         if failed:
             raise RuntimeError("impute_sharded: rank(s) %s failed:\n%s" % ([r for r, _ in failed], failed[0][1]))
-        if not alone:
-            # every rank reads every manifest: where chunk c's piece of every output sits in its rank's part file, hence
-            # where it belongs in the final file (the sizes of the chunks before it) -- and moves ITS OWN pieces there, so the
-            # merge is as parallel as the job.  Rank 0 creates the files at their final size first.
-            where = {}  # chunk -> (rank, start offsets in the part file, end offsets)
-            for r in range(ctl.world):
-                with open(os.path.join(parts_dir, "manifest.rank%d.json" % r)) as fh:
-                    m = json.load(fh)
-                prev = [0] * 6
-                for c, e in zip(m["chunks"], m["ends"]):
-                    where[c] = (r, prev, e)
-                    prev = e
-            missing = [c for c in range(n_chunks) if c not in where]
-            if missing:
-                raise RuntimeError("impute_sharded: no rank reported chunk(s) %s" % missing[:8])
-            final_off = [[0] * 6]  # final_off[c][k]: where chunk c's piece of output k starts in the final file
-            for c in range(n_chunks):
-                r, a, e = where[c]
-                final_off.append([final_off[-1][k] + e[k] - a[k] for k in range(6)])
-            if ctl.rank == 0:
-                for ki, k in enumerate(OUTPUT_KEYS):
-                    if flags[k]:
-                        fd = os.open(config[names[k][0]], os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
-                        try:
-                            os.ftruncate(fd, final_off[n_chunks][ki])
-                        finally:
-                            os.close(fd)
-            ctl.barrier()
-            for ki, k in enumerate(OUTPUT_KEYS):
-                if not flags[k]:
-                    continue
-                pieces = [(c, where[c]) for c in range(n_chunks) if where[c][0] == ctl.rank and where[c][2][ki] > where[c][1][ki]]
-                if not pieces:
-                    continue
-                src = os.open(os.path.join(parts_dir, "%s.rank%d" % (k, ctl.rank)), os.O_RDONLY)
-                dst = os.open(config[names[k][0]], os.O_WRONLY)
-                try:
-                    for c, (r, a, e) in pieces:
-                        _copy_range(src, dst, a[ki], e[ki] - a[ki], final_off[c][ki])
-                finally:
-                    os.close(src)
-                    os.close(dst)
+        if peer_failed is not None:
+            raise peer_failed
         if ctl.rank == 0:
-            result = {}
+            if not alone:
+                total = placement.base(n_chunks)  # every size is on the store by now
+                for ki, k in enumerate(OUTPUT_KEYS):
+                    if flags[k] and os.path.getsize(out_paths[k]) != total[ki]:
+                        raise RuntimeError("impute_sharded: %s holds %d bytes, the chunks add up to %d" % (
+                            out_paths[k], os.path.getsize(out_paths[k]), total[ki]))
+                for r in range(1, ctl.world):
+                    unsupported += [tuple(u) for u in json.loads(ctl.wait_key("grim_unsup_%s_%d" % (tag, r), tag))]
+                unsupported.sort(key=lambda u: u[0])
+            result = {"unsupported": [tuple(u) for u in unsupported]}
             for k in OUTPUT_KEYS:
                 path_key, _ = names[k]
                 if not flags[k]:
@@ -369,9 +431,7 @@ def impute_sharded(conf_file, hap_pop_pair=False, graph=None, compute=None, proj
                 elif not return_texts:
                     result[k] = config[path_key]
     finally:
-        ctl.barrier()  # nobody removes the parts before every rank is through with them
-        if ctl.rank == 0 and parts_dir is not None:
-            shutil.rmtree(parts_dir, ignore_errors=True)
+        ctl.barrier()  # one barrier at the end on every path: nobody leaves while another rank still reads the store
     if ctl.rank == 0 and return_texts and result is not None:
         for k in OUTPUT_KEYS:
             if flags[k]:

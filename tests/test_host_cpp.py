@@ -43,7 +43,7 @@ def _decode(g, subj, toks, parsed=None, lines_of=None):
     return out
 
 
-@pytest.mark.parametrize("scenario", ["cau_edge", "cau_mixed", "pop4_edge", "pop4_mixed", "cau_filter", "cau_planc"])
+@pytest.mark.parametrize("scenario", ["cau_edge", "cau_mixed", "pop4_edge", "pop4_mixed", "cau_filter", "cau_planc", "cau_irregular"])
 def test_cpp_tokenizer_equals_python_tokenizer(scenario):
     from grim import _native as nat
     from grim.imputation import impute as I

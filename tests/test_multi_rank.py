@@ -1,4 +1,5 @@
-"""N>1 path on CPU: world_size-2 and -3 gloo jobs, chunks pulled from the job's store, part files concatenated by rank 0.
+"""N>1 path on CPU: world_size-2 and -3 gloo jobs, chunks pulled from the job's store, every rank writing its pieces straight
+into the shared output files at the offsets the published chunk sizes imply.
 The per-chunk compute is injected (the oracle) -- what is under test is grim/shard.py; the default (HIP) compute under a
 process group is tests/test_multi_rank_gpu.py."""
 import json
@@ -117,8 +118,9 @@ def test_world_size_2_gloo(tmp_path):
 
 
 def test_failed_run_then_good_run_in_the_same_directory(tmp_path):
-    """a job that dies leaves nothing a later job in the same output directory could pick up: the parts directory is the
-    job's own (unique id from the store), is removed on the error path too, and the merge follows the manifests"""
+    """a job that dies leaves nothing a later job in the same output directory could pick up: there are no part files (every
+    rank writes into the final files, which rank 0 empties first), the store keys carry the job's own id, and part
+    directories of older builds lying around are never read"""
     rows = synth.read_freqs(synth.CAU_FREQS)
     lines = synth.SubjectGen(rows, 81).mixed(30) + synth.edge_cases("CAU")[:4]
     work, conf, out = _launch(tmp_path, 2, 5, lines, 29523, fail_rank=1, tag="mrs")

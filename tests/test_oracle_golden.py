@@ -95,3 +95,21 @@ def test_oracle_intermediates_equal_reference_dump(name, monkeypatch):
         assert len(tops) == exp[sid]["top"]["calls"], (sid, "number of convert_list_to_one_dim calls")
         assert tops[:4] == exp[sid]["top"]["first"], (sid, "first top lists")
         assert hashlib.sha256(repr(tops).encode()).hexdigest() == exp[sid]["top"]["sha256"], (sid, "top lists")
+
+
+def test_every_golden_directory_is_named_in_a_committed_generator():
+    """tests/golden/<dir> is data a committed script made from the real reference: every scenario directory must be the
+    target of a `run_scenario("<dir>", ...)` call in tools/make_golden*.py, every other entry of tests/golden/ must be
+    named there too -- so `python tools/make_golden.py` (or GOLDEN_ONLY=<dir>) can always re-make the committed bytes."""
+    import glob
+    import os
+    import re
+
+    src = "".join(open(f).read() for f in sorted(glob.glob(os.path.join(harness.HERE, "make_golden*.py"))))
+    named = set(re.findall(r'run_scenario\(\s*"([A-Za-z0-9_]+)"', src))
+    missing = [s for s in harness.scenarios() if s not in named]
+    assert not missing, "golden scenarios without a generator call: %s" % missing
+    for entry in sorted(os.listdir(harness.GOLD)):
+        if entry in named:
+            continue
+        assert entry.split(".")[0] in src, "tests/golden/%s is not named in any tools/make_golden*.py" % entry

@@ -381,5 +381,25 @@ def main():
                  dict(bc, UNK_priors="MR", number_of_options_threshold=8))
 
 
+    # save_space_mode (open_option_ cuts either operand to its ten largest entries, impute.py:1048-1059).  The subject lines of
+    # these two are the committed tests/golden/<name>/input.csv (mixed + plan_c_cases + edge cases / plan_c_wide_cases; the
+    # generator call of the round they were made in was not kept): the outputs are re-made from them.
+    def committed_input(name):
+        return [l.rstrip("\n") for l in open(os.path.join(GOLD, name, "input.csv"))]
+
+    run_scenario("cau_save", w1, ["CAU"], committed_input("cau_save"), {"save_space_mode": True})
+    run_scenario("pop4_save", w4, POP4, committed_input("pop4_save"), {"UNK_priors": "MR", "save_space_mode": True})
+    # GL strings that name a locus twice or mix loci in an entry: what the reference makes of them (this build reports such
+    # subjects -- reason 8 -- instead of answering)
+    irr = synth.irregular_cases("CAU")
+    mix = synth.SubjectGen(cau, 41).mixed(30)
+    irr_lines = [x for pair in zip(mix[:10], irr) for x in pair] + mix[10:]
+    run_scenario("cau_irregular", w1, ["CAU"], irr_lines)
+    run_scenario("cau_irregular_noplanb", w1, ["CAU"], irr_lines, {"planb": False})
+    irr4 = synth.irregular_cases("HIS")
+    mix4 = synth.SubjectGen(cau, 42, pops=POP4).mixed(30)
+    run_scenario("pop4_irregular", w4, POP4, [x for pair in zip(mix4[:10], irr4) for x in pair] + mix4[10:], {"UNK_priors": "MR"})
+
+
 if __name__ == "__main__":
     main()
