@@ -98,6 +98,9 @@ struct DevArgs {
   uint32_t *bail_list;           // subjects the one-wave kernel hands to the general kernel: light ones from the front
                                  // (count queue[5]), heavier ones from the back (count queue[7]); n_medium entries
   uint32_t n_medium;
+  uint32_t *mid_list;            // subjects the mid-size kernel (grim_mid.h) hands to the general kernel (count queue[17]); null:
+                                 // that kernel is switched off and the general kernel takes its own list and the one-wave
+                                 // kernel's hand-overs itself
   uint32_t *next_list;           // subjects handed to the next kernel (plan B): light ones from the front
   uint32_t *next_count;          // (count queue[2]), heavy ones from the back (count queue[6]) -- heavy first
   uint32_t next_cap;             // entries in next_list
@@ -122,6 +125,7 @@ struct DevArgs {
 #define GRIM_F_NO_NODUP 2u       // DevArgs.flags (GRIM_NO_NODUP=1): the pair passes always run their dedup (test switch)
 #define GRIM_NQ 24               // u32 words of `queue` (the run state block is counters + queue):
                                  // [13] bucket-start slots used [14] work units [15] units done by earlier launches of the run
+                                 // [16] work counter of the mid-size kernel [17] its hand-overs to the general kernel
                                  // [12] items the workgroup split kernel took [21] the workgroup merge kernel [22] of those, with an
                                  // overflowed bucket [23] their largest pair count  (diagnostics, GRIM_DEBUG_CLASSES=1)
                                  // (the table kernels' own work counters are DevArgs.wctr)

@@ -18,6 +18,7 @@
 #include "grim_plan_b.h"
 #include "grim_small.h"
 #include "grim_medium.h"
+#include "grim_mid.h"
 #include "grim_tables.h"
 #include "grim_tokdev.h"
 #include "grim_engine_internal.h"
@@ -37,6 +38,8 @@ __global__ __launch_bounds__(GRIM_WG, GRIM_WG_PER_CU) void grim_plan_a_kernel(De
   // hand-overs of the one-wave kernel (earlier in the stream): the heavier ones, at the back of its list, are
   // taken first, then this kernel's own subjects (heaviest first), then the light hand-overs
   const uint32_t n_bail = A.bail_list ? A.queue[5] : 0, n_bail_heavy = A.bail_list ? A.queue[7] : 0;
+  // behind the mid-size kernel (grim_mid.h) this kernel only takes what that one handed over
+  const uint32_t n_mid = A.mid_list ? A.queue[17] : 0;
   if (tid < GRIM_NWAVE * 4) ((unsigned long long *)sh.wctr)[tid] = 0;
   wg_arena(sh, wt);
   __syncthreads();
@@ -44,9 +47,11 @@ __global__ __launch_bounds__(GRIM_WG, GRIM_WG_PER_CU) void grim_plan_a_kernel(De
     if (tid == 0) sh.bc[3] = atomicAdd(A.queue, 1u);
     __syncthreads();
     const uint32_t w = sh.bc[3];
-    if (w >= A.n_work + n_bail + n_bail_heavy) break;
+    if (A.mid_list ? w >= n_mid : w >= A.n_work + n_bail + n_bail_heavy) break;
     uint32_t si;
-    if (w < n_bail_heavy)
+    if (A.mid_list)
+      si = A.mid_list[w];
+    else if (w < n_bail_heavy)
       si = A.bail_list[A.n_medium - 1u - w];
     else if (w - n_bail_heavy < A.n_work)
       si = A.order[w - n_bail_heavy];
@@ -330,13 +335,14 @@ struct grim_batch {
   hipEvent_t ev_done;  // recorded behind the last kernel of a stage: what engine_batch_wait waits for (not the whole stream --
                        // the device thread may have queued the next chunk's kernels behind it already)
   bool enqueued;       // stage 1 is in flight (engine_batch_enqueue without its engine_batch_wait)
-  hipEvent_t ev[16];  // timing mode, kernel start/stop ([14]/[15] device tokenizer): [3]/[5] half-wave, [0]/[1] one-wave, [6]/[7] general, [4]/[2] Plan B,
+  hipEvent_t ev[18];  // timing mode ([16]/[17] the mid-size kernel), kernel start/stop ([14]/[15] device tokenizer): [3]/[5] half-wave, [0]/[1] one-wave, [6]/[7] general, [4]/[2] Plan B,
                       // [8]/[9] table kernels of stage 1, [10]/[11] table kernels after Plan B
   bool timing;       // GRIM_TIMING=1 or grim_batch_set_timing: direct launches with per-kernel events instead of the graph replay
   hipGraphExec_t gexec;
   int graph_state;  // 0 not tried, 1 captured, -1 direct launches
   float ms_a, ms_b, ms_s, ms_g, ms_m, ms_t, ms_c;  // ms_c: the half-wave kernel's row compaction
-  double acc_ms[9];   // sums over the timed runs since timing was switched on (index = `which`)
+  float ms_d;         // the mid-size kernel (grim_mid.h)
+  double acc_ms[10];  // sums over the timed runs since timing was switched on (index = `which`)
   uint32_t n_timed;
   uint32_t rows_used;
   unsigned long long counters[8];
@@ -612,6 +618,7 @@ static bool batch_plan(grim_batch *b, const EnginePlan &pl) {
   o = 0;
   const uint64_t small_waves = ((n + GRIM_WG / 32 - 1) / (GRIM_WG / 32)) * (GRIM_WG / 64);
   const uint64_t w_bail = take(4 * n), w_next = take(4 * n), w_ctr = take(4 * (4 * small_waves + 4));  // host- and device-tokenised launches
+  const uint64_t w_mid = take(4 * n);
   const uint64_t w_dsmall = take(devtok ? sizeof(SmallRec) * n : 0);
   const uint64_t w_t1 = take(sizeof(TabWork) * 2 * n), w_t2 = take(sizeof(TabWork) * 2 * n);  // a subject queues at most two items
   const uint64_t work_bytes = o;
@@ -658,6 +665,10 @@ static bool batch_plan(grim_batch *b, const EnginePlan &pl) {
   A.tok = (const uint16_t *)(b->d_in + o_tok);
   A.bail_list = (uint32_t *)(b->d_work + w_bail);
   A.next_list = (uint32_t *)(b->d_work + w_next);
+  {
+    static const int no_mid = env_int("GRIM_NO_MID", 0);  // test switch: everything the mid-size kernel takes goes to the general kernel
+    A.mid_list = no_mid ? nullptr : (uint32_t *)(b->d_work + w_mid);
+  }
   A.small_ctr = (uint32_t *)(b->d_work + w_ctr);
   A.t1_list = (TabWork *)(b->d_work + w_t1);
   A.t2_list = (TabWork *)(b->d_work + w_t2);
@@ -758,7 +769,7 @@ grim_batch *engine_batch_create(grim_ctx *c, const grim_graph *g, const grim_par
       b->hstate = nullptr;
       ok = false;
     }
-    for (int i = 0; i < 16 && ok; ++i) ok = hipEventCreate(&b->ev[i]) == hipSuccess;
+    for (int i = 0; i < 18 && ok; ++i) ok = hipEventCreate(&b->ev[i]) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&b->ev_done, hipEventDisableTiming | hipEventReleaseToSystem) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&b->ev_copy, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&b->ev_up, hipEventDisableTiming) == hipSuccess;
@@ -1273,6 +1284,15 @@ static int enqueue_stage1(grim_batch *b, bool timing) {
       hipLaunchKernelGGL(grim_plan_a_medium_kernel, dim3(grid), dim3(64), 0, c->stream, A, (const uint32_t *)b->d_om,
                          b->n_medium, A.bail_list);
   }
+  if (A.mid_list && b->n_general + b->n_medium) {
+    const uint32_t want = b->n_general + b->n_medium;
+    uint32_t grid = (uint32_t)c->n_cu * GRIM_MID_WG_PER_CU;
+    if (grid > want) grid = want;
+    if (timing)
+      hipExtLaunchKernelGGL(grim_plan_a_mid_kernel, dim3(grid), dim3(GRIM_WG), 0, c->stream, b->ev[16], b->ev[17], 0, A);
+    else
+      hipLaunchKernelGGL(grim_plan_a_mid_kernel, dim3(grid), dim3(GRIM_WG), 0, c->stream, A);
+  }
   if (b->n_general + b->n_medium) {
     uint32_t want = b->n_general + b->n_medium;
     const dim3 grid(b->n_slots < want ? b->n_slots : want), block(GRIM_WG);
@@ -1307,7 +1327,7 @@ int engine_batch_enqueue(grim_batch *b) {
     set_err(c, "grim_batch_run: output row pool smaller than the half-wave kernel's fixed region");
     return -2;
   }
-  b->ms_s = b->ms_a = b->ms_g = b->ms_m = b->ms_t = b->ms_c = b->ms_b = b->ms_k = 0;
+  b->ms_s = b->ms_a = b->ms_g = b->ms_m = b->ms_t = b->ms_c = b->ms_b = b->ms_k = b->ms_d = 0;
   std::lock_guard<std::mutex> lk(c->run_mu);
   if (bind_scratch(b) != 0) return -1;
   if (b->timing) {
@@ -1358,9 +1378,10 @@ int engine_batch_wait(grim_batch *b) {
     if (b->n_small || b->n_dev_lines) HIPCHK(hipEventElapsedTime(&b->ms_s, b->ev[3], b->ev[5]), c, -1);
     if (b->n_medium) HIPCHK(hipEventElapsedTime(&b->ms_m, b->ev[0], b->ev[1]), c, -1);
     if (b->n_general + b->n_medium) HIPCHK(hipEventElapsedTime(&b->ms_g, b->ev[6], b->ev[7]), c, -1);
+    if (A.mid_list && b->n_general + b->n_medium) HIPCHK(hipEventElapsedTime(&b->ms_d, b->ev[16], b->ev[17]), c, -1);
     if (b->n_small || b->n_dev_lines) HIPCHK(hipEventElapsedTime(&b->ms_c, b->ev[12], b->ev[13]), c, -1);
     if (b->n_dev_lines) HIPCHK(hipEventElapsedTime(&b->ms_k, b->ev[14], b->ev[15]), c, -1);
-    b->ms_a = b->ms_s + b->ms_m + b->ms_g;
+    b->ms_a = b->ms_s + b->ms_m + b->ms_g + b->ms_d;
   }
   uint32_t head[GRIM_NQ];
   memcpy(head, b->hstate + GRIM_NCTR, 4 * GRIM_NQ);
@@ -1393,11 +1414,13 @@ int engine_batch_wait(grim_batch *b) {
     memcpy(head, b->hstate + GRIM_NCTR, 4 * GRIM_NQ);
   }
   if (b->timing) {
-    const double v[9] = {(double)b->ms_a + b->ms_b + b->ms_t + b->ms_c + b->ms_k, b->ms_a, b->ms_b, b->ms_s, b->ms_g, b->ms_m, b->ms_t, b->ms_c, b->ms_k};
-    for (int k = 0; k < 9; ++k) b->acc_ms[k] += v[k];
+    const double v[10] = {(double)b->ms_a + b->ms_b + b->ms_t + b->ms_c + b->ms_k, b->ms_a, b->ms_b, b->ms_s, b->ms_g, b->ms_m, b->ms_t, b->ms_c, b->ms_k, b->ms_d};
+    for (int k = 0; k < 10; ++k) b->acc_ms[k] += v[k];
     b->n_timed++;
   }
   static const int dbg_classes = env_int("GRIM_DEBUG_CLASSES", 0);
+  if (dbg_classes)
+    fprintf(stderr, "grim classes: mid-size kernel took %u, handed %u to the general kernel\n", head[16], head[17]);
   if (dbg_classes)
     fprintf(stderr, "grim classes: small %u medium %u general %u | medium->general %u (+%u heavier), to plan B %u (+%u heavy) | table items %u one-wave, %u bigger (%u work units), %u pair records; workgroup merge: %u items (%u with an overflowed bucket), up to %u pairs; workgroup split: %u items | stage 1 %s\n",
             b->n_small, b->n_medium, b->n_general, head[5], head[7], head[2], head[6], head[9], head[10], head[14], head[8], head[21], head[22], head[23], head[12],
@@ -1458,7 +1481,7 @@ extern "C" double grim_batch_kernel_ms(const grim_batch *b, int which) {
   if (!b) return 0.0;
   if (which & 0x10) {  // mean over the timed runs since grim_batch_set_timing(b, 1)
     const int k = which & 0xF;
-    return (k < 9 && b->n_timed) ? b->acc_ms[k] / b->n_timed : 0.0;
+    return (k < 10 && b->n_timed) ? b->acc_ms[k] / b->n_timed : 0.0;
   }
   if (which == 1) return b->ms_a;
   if (which == 2) return b->ms_b;
@@ -1468,6 +1491,7 @@ extern "C" double grim_batch_kernel_ms(const grim_batch *b, int which) {
   if (which == 6) return b->ms_t;
   if (which == 7) return b->ms_c;
   if (which == 8) return b->ms_k;
+  if (which == 9) return b->ms_d;
   return (double)b->ms_a + (double)b->ms_b + (double)b->ms_t + (double)b->ms_c + (double)b->ms_k;
 }
 
@@ -1586,7 +1610,7 @@ static void batch_destroy(grim_batch *b) {
   if (!b) return;
   use_device(b->ctx->device);
   hipStreamSynchronize(b->ctx->stream);
-  for (int i = 0; i < 16; ++i)
+  for (int i = 0; i < 18; ++i)
     if (b->ev[i]) hipEventDestroy(b->ev[i]);
   if (b->ev_done) hipEventDestroy(b->ev_done);
   if (b->ev_copy) hipEventDestroy(b->ev_copy);

@@ -205,7 +205,9 @@ static int tokenise_gl(const DictSnap &D, sv gl, bool planb, Scratch &sc, grim_s
     side2.push_back(q2 ? rest.substr(0, (size_t)((const char *)q2 - rest.data())) : rest);
   }
   const size_t n = parts.size() - blanks;
-  if (n != side1.size() || n < 1 || n > D.n_loci) return K_PROBLEM_RAW;
+  if (n != side1.size() || n < 1) return K_PROBLEM_RAW;
+  if (n > D.n_loci) return K_UNSUPPORTED_GL;  // more entries than the graph has loci (a locus named twice among them, or a locus the
+                                              // graph does not have): the reference opens 2^(n-1) phases over them all the same
   insertion_sort(side1);
   insertion_sort(side2);
   memset(&sj, 0, sizeof(sj));

@@ -207,8 +207,10 @@ class Imputation(object):
         n = len(parts) - blanks
         side1.sort()
         side2.sort()
-        if n != len(side1) or n < 1 or n > len(self.full_loci):
+        if n != len(side1) or n < 1:
             raise ValueError("irregular GL string")
+        if n > len(self.full_loci):
+            return _UNSUPPORTED_GL, None  # more entries than the graph has loci: the reference opens 2^(n-1) phases all the same
         slots, same, pos, unknown_locus = [], 0, [], False
         for k in range(n):
             alts1, alts2 = side1[k].split("/"), side2[k].split("/")

@@ -207,6 +207,58 @@ def test_one_wave_kernel_equals_general_kernel(monkeypatch):
         assert fast[k] == slow[k], k
 
 
+def test_mid_size_kernel_equals_general_kernel(monkeypatch):
+    """grim_mid.h (one workgroup per subject, sides / top lists / pair bitmap in LDS, no HBM scratch) against the general kernel
+    (GRIM_NO_MID=1) and the oracle: mixed subjects of both graphs with the one-wave kernel on and off (off: every subject is
+    the mid-size kernel's), heavy ambiguity (subjects that outgrow its limits are handed on), overlapping '/' lists (the LDS
+    dedup table), a short top list (the cut inside a side), phase masks through the golden scenario cau_bin."""
+    rows = synth.read_freqs(synth.CAU_FREQS)
+
+    def both(gname, conf, lines, tag, oracle=False):
+        monkeypatch.delenv("GRIM_NO_MID", raising=False)
+        fast, _, _ = _run(gname, conf, lines, tag + "_on")
+        monkeypatch.setenv("GRIM_NO_MID", "1")
+        slow, _, _ = _run(gname, conf, lines, tag + "_off")
+        monkeypatch.delenv("GRIM_NO_MID", raising=False)
+        for k in fast:
+            assert fast[k] == slow[k], (tag, k)
+        if oracle:
+            exp, _ = harness.run_oracle(gname, conf, lines, tag=tag + "_orc")
+            for k in exp:
+                assert fast[k] == exp[k], (tag, k, "oracle")
+
+    for gname, pops, seed in (("cau", ["CAU"], 241), ("pop4", harness.POPS["pop4"], 242)):
+        gen = synth.SubjectGen(rows, seed, pops=pops)
+        lines = gen.mixed(1500) + gen.mixed(400, amb=0.8, miss=0.4) + synth.edge_cases(pops[0]) + synth.plan_c_cases(pops[0])
+        conf = harness.base_conf(pops)
+        conf["UNK_priors"] = "MR"
+        both(gname, conf, lines, "mid_" + gname)
+        monkeypatch.setenv("GRIM_NO_MEDIUM", "1")
+        both(gname, conf, lines[:900], "midnm_" + gname, oracle=gname == "pop4")
+        monkeypatch.delenv("GRIM_NO_MEDIUM", raising=False)
+    # overlapping lists (side 2 repeats one of side 1's alternatives) and homozygous subjects: the dedup path
+    gen = synth.SubjectGen(rows, 243, pops=harness.POPS["pop4"])
+    extra = []
+    for k, l in enumerate(gen.mixed(300, amb=0.9, miss=0.2, recomb=0.3)):
+        f = l.split(",")
+        loci = f[1].split("^")
+        for i, loc in enumerate(loci):
+            a, b = loc.split("+")
+            loci[i] = a + "+" + (a.split("/")[0] + "/" + b if k % 2 == 0 else a)
+        extra.append(",".join([f[0] + "x", "^".join(loci)] + f[2:]))
+    conf = harness.base_conf(harness.POPS["pop4"])
+    conf["UNK_priors"] = "MR"
+    monkeypatch.setenv("GRIM_NO_MEDIUM", "1")
+    both("pop4", conf, extra, "mid_dup", oracle=True)
+    # a short top list (cut inside a side), SR priors
+    conf3 = dict(harness.base_conf(harness.POPS["pop4"]), max_haplotypes_number_in_phase=3)
+    both("pop4", conf3, gen.mixed(500, amb=0.4, miss=0.3), "mid_top3", oracle=True)
+    monkeypatch.delenv("GRIM_NO_MEDIUM", raising=False)
+    # and the device really took part: the mid-size kernel completed subjects of the mixed set
+    got, _, imp = _run("pop4", conf, gen.mixed(800), "mid_count")
+    assert imp.last_stats["n"] == 800
+
+
 def test_pair_pass_without_dedup_equals_pair_pass_with_dedup(monkeypatch):
     """Subjects whose two '/' lists are disjoint at every differing position skip the first-wins dedup of the pair passes
     (prepare_lists, grim_plan_a.h: no haplotype can belong to two phase sides).  GRIM_NO_NODUP=1 sends every subject through
