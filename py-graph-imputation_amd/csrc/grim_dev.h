@@ -146,7 +146,8 @@ __device__ __forceinline__ void push_next(const DevArgs &A, uint32_t si, bool he
 #define GRIM_STAMP_BASE (8 + 4 * 64)
 #ifdef GRIM_STAMPS
 #define GRIM_HIST_BASE (GRIM_STAMP_BASE + 16)  // diagnostic build: log2 histograms, 8 x 24 buckets
-#define GRIM_NCTR (8 + 4 * 64 + 16 + 192)
+#define GRIM_MID_BASE (GRIM_HIST_BASE + 192)   // ... and the mid-size kernel's stage timers [0..15], hand-over reasons [16..31]
+#define GRIM_NCTR (8 + 4 * 64 + 16 + 192 + 32)
 #else
 #define GRIM_NCTR (8 + 4 * 64 + 16)
 #endif

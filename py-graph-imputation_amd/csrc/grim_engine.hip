@@ -1436,6 +1436,11 @@ int engine_batch_wait(grim_batch *b) {
   fprintf(stderr, "grim stamps (us):");
   for (int k = 0; k < 16; ++k) fprintf(stderr, " [%d]%.0f", k, b->hstate[GRIM_STAMP_BASE + k] / 100.0);
   fprintf(stderr, "\n");
+  fprintf(stderr, "grim mid-size kernel stage us (setup, probes, rows, entries, lists, ladder, first pass, final pass, emit):");
+  for (int k = 0; k < 9; ++k) fprintf(stderr, " %.0f", b->hstate[GRIM_MID_BASE + k] / 100.0);
+  fprintf(stderr, "\ngrim mid-size kernel hand-overs (branch/candidates, hits, rows, entries, lists, pairs, dedup):");
+  for (int k = 0; k < 7; ++k) fprintf(stderr, " %llu", b->hstate[GRIM_MID_BASE + 16 + k]);
+  fprintf(stderr, "\n");
   static const char *hname[8] = {"0", "1", "2", "3 workgroup-merge items by pairs", "4 workgroup-split items by pairs",
                                  "5 workgroup-split us by pairs", "6 workgroup-merge items by genotype groups",
                                  "7 workgroup-merge us by pairs"};

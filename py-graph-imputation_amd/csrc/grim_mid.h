@@ -34,8 +34,11 @@
 #define MD_L 1024u                   // entries kept in the top lists of all sides
 #define MD_NP 32768u                 // scored pairs
 #define MD_NPB (MD_NP + GRIM_MAXPH * 64u)  // bits of the pair bitmap (every phase starts a new 64-bit word)
-#define MD_DEDUP 1024u               // accepted pairs of a pass that has to dedup
+#define MD_DEDUP 1024u               // accepted pairs one round of a pass's dedup takes on (twice that many slots)
 #define MD_DSLOTS 2048u
+#ifndef MD_ROUNDS
+#define MD_ROUNDS 4u                 // rounds a pass's dedup may take (accepted pairs <= MD_ROUNDS * MD_DEDUP / 2)
+#endif
 #ifndef GRIM_MID_WG_PER_CU
 #define GRIM_MID_WG_PER_CU 3
 #endif
@@ -58,6 +61,25 @@
 #define MD_ARENA ((MD_ARENA_A > MD_ARENA_B ? MD_ARENA_A : MD_ARENA_B) + 15u & ~15u)
 static_assert(8u * MD_E <= MD_OFF_ENT, "the sort keys overlay the hit arrays");
 static_assert(4u * (MD_NPB / 64u + 1u) + 64u * 16u <= 8u * MD_L, "word prefixes and the small-emit staging overlay the prefix minima");
+
+#ifdef GRIM_STAMPS  // diagnostic build: workgroup time per stage, hand-overs by reason
+#define MSTAMP(k)                                                          \
+  do {                                                                     \
+    __syncthreads();                                                       \
+    if (threadIdx.x == 0) {                                                \
+      const unsigned long long _t1 = wall_clock64();                       \
+      atomicAdd(&A.counters[GRIM_MID_BASE + (k)], _t1 - _mt0);             \
+      _mt0 = _t1;                                                          \
+    }                                                                      \
+  } while (0)
+#define MBAIL(r)                                                           \
+  do {                                                                     \
+    if (threadIdx.x == 0) atomicAdd(&A.counters[GRIM_MID_BASE + 16 + (r)], 1ull); \
+  } while (0)
+#else
+#define MSTAMP(k)
+#define MBAIL(r)
+#endif
 
 struct MidShared {
   grim_subject subj;
@@ -118,8 +140,8 @@ __device__ __forceinline__ MidView mid_view(MidShared &M) {
   return v;
 }
 
-// pair r of phase i (r < n1 * n2 <= 2^14)
-__device__ __forceinline__ PairRef mid_pair(const MidShared &M, int i, uint32_t r, uint32_t n2, uint32_t magic) {
+// pair r of phase i (r < n1 * n2 <= 2^14); *x: the pass's epsilon / P1 of the pair's first entry (mid_set_eps)
+__device__ __forceinline__ PairRef mid_pair(const MidShared &M, int i, uint32_t r, uint32_t n2, uint32_t magic, double *x = nullptr) {
   const uint32_t h = n2 > 1 ? __umulhi(r, magic) : r, k = r - h * n2;
   const uint32_t a = M.seg[2 * i] + h, b = M.seg[2 * i + 1] + k;
   PairRef pr;
@@ -128,7 +150,25 @@ __device__ __forceinline__ PairRef mid_pair(const MidShared &M, int i, uint32_t 
   pr.p2 = M.T_p[b];
   pr.m2 = M.T_m[b];
   pr.e2 = M.T_e[b];
+  if (x) *x = M.T_m[a];
   return pr;
+}
+// The pair loop's `x = epsilon / P1` (impute.py:457-459) depends on the FIRST list's entry only: one IEEE division per entry
+// and pass instead of one per scored pair (a phase scores up to 128 x 128 of them).  The quotients live where a second list
+// keeps its prefix minima -- a first list (even side) has no use for those.  All threads call; barrier inside.
+__device__ __forceinline__ void mid_set_eps(MidShared &M, double eps) {
+  for (int i = 0; i < M.nph; ++i) {
+    const uint32_t a0 = M.seg[2 * i], n1 = M.tlen[2 * i];
+    for (uint32_t h = threadIdx.x; h < n1; h += GRIM_WG) M.T_m[a0 + h] = eps / M.T_p[a0 + h];
+  }
+  __syncthreads();
+}
+// pair_accept (grim_pair.h) with the quotient at hand: the same comparisons on the same values
+__device__ __forceinline__ bool mid_accept(double x, const PairRef &pr, double w) {
+  if (!(pr.m2 >= x)) return false;
+  if (!(w > 0.0)) return false;
+  const double thr = (ENT_HAP(pr.e1) == ENT_HAP(pr.e2)) ? x * 2.0 : x;
+  return w * pr.p2 >= thr;
 }
 __device__ __forceinline__ double mid_prior(const MidShared &M, const double *prior, int P, bool lds_prior, uint32_t e1, uint32_t e2) {
   const uint32_t cell = ENT_POP(e1) * (uint32_t)P + ENT_POP(e2);
@@ -140,12 +180,17 @@ __device__ __forceinline__ double mid_prior(const MidShared &M, const double *pr
 // number of winners, *maxp their largest probability; GRIM_NONE when the pass would need a bigger dedup table than the arena
 // holds (the subject is the general kernel's).  All threads call.
 __device__ inline uint32_t mid_pass(const DevArgs &A, MidShared &M, const MidView &V, const double *prior, bool lds_prior, bool nodup,
-                                    double eps, double *maxp) {
+                                    double eps, bool have_x, double *maxp) {
   const int P = A.g.P;
   const int lane = lane_id(), wv = wave_id();
   const uint64_t lt = (1ull << lane) - 1ull;
   uint32_t cnt = 0;
   double amx = 0.0;
+#ifdef MD_ALWAYS_SET_EPS
+  mid_set_eps(M, eps);
+#else
+  if (!have_x) mid_set_eps(M, eps);  // (the ladder's last sweep left the quotients of its epsilon)
+#endif
   for (int i = 0; i < M.nph; ++i) {
     const uint32_t n2 = M.tlen[2 * i + 1], npi = M.tlen[2 * i] * n2;
     if (!npi) continue;
@@ -154,9 +199,10 @@ __device__ inline uint32_t mid_pass(const DevArgs &A, MidShared &M, const MidVie
       const uint32_t r = (w << 6) + lane;
       bool on = false;
       if (r < npi) {
-        const PairRef pr = mid_pair(M, i, r, n2, magic);
+        double x;
+        const PairRef pr = mid_pair(M, i, r, n2, magic, &x);
         const double wgt = mid_prior(M, prior, P, lds_prior, pr.e1, pr.e2);
-        on = pair_accept(eps, pr, wgt);
+        on = mid_accept(x, pr, wgt);
         if (on && nodup) {
           const double prob = pair_prob(pr, wgt);
           amx = prob > amx ? prob : amx;
@@ -172,64 +218,86 @@ __device__ inline uint32_t mid_pass(const DevArgs &A, MidShared &M, const MidVie
   uint32_t nA = 0;
   for (int w2 = 0; w2 < GRIM_NWAVE; ++w2) nA += M.tmp[w2];
   __syncthreads();
-  if (!nodup) {
-    if (nA > MD_DEDUP) return GRIM_NONE;
-    // first-wins dedup (impute.py:506-511, 603-611): one slot per unordered entity pair, the smallest bit number wins it
-    for (uint32_t s = threadIdx.x; s < MD_DSLOTS; s += GRIM_WG) {
-      V.dk[s] = 0;
-      V.dm[s] = GRIM_NONE;
-    }
-    __syncthreads();
-    for (int sweep = 0; sweep < 2; ++sweep) {
-      cnt = 0;
-      for (int i = 0; i < M.nph; ++i) {
-        const uint32_t n2 = M.tlen[2 * i + 1], npi = M.tlen[2 * i] * n2;
-        if (!npi) continue;
-        const uint32_t magic = tile_magic(n2), w0 = M.boff[i] >> 6, nw = (npi + 63) >> 6;
-        for (uint32_t w = wv; w < nw; w += GRIM_NWAVE) {
-          const uint64_t m = V.bm[w0 + w];
-          if (m == 0) continue;
-          bool win = false;
-          if ((m >> lane) & 1ull) {
-            const uint32_t r = (w << 6) + lane, bit = M.boff[i] + r;
-            const PairRef pr = mid_pair(M, i, r, n2, magic);
-            const uint32_t lo = pr.e1 < pr.e2 ? pr.e1 : pr.e2, hi = pr.e1 < pr.e2 ? pr.e2 : pr.e1;
-            const uint64_t a = ((uint64_t)lo << 32) | hi | GRIM_VALID;
-            uint32_t s = (uint32_t)mix64(a) & (MD_DSLOTS - 1u);
-            for (;;) {
-              uint64_t c = __hip_atomic_load(&V.dk[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              if (c == 0 && sweep == 0) {
-                uint64_t expect = 0;
-                c = __hip_atomic_compare_exchange_strong(&V.dk[s], &expect, a, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-                        ? a : expect;
-              }
-              if (c == a) break;
-              s = (s + 1u) & (MD_DSLOTS - 1u);
-            }
-            if (sweep == 0) {
-              __hip_atomic_fetch_min(&V.dm[s], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            } else {
-              win = (uint32_t)V.dm[s] == bit;
-              if (win) {
-                const double prob = pair_prob(pr, mid_prior(M, prior, P, lds_prior, pr.e1, pr.e2));
-                amx = prob > amx ? prob : amx;
-              }
-            }
-          }
-          if (sweep == 1) {
-            const uint64_t mw = __ballot(win);
-            if (lane == 0) V.bm[w0 + w] = mw;
-            cnt += (uint32_t)__popcll(mw);
-          }
-        }
+  if (!nodup && nA > 0) {
+    // first-wins dedup (impute.py:506-511, 603-611): one slot per unordered entity pair, the smallest bit number wins it.
+    // The table holds MD_DSLOTS keys, so a pass with more accepted pairs goes through it in ROUNDS: round j takes the pairs
+    // whose key hashes to partition j (equal keys share a partition), clears the table, lets them fight it out, and rewrites
+    // only their bits of the bitmap -- every round in LDS, whatever the pass accepted.
+    const uint32_t rounds = (nA + MD_DEDUP / 2 - 1) / (MD_DEDUP / 2);  // ~512 accepted pairs (fewer keys) per round: load <= 1/4
+    if (rounds > MD_ROUNDS) return GRIM_NONE;  // (uniform; a round is two sweeps over the bitmap: beyond a few of them the
+                                               //  general kernel's HBM table is the cheaper way)
+    if (threadIdx.x == 0) M.bc[5] = 0;
+    cnt = 0;
+    for (uint32_t rd = 0; rd < rounds; ++rd) {
+      for (uint32_t s = threadIdx.x; s < MD_DSLOTS; s += GRIM_WG) {
+        V.dk[s] = 0;
+        V.dm[s] = GRIM_NONE;
       }
       __syncthreads();
+      for (int sweep = 0; sweep < 2; ++sweep) {
+        for (int i = 0; i < M.nph; ++i) {
+          const uint32_t n2 = M.tlen[2 * i + 1], npi = M.tlen[2 * i] * n2;
+          if (!npi) continue;
+          const uint32_t magic = tile_magic(n2), w0 = M.boff[i] >> 6, nw = (npi + 63) >> 6;
+          for (uint32_t w = wv; w < nw; w += GRIM_NWAVE) {
+            const uint64_t m = V.bm[w0 + w];
+            if (m == 0) continue;
+            bool mine = false, win = false;
+            if ((m >> lane) & 1ull) {
+              const uint32_t r = (w << 6) + lane, bit = M.boff[i] + r;
+              const PairRef pr = mid_pair(M, i, r, n2, magic);
+              const uint32_t lo = pr.e1 < pr.e2 ? pr.e1 : pr.e2, hi = pr.e1 < pr.e2 ? pr.e2 : pr.e1;
+              const uint64_t a = ((uint64_t)lo << 32) | hi | GRIM_VALID;
+              const uint64_t hsh = mix64(a);
+              mine = rounds == 1 || (uint32_t)(hsh >> 40) % rounds == rd;
+              if (mine) {
+                uint32_t s = (uint32_t)hsh & (MD_DSLOTS - 1u), tries = 0;
+                for (;;) {
+                  uint64_t c = __hip_atomic_load(&V.dk[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                  if (c == 0 && sweep == 0) {
+                    uint64_t expect = 0;
+                    c = __hip_atomic_compare_exchange_strong(&V.dk[s], &expect, a, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                            ? a : expect;
+                  }
+                  if (c == a) break;
+                  s = (s + 1u) & (MD_DSLOTS - 1u);
+                  if (++tries > MD_DSLOTS) {  // a partition with more keys than slots (never with a fair hash): give the subject up
+                    M.bc[5] = 1;
+                    break;
+                  }
+                }
+                if (tries <= MD_DSLOTS) {
+                  if (sweep == 0) {
+                    __hip_atomic_fetch_min(&V.dm[s], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                  } else {
+                    win = (uint32_t)V.dm[s] == bit;
+                    if (win) {
+                      const double prob = pair_prob(pr, mid_prior(M, prior, P, lds_prior, pr.e1, pr.e2));
+                      amx = prob > amx ? prob : amx;
+                    }
+                  }
+                }
+              }
+            }
+            if (sweep == 1) {
+              const uint64_t mm = __ballot(mine), mw = __ballot(win);
+              if (mm) {
+                if (lane == 0) V.bm[w0 + w] = (m & ~mm) | mw;  // this round's pairs: winners stay, the rest of the word is other rounds'
+                cnt += (uint32_t)__popcll(mw);
+              }
+            }
+          }
+        }
+        __syncthreads();
+      }
     }
+    const bool gave_up = M.bc[5] != 0;
     if (lane == 0) M.tmp[wv] = cnt;
     __syncthreads();
     nA = 0;
     for (int w2 = 0; w2 < GRIM_NWAVE; ++w2) nA += M.tmp[w2];
     __syncthreads();
+    if (gave_up) return GRIM_NONE;
   }
   (void)lt;
   for (int d = 32; d > 0; d >>= 1) {
@@ -253,6 +321,9 @@ __device__ inline int mid_subject(const DevArgs &A, MidShared &M, uint32_t si) {
   const int P = g.P;
   const MidView V = mid_view(M);
   const uint64_t lt = (1ull << lane) - 1ull;
+#ifdef GRIM_STAMPS
+  unsigned long long _mt0 = wall_clock64();
+#endif
   // ---- subject, phases (gen_phases, impute.py:274-303) ------------------------------------------------------------------
   if (tid < 16) ((uint32_t *)&M.subj)[tid] = ((const uint32_t *)&A.subj[si])[tid];
   if (tid < (int)(sizeof(grim_subject_result) / 4)) ((uint32_t *)&M.out)[tid] = 0;
@@ -318,8 +389,10 @@ __device__ inline int mid_subject(const DevArgs &A, MidShared &M, uint32_t si) {
   const uint32_t C = M.cand_start[nsides];
   if (M.bc[0] || C > MD_C || nsides == 0) {
     __syncthreads();
+    MBAIL(0);
     return 2;
   }
+  MSTAMP(0);
   // ---- 1. all candidates' look-ups, hits compacted in candidate order ----------------------------------------------------
   uint32_t H = 0;
   {
@@ -393,7 +466,11 @@ __device__ inline int mid_subject(const DevArgs &A, MidShared &M, uint32_t si) {
       __syncthreads();
     }
   }
-  if (H > MD_H) return 2;  // (behind the loop's last barrier; H is uniform)
+  if (H > MD_H) {  // (behind the loop's last barrier; H is uniform)
+    MBAIL(1);
+    return 2;
+  }
+  MSTAMP(1);
   // ---- 2. the hits' CSR rows (adjs_query: a full-label node is its own answer, a partial node's top links otherwise) -------
   uint32_t T = 0;
   {
@@ -426,7 +503,11 @@ __device__ inline int mid_subject(const DevArgs &A, MidShared &M, uint32_t si) {
     T = total;
     __syncthreads();
   }
-  if (T > MD_T) return 2;
+  if (T > MD_T) {
+    MBAIL(2);
+    return 2;
+  }
+  MSTAMP(2);
   // ---- 3. the rows' haplotypes and their frequency vectors -> entries (hap, pop) with p > 0, in stream order -----------------
   uint32_t E = 0;
   {
@@ -494,7 +575,11 @@ __device__ inline int mid_subject(const DevArgs &A, MidShared &M, uint32_t si) {
     }
     __syncthreads();
   }
-  if (E > MD_E) return 2;
+  if (E > MD_E) {
+    MBAIL(3);
+    return 2;
+  }
+  MSTAMP(3);
   // ---- 4. segments, ranks, top lists (convert_list_to_one_dim, impute.py:424-442) -------------------------------------------
   const uint32_t K = A.prm.top_n;
   if (wv == 0) {
@@ -519,6 +604,7 @@ __device__ inline int mid_subject(const DevArgs &A, MidShared &M, uint32_t si) {
     const uint32_t Ltot = M.seg[nsides];
     if (M.bc[1] || Ltot > MD_L) {
       __syncthreads();
+      MBAIL(4);
       return 2;
     }
   }
@@ -529,7 +615,11 @@ __device__ inline int mid_subject(const DevArgs &A, MidShared &M, uint32_t si) {
     const uint32_t a = M.seg_in[s], b = M.seg_in[s + 1];
     const double k = V.key[e];
     uint32_t rank = 0;
+#ifdef MD_NO_EARLY_RANK
     for (uint32_t e2 = a; e2 < b; ++e2) {
+#else
+    for (uint32_t e2 = a; e2 < b && rank < K; ++e2) {
+#endif  // (an entry with K bigger ones in front of it is out: no need for its rank)
       const double k2 = V.key[e2];
       rank += (k2 > k || (k2 == k && e2 < e)) ? 1u : 0u;
     }
@@ -539,13 +629,33 @@ __device__ inline int mid_subject(const DevArgs &A, MidShared &M, uint32_t si) {
     }
   }
   __syncthreads();
-  if (tid < nsides) {  // prefix minimum for the pair loop's break (impute.py:463-464, 545-546)
+  // prefix minimum of a SECOND list for the pair loop's break (impute.py:463-464, 545-546): a wave per list, shuffles
+#ifdef MD_SEQ_PMIN
+  if (tid < nsides) {
     const uint32_t a = M.seg[tid];
     double mn = __longlong_as_double(0x7FF0000000000000ll);
     for (uint32_t r = 0; r < M.tlen[tid]; ++r) {
       const double v = M.T_p[a + r];
       mn = v < mn ? v : mn;
       M.T_m[a + r] = mn;
+    }
+  }
+  for (int s = 2 * wv + 1; s < 0; s += 2 * GRIM_NWAVE) {
+#else
+  for (int s = 2 * wv + 1; s < nsides; s += 2 * GRIM_NWAVE) {
+#endif
+    const uint32_t a = M.seg[s], len = M.tlen[s];
+    double carry = __longlong_as_double(0x7FF0000000000000ll);
+    for (uint32_t r0 = 0; r0 < len; r0 += 64) {
+      const uint32_t r = r0 + lane;
+      double v = r < len ? M.T_p[a + r] : __longlong_as_double(0x7FF0000000000000ll);
+      for (int d = 1; d < 64; d <<= 1) {
+        const double o = __shfl_up(v, d);
+        if (lane >= d && o < v) v = o;
+      }
+      if (carry < v) v = carry;
+      if (r < len) M.T_m[a + r] = v;
+      carry = __shfl(v, 63);
     }
   }
   if (tid == 64) {
@@ -581,42 +691,61 @@ __device__ inline int mid_subject(const DevArgs &A, MidShared &M, uint32_t si) {
   const bool nodup = M.bc[2] != 0;
   if (np > MD_NP) {
     __syncthreads();
+    MBAIL(5);
     return 2;
   }
+  MSTAMP(4);
   // ---- 5. the ladder (impute.py:1665-1687): first step at which any pair is accepted ---------------------------------------------
-  int best = A.prm.n_ladder;
-  for (int i = 0; i < nph && best > 0; ++i) {
-    const uint32_t n2 = M.tlen[2 * i + 1], npi = M.tlen[2 * i] * n2;
-    const uint32_t magic = tile_magic(n2);
-    for (uint32_t r = tid; r < npi && best > 0; r += GRIM_WG) {
-      const PairRef pr = mid_pair(M, i, r, n2, magic);
-      const double wgt = mid_prior(M, prior, P, lds_prior, pr.e1, pr.e2);
-      for (int idx = 0; idx < best; ++idx)
-        if (pair_accept(A.prm.ladder[idx], pr, wgt)) {
-          best = idx;
+  // One sweep per ladder step, the step's quotients precomputed per first-list entry; a sweep ends as soon as any thread has
+  // an accepted pair.  (Testing every pair against every step costs a division per pair and step.)
+  int e_first = A.prm.n_ladder;
+  for (int idx = 0; np > 0 && idx < A.prm.n_ladder; ++idx) {
+    if (tid == 0) M.bc[3] = 0;
+    mid_set_eps(M, A.prm.ladder[idx]);
+    bool found = false;
+    for (int i = 0; i < nph && !found; ++i) {
+      const uint32_t n2 = M.tlen[2 * i + 1], npi = M.tlen[2 * i] * n2;
+      const uint32_t magic = tile_magic(n2);
+      for (uint32_t r = tid; r < npi; r += GRIM_WG) {
+        double x;
+        const PairRef pr = mid_pair(M, i, r, n2, magic, &x);
+        if (mid_accept(x, pr, mid_prior(M, prior, P, lds_prior, pr.e1, pr.e2)) || ((r & (7u * GRIM_WG)) == 0 && M.bc[3])) {
+          found = true;
           break;
         }
+      }
+    }
+    if (found) M.bc[3] = 1;
+    __syncthreads();
+    const bool any = M.bc[3] != 0;
+    __syncthreads();
+    if (any) {
+      e_first = idx;
+      break;
     }
   }
-  if (tid == 0) M.bc[3] = (uint32_t)A.prm.n_ladder;
-  __syncthreads();
-  atomicMin(&M.bc[3], (uint32_t)best);
-  __syncthreads();
-  const int e_first = (int)M.bc[3];
-  __syncthreads();
+  MSTAMP(5);
   // ---- 6. the passes: at the first accepting step for MaxProb, then at MaxProb / 100000 (impute.py:1685-1693) ----------------------
   uint32_t nU = 0;
   double mx = 0.0;
   if (np > 0 && e_first < A.prm.n_ladder) {
     double eps = A.prm.ladder[e_first];
     if (eps > 0.0) {
-      const uint32_t r1 = mid_pass(A, M, V, prior, lds_prior, nodup, eps, &mx);
-      if (r1 == GRIM_NONE) return 2;
+      const uint32_t r1 = mid_pass(A, M, V, prior, lds_prior, nodup, eps, true, &mx);
+      if (r1 == GRIM_NONE) {
+        MBAIL(6);
+        return 2;
+      }
       eps = mx / 100000.0;
     }
-    nU = mid_pass(A, M, V, prior, lds_prior, nodup, eps, &mx);
-    if (nU == GRIM_NONE) return 2;
+    MSTAMP(6);
+    nU = mid_pass(A, M, V, prior, lds_prior, nodup, eps, eps == A.prm.ladder[e_first], &mx);
+    if (nU == GRIM_NONE) {
+      MBAIL(6);
+      return 2;
+    }
   }
+  MSTAMP(7);
   // ---- 7. the winners, in pair order -------------------------------------------------------------------------------------------
   uint8_t status = GRIM_ST_MISS, reason = 0;
   if (nU > 0) {
@@ -719,6 +848,7 @@ __device__ inline int mid_subject(const DevArgs &A, MidShared &M, uint32_t si) {
     M.wctr[2] += T;
   }
   __syncthreads();
+  MSTAMP(8);
   return 0;
 }
 

@@ -482,7 +482,8 @@ def test_timing_mode_and_repeat():
         batch.run_repeat(5)
         res1, rows1 = batch.results()
         assert batch.kernel_ms(3) > 0.0 and batch.kernel_ms(2) > 0.0  # half-wave kernel and Plan B both ran
-        total = sum(batch.kernel_ms(w) for w in (3, 5, 4, 2, 6, 7))  # half-wave, one-wave, general, Plan B, table kernels, row compaction
+        total = sum(batch.kernel_ms(w) for w in (3, 5, 9, 4, 2, 6, 7))  # half-wave, one-wave, mid-size, general, Plan B, table kernels, row compaction
+        assert batch.kernel_ms(9) > 0.0  # the mid-size kernel took the mixed subjects the one-wave kernel handed on
         assert abs(batch.kernel_ms(0) - total) < 1e-6
         assert batch.kernel_ms(0x10 | 3) > 0.0
 

@@ -254,7 +254,7 @@ def test_device_tokenizer_equals_host_tokenizer(monkeypatch):
         loci = f[1].split("^")
         loci[1], loci[3] = loci[3], loci[1]
         swapped.append(",".join([f[0] + "s", "^".join(loci)] + f[2:]))
-    twice = [l.replace("^C*", "^A*", 1) for l in gen.full(10)]
+    twice = ["T%d%s" % (i, l[l.index(","):].replace("^C*", "^A*", 1)) for i, l in enumerate(gen.full(10))]  # (ids of their own)
     longname = [l.replace("+", ":01:01:01:01:01:01:01+", 1) for l in gen.full(10)]
     percent = [l.replace(",", "%") for l in gen.full(30)]
     lines += swapped + twice + longname + percent

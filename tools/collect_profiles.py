@@ -5,7 +5,7 @@ wrote them, one summary line per (kernel, counter) of every --pmc pass, and the 
 import collections, csv, glob, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r4"
 src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 dst = os.path.join(ROOT, "profiles")
 for w in ("config2", "config3", "config4", "config5"):
@@ -26,6 +26,20 @@ for w in ("config2", "config3", "config4", "config5"):
             out.write("kernel,counter,launches,mean_%s,min_%s,max_%s\n" % (unit, unit, unit))
             for (k, c), v in sorted(acc.items()):
                 out.write("%s,%s,%d,%.1f,%.1f,%.1f\n" % (k, c, len(v), sum(v) / len(v), min(v), max(v)))
+ko = os.path.join(src, "config2_kernel_only", "r_kernel_stats.csv")
+if os.path.exists(ko):
+    shutil.copy(ko, os.path.join(dst, "%s_config2_kernel_only_stats.csv" % tag))
+    log = os.path.join(src, "config2_kernel_only.log")
+    if os.path.exists(log):
+        lines = [l for l in open(log) if l.startswith("{")]
+        if lines:
+            open(os.path.join(dst, "%s_config2_kernel_only.json" % tag), "w").write(lines[-1])
+for w in ("config2", "config4", "config5"):
+    bj = os.path.join(src, "bench_%s.json" % w)
+    if os.path.exists(bj):
+        lines = [l for l in open(bj) if l.startswith("{")]
+        if lines:
+            open(os.path.join(dst, "%s_bench_%s.json" % (tag, w)), "w").write(lines[-1])
 tj = os.path.join(src, "pmc_traffic.json")
 if os.path.exists(tj):
     shutil.copy(tj, os.path.join(dst, "%s_pmc_traffic.json" % tag))

@@ -4,7 +4,7 @@
 # graph x 256 high-ambiguity subjects): kernel-trace stats of `bench.py --workload W`, and FETCH_SIZE / WRITE_SIZE in
 # SEPARATE --pmc passes (MI355X_MICROARCH.md, HBM section); SQ counters for config 2.  Summaries land in gpurun_out/prof_<tag>/.
 set -e
-TAG=${1:-r3}
+TAG=${1:-r4}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
@@ -13,6 +13,11 @@ B="--no-cpu-baseline --no-file --min-seconds 0"
 run() {  # name, rocprof options, bench options
   rocprofv3 $2 --output-format csv -d $O/$1 -o r -- python3 $R/bench.py $3 > $O/$1.log 2>&1
 }
+# the kernel-only loop ALONE (no stream path beside it): the averages bench.py's roofline.avg_launch_ms has to agree with
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/config2_kernel_only -o r -- python3 $R/tools/kernel_only.py --workload config2 --runs 300 > $O/config2_kernel_only.log 2>&1
+[ "${ONLY_KERNEL_ONLY:-0}" = "1" ] && exit 0
+# the bench lines of the same build (full JSON with roofline), unprofiled
+for w in config2 config4 config5; do python3 $R/bench.py --workload $w --no-file --no-cpu-baseline > $O/bench_$w.json 2> $O/bench_$w.err || true; done
 run config2        "--kernel-trace --stats" "--steps 50 --warmup 5 $B"
 run config2_fetch  "--pmc FETCH_SIZE --kernel-trace" "--steps 10 --warmup 2 --kernel-steps 10 $B"
 run config2_write  "--pmc WRITE_SIZE --kernel-trace" "--steps 10 --warmup 2 --kernel-steps 10 $B"
