@@ -34,11 +34,8 @@
 #define MD_L 1024u                   // entries kept in the top lists of all sides
 #define MD_NP 32768u                 // scored pairs
 #define MD_NPB (MD_NP + GRIM_MAXPH * 64u)  // bits of the pair bitmap (every phase starts a new 64-bit word)
-#define MD_DEDUP 1024u               // accepted pairs one round of a pass's dedup takes on (twice that many slots)
+#define MD_DEDUP 1024u               // accepted pairs of a pass that has to dedup (twice that many slots)
 #define MD_DSLOTS 2048u
-#ifndef MD_ROUNDS
-#define MD_ROUNDS 4u                 // rounds a pass's dedup may take (accepted pairs <= MD_ROUNDS * MD_DEDUP / 2)
-#endif
 #ifndef GRIM_MID_WG_PER_CU
 #define GRIM_MID_WG_PER_CU 3
 #endif
@@ -186,11 +183,7 @@ __device__ inline uint32_t mid_pass(const DevArgs &A, MidShared &M, const MidVie
   const uint64_t lt = (1ull << lane) - 1ull;
   uint32_t cnt = 0;
   double amx = 0.0;
-#ifdef MD_ALWAYS_SET_EPS
-  mid_set_eps(M, eps);
-#else
   if (!have_x) mid_set_eps(M, eps);  // (the ladder's last sweep left the quotients of its epsilon)
-#endif
   for (int i = 0; i < M.nph; ++i) {
     const uint32_t n2 = M.tlen[2 * i + 1], npi = M.tlen[2 * i] * n2;
     if (!npi) continue;
@@ -219,85 +212,66 @@ __device__ inline uint32_t mid_pass(const DevArgs &A, MidShared &M, const MidVie
   for (int w2 = 0; w2 < GRIM_NWAVE; ++w2) nA += M.tmp[w2];
   __syncthreads();
   if (!nodup && nA > 0) {
-    // first-wins dedup (impute.py:506-511, 603-611): one slot per unordered entity pair, the smallest bit number wins it.
-    // The table holds MD_DSLOTS keys, so a pass with more accepted pairs goes through it in ROUNDS: round j takes the pairs
-    // whose key hashes to partition j (equal keys share a partition), clears the table, lets them fight it out, and rewrites
-    // only their bits of the bitmap -- every round in LDS, whatever the pass accepted.
-    const uint32_t rounds = (nA + MD_DEDUP / 2 - 1) / (MD_DEDUP / 2);  // ~512 accepted pairs (fewer keys) per round: load <= 1/4
-    if (rounds > MD_ROUNDS) return GRIM_NONE;  // (uniform; a round is two sweeps over the bitmap: beyond a few of them the
-                                               //  general kernel's HBM table is the cheaper way)
-    if (threadIdx.x == 0) M.bc[5] = 0;
+    // first-wins dedup (impute.py:506-511, 603-611): one slot per unordered entity pair, the smallest bit number wins it.  The
+    // LDS table holds a pass of up to MD_DEDUP accepted pairs at load <= 1/2; a pass that accepted more is the general
+    // kernel's (its table is in HBM).  (Going through the table in rounds by key partition was tried: a round is two sweeps
+    // over the whole bitmap, and the subjects that need it need dozens -- 7.1 ms for the kernel instead of 2.0.)
+    if (nA > MD_DEDUP) return GRIM_NONE;  // (uniform)
+    for (uint32_t s = threadIdx.x; s < MD_DSLOTS; s += GRIM_WG) {
+      V.dk[s] = 0;
+      V.dm[s] = GRIM_NONE;
+    }
+    __syncthreads();
     cnt = 0;
-    for (uint32_t rd = 0; rd < rounds; ++rd) {
-      for (uint32_t s = threadIdx.x; s < MD_DSLOTS; s += GRIM_WG) {
-        V.dk[s] = 0;
-        V.dm[s] = GRIM_NONE;
-      }
-      __syncthreads();
-      for (int sweep = 0; sweep < 2; ++sweep) {
-        for (int i = 0; i < M.nph; ++i) {
-          const uint32_t n2 = M.tlen[2 * i + 1], npi = M.tlen[2 * i] * n2;
-          if (!npi) continue;
-          const uint32_t magic = tile_magic(n2), w0 = M.boff[i] >> 6, nw = (npi + 63) >> 6;
-          for (uint32_t w = wv; w < nw; w += GRIM_NWAVE) {
-            const uint64_t m = V.bm[w0 + w];
-            if (m == 0) continue;
-            bool mine = false, win = false;
-            if ((m >> lane) & 1ull) {
-              const uint32_t r = (w << 6) + lane, bit = M.boff[i] + r;
-              const PairRef pr = mid_pair(M, i, r, n2, magic);
-              const uint32_t lo = pr.e1 < pr.e2 ? pr.e1 : pr.e2, hi = pr.e1 < pr.e2 ? pr.e2 : pr.e1;
-              const uint64_t a = ((uint64_t)lo << 32) | hi | GRIM_VALID;
-              const uint64_t hsh = mix64(a);
-              mine = rounds == 1 || (uint32_t)(hsh >> 40) % rounds == rd;
-              if (mine) {
-                uint32_t s = (uint32_t)hsh & (MD_DSLOTS - 1u), tries = 0;
-                for (;;) {
-                  uint64_t c = __hip_atomic_load(&V.dk[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                  if (c == 0 && sweep == 0) {
-                    uint64_t expect = 0;
-                    c = __hip_atomic_compare_exchange_strong(&V.dk[s], &expect, a, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-                            ? a : expect;
-                  }
-                  if (c == a) break;
-                  s = (s + 1u) & (MD_DSLOTS - 1u);
-                  if (++tries > MD_DSLOTS) {  // a partition with more keys than slots (never with a fair hash): give the subject up
-                    M.bc[5] = 1;
-                    break;
-                  }
-                }
-                if (tries <= MD_DSLOTS) {
-                  if (sweep == 0) {
-                    __hip_atomic_fetch_min(&V.dm[s], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                  } else {
-                    win = (uint32_t)V.dm[s] == bit;
-                    if (win) {
-                      const double prob = pair_prob(pr, mid_prior(M, prior, P, lds_prior, pr.e1, pr.e2));
-                      amx = prob > amx ? prob : amx;
-                    }
-                  }
-                }
+    for (int sweep = 0; sweep < 2; ++sweep) {
+      for (int i = 0; i < M.nph; ++i) {
+        const uint32_t n2 = M.tlen[2 * i + 1], npi = M.tlen[2 * i] * n2;
+        if (!npi) continue;
+        const uint32_t magic = tile_magic(n2), w0 = M.boff[i] >> 6, nw = (npi + 63) >> 6;
+        for (uint32_t w = wv; w < nw; w += GRIM_NWAVE) {
+          const uint64_t m = V.bm[w0 + w];
+          if (m == 0) continue;
+          bool win = false;
+          if ((m >> lane) & 1ull) {
+            const uint32_t r = (w << 6) + lane, bit = M.boff[i] + r;
+            const PairRef pr = mid_pair(M, i, r, n2, magic);
+            const uint32_t lo = pr.e1 < pr.e2 ? pr.e1 : pr.e2, hi = pr.e1 < pr.e2 ? pr.e2 : pr.e1;
+            const uint64_t a = ((uint64_t)lo << 32) | hi | GRIM_VALID;
+            uint32_t s = (uint32_t)mix64(a) & (MD_DSLOTS - 1u);
+            for (;;) {  // (at most MD_DEDUP keys in MD_DSLOTS slots: an empty slot ends every probe sequence)
+              uint64_t c = __hip_atomic_load(&V.dk[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              if (c == 0 && sweep == 0) {
+                uint64_t expect = 0;
+                c = __hip_atomic_compare_exchange_strong(&V.dk[s], &expect, a, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                        ? a : expect;
               }
+              if (c == a) break;
+              s = (s + 1u) & (MD_DSLOTS - 1u);
             }
-            if (sweep == 1) {
-              const uint64_t mm = __ballot(mine), mw = __ballot(win);
-              if (mm) {
-                if (lane == 0) V.bm[w0 + w] = (m & ~mm) | mw;  // this round's pairs: winners stay, the rest of the word is other rounds'
-                cnt += (uint32_t)__popcll(mw);
+            if (sweep == 0) {
+              __hip_atomic_fetch_min(&V.dm[s], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+              win = (uint32_t)V.dm[s] == bit;
+              if (win) {
+                const double prob = pair_prob(pr, mid_prior(M, prior, P, lds_prior, pr.e1, pr.e2));
+                amx = prob > amx ? prob : amx;
               }
             }
           }
+          if (sweep == 1) {
+            const uint64_t mw = __ballot(win);
+            if (lane == 0) V.bm[w0 + w] = mw;
+            cnt += (uint32_t)__popcll(mw);
+          }
         }
-        __syncthreads();
       }
+      __syncthreads();
     }
-    const bool gave_up = M.bc[5] != 0;
     if (lane == 0) M.tmp[wv] = cnt;
     __syncthreads();
     nA = 0;
     for (int w2 = 0; w2 < GRIM_NWAVE; ++w2) nA += M.tmp[w2];
     __syncthreads();
-    if (gave_up) return GRIM_NONE;
   }
   (void)lt;
   for (int d = 32; d > 0; d >>= 1) {
@@ -615,11 +589,7 @@ __device__ inline int mid_subject(const DevArgs &A, MidShared &M, uint32_t si) {
     const uint32_t a = M.seg_in[s], b = M.seg_in[s + 1];
     const double k = V.key[e];
     uint32_t rank = 0;
-#ifdef MD_NO_EARLY_RANK
-    for (uint32_t e2 = a; e2 < b; ++e2) {
-#else
-    for (uint32_t e2 = a; e2 < b && rank < K; ++e2) {
-#endif  // (an entry with K bigger ones in front of it is out: no need for its rank)
+    for (uint32_t e2 = a; e2 < b && rank < K; ++e2) {  // (an entry with K bigger ones in front of it is out: no need for its rank)
       const double k2 = V.key[e2];
       rank += (k2 > k || (k2 == k && e2 < e)) ? 1u : 0u;
     }
@@ -630,20 +600,7 @@ __device__ inline int mid_subject(const DevArgs &A, MidShared &M, uint32_t si) {
   }
   __syncthreads();
   // prefix minimum of a SECOND list for the pair loop's break (impute.py:463-464, 545-546): a wave per list, shuffles
-#ifdef MD_SEQ_PMIN
-  if (tid < nsides) {
-    const uint32_t a = M.seg[tid];
-    double mn = __longlong_as_double(0x7FF0000000000000ll);
-    for (uint32_t r = 0; r < M.tlen[tid]; ++r) {
-      const double v = M.T_p[a + r];
-      mn = v < mn ? v : mn;
-      M.T_m[a + r] = mn;
-    }
-  }
-  for (int s = 2 * wv + 1; s < 0; s += 2 * GRIM_NWAVE) {
-#else
   for (int s = 2 * wv + 1; s < nsides; s += 2 * GRIM_NWAVE) {
-#endif
     const uint32_t a = M.seg[s], len = M.tlen[s];
     double carry = __longlong_as_double(0x7FF0000000000000ll);
     for (uint32_t r0 = 0; r0 < len; r0 += 64) {

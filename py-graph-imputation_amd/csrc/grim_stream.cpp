@@ -458,12 +458,22 @@ static int fixup_part(grim_stream *s, Chunk *c, uint32_t lo, uint32_t hi, PartSt
     for (uint32_t r = 0; r < c->n_ranges; ++r)
       if (c->tr[r].n_tok) tok_used = c->slab_off[r] + c->tr[r].n_tok;
     int rc;
-    {
-      std::lock_guard<std::mutex> lk(s->races.mu);
-      EngineLoad ld{c->n_lines, (uint32_t)fos.size(), (uint32_t)fom.size(), (uint32_t)fog.size(), tok_used, s->races.n, s->races.mats.data(), 0, 0, 0};
-      rc = engine_batch_load(b, &ld);
+    for (int attempt = 0;; ++attempt) {
+      {
+        std::lock_guard<std::mutex> lk(s->races.mu);
+        EngineLoad ld{c->n_lines, (uint32_t)fos.size(), (uint32_t)fom.size(), (uint32_t)fog.size(), tok_used, s->races.n, s->races.mats.data(), 0, 0, 0};
+        rc = engine_batch_load(b, &ld);
+      }
+      if (rc == 0) rc = grim_batch_run(b);  // (grows the pair pool and runs again by itself when a subject needs it)
+      // the ROWS ran out: what finish_part does for a first run -- twice the pool, up to every line's worst case, and again
+      // (the second run's inputs are still in the pinned arena)
+      if (rc != -2 || attempt >= 8 || !s->rows_max || !engine_batch_grow_rows(b, s->rows_max)) break;
+      ++ps.reruns;
+      const uint64_t have = engine_batch_row_limit(b);
+      uint64_t cur = s->rows_hint.load();
+      while (have > cur && !s->rows_hint.compare_exchange_weak(cur, have)) {
+      }
     }
-    if (rc == 0) rc = grim_batch_run(b);  // (grows the pair pool and runs again by itself when a subject needs it)
     if (rc != 0) return -1;
     part_stats(s, b, ps);
     const uint32_t nrows2 = grim_batch_total_rows(b);
