@@ -46,6 +46,62 @@ WORKLOADS = {
 }
 
 
+PROFILE_TAG = "r4"  # profiles/<tag>_*: the committed rocprofv3 evidence bench.py cites (tools/profile_round.sh + collect_profiles.py)
+
+
+def source_digest():
+    """sha256 over the kernel / host sources and the C header: identifies the BUILD a committed profile was taken of"""
+    import hashlib
+
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "py-graph-imputation_amd", "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc)) + [os.path.join(ROOT, "include", "grim_hip.h")]
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_profile(workload):
+    """what profiles/ holds for this workload -- NOT measured in this run: rocprofv3 averages / minima of every kernel of the
+    stream path, the kernel-only pass (config 2), the PMC traffic; with the digest of the sources they were taken of and
+    whether that is the build being measured now"""
+    import csv
+
+    out = {"note": "committed profile (tools/profile_round.sh on a gpurun box), not this run"}
+    meta_path = os.path.join(ROOT, "profiles", PROFILE_TAG + "_meta.json")
+    if not os.path.exists(meta_path):
+        return None
+    meta = json.load(open(meta_path))
+    out["profile_commit"] = meta.get("commit")
+    out["profile_source_digest"] = meta.get("source_digest")
+    out["this_build_source_digest"] = source_digest()
+    out["same_build"] = out["profile_source_digest"] == out["this_build_source_digest"]
+
+    def stats(path):
+        avg, mn, calls = {}, {}, {}
+        for r in csv.DictReader(open(path)):
+            k = r["Name"].split("(")[0]
+            if k.startswith("grim_"):
+                avg[k] = round(float(r["AverageNs"]) / 1e3, 2)
+                mn[k] = round(float(r["MinNs"]) / 1e3, 2)
+                calls[k] = int(r["Calls"])
+        return {"avg_us": avg, "min_us": mn, "calls": calls}
+
+    sp = os.path.join(ROOT, "profiles", "%s_%s_kernel_stats.csv" % (PROFILE_TAG, workload))
+    if os.path.exists(sp):
+        out["stream_path"] = dict(stats(sp), source="profiles/" + os.path.basename(sp) + " (bench.py under rocprofv3: copies and the other "
+                                  "kernels of the stream run beside each launch and stretch the averages)")
+    kp = os.path.join(ROOT, "profiles", "%s_%s_kernel_only_stats.csv" % (PROFILE_TAG, workload))
+    if os.path.exists(kp):
+        out["kernel_only"] = dict(stats(kp), source="profiles/" + os.path.basename(kp) + " (tools/kernel_only.py under rocprofv3: the "
+                                  "resident-batch loop alone -- the averages avg_launch_ms has to agree with)")
+    tp = os.path.join(ROOT, "profiles", PROFILE_TAG + "_pmc_traffic.json")
+    if os.path.exists(tp):
+        out["pmc_traffic_file"] = "profiles/" + os.path.basename(tp)
+    return out
+
+
 def make_lines(workload, n, rank, world, rows):
     import harness
     import synth
@@ -321,34 +377,22 @@ def main():
     batch.close()
     parsed.close()
 
-    # HBM traffic per launch of the dominant kernel: PMC numbers cannot be collected from inside this process; they
-    # come from the committed rocprofv3 --pmc passes over this same command (tools/profile_round.sh)
+    # HBM traffic per launch of the dominant kernel: PMC numbers cannot be collected from inside this process; they come from
+    # the committed rocprofv3 --pmc passes over this same command (tools/profile_round.sh) and are labelled as such
+    prof = committed_profile(args.workload) if n_step == dflt_n else None
     traffic, traffic_src = None, None
-    pmc_path = os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")
-    if not os.path.exists(pmc_path):
-        pmc_path = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
-    if os.path.exists(pmc_path):
-        pmc = json.load(open(pmc_path)).get(args.workload, {}).get(names[dom])
-        if pmc and "hbm_bytes_raw" in pmc and n_step == dflt_n:
+    if prof and prof.get("pmc_traffic_file"):
+        pmc = json.load(open(os.path.join(ROOT, prof["pmc_traffic_file"]))).get(args.workload, {}).get(names[dom])
+        if pmc and "hbm_bytes_raw" in pmc:
             traffic = pmc["hbm_bytes_raw"]
-            traffic_src = "profiles/" + os.path.basename(pmc_path) + ": (FETCH_SIZE + WRITE_SIZE) KB x 1024 per launch, separate --pmc passes; " \
-                          "with FETCH_SIZE doubled (gfx950 wide-read correction): %d" % pmc["hbm_bytes_fetch_doubled"]
-
-    # the committed rocprofv3 kernel stats of this workload (tools/profile_round.sh), every kernel of the stream path: the
-    # cross-check for avg_launch_ms, and the kernels the kernel-only loop above does not run (the tokenizer kernel parses
-    # the GL strings in front of the half-wave kernel and is, at 10 000 lines, the longer of the two; the export kernel
-    # brings the results back on the copy stream)
-    rocprof = None
-    stats_path = os.path.join(ROOT, "profiles", "r3_%s_kernel_stats.csv" % args.workload)
-    if os.path.exists(stats_path) and n_step == dflt_n:
-        import csv
-        rocprof = {"source": "profiles/" + os.path.basename(stats_path) + " (under the profiler the runtime's copies run beside "
-                             "the kernels and stretch the averages; min_us is the undisturbed launch)", "avg_us": {}, "min_us": {}}
-        for r in csv.DictReader(open(stats_path)):
-            k = r["Name"].split("(")[0]
-            if k.startswith("grim_"):
-                rocprof["avg_us"][k] = round(float(r["AverageNs"]) / 1e3, 2)
-                rocprof["min_us"][k] = round(float(r["MinNs"]) / 1e3, 2)
+            traffic_src = prof["pmc_traffic_file"] + ": (FETCH_SIZE + WRITE_SIZE) KB x 1024 per launch, separate --pmc passes (committed " \
+                          "profile of source digest %s, this build %s); with FETCH_SIZE doubled (gfx950 wide-read correction): %d" % (
+                              prof["profile_source_digest"], prof["this_build_source_digest"], pmc["hbm_bytes_fetch_doubled"])
+    rocprof = prof
+    frac_committed = None
+    if prof and whole and prof.get("kernel_only", {}).get("avg_us", {}).get(names[dom]):
+        # the roofline fraction recomputed from the COMMITTED kernel-only average: what a reader can check without a GPU
+        frac_committed = algo_bytes / (prof["kernel_only"]["avg_us"][names[dom]] * 1e-6) / 1e9 / HBM_PEAK_GBS
 
     out = None
     if rank == 0:
@@ -392,6 +436,7 @@ def main():
                 "kernel": names[dom] if whole else "+".join(n for n, v in zip(names, per_kernel) if v > 0),
                 "avg_launch_ms": roof_ms, "algorithmic_bytes_per_launch": algo_bytes,
                 "kernel_ms": dict(zip(names, per_kernel)),
+                "frac_from_committed_kernel_only_profile": frac_committed,
                 "rocprof": rocprof,
             },
         }

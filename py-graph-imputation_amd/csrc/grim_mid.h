@@ -34,8 +34,7 @@
 #define MD_L 1024u                   // entries kept in the top lists of all sides
 #define MD_NP 32768u                 // scored pairs
 #define MD_NPB (MD_NP + GRIM_MAXPH * 64u)  // bits of the pair bitmap (every phase starts a new 64-bit word)
-#define MD_DEDUP 1024u               // accepted pairs of a pass that has to dedup (twice that many slots)
-#define MD_DSLOTS 2048u
+#define MD_ESLOTS 2048u               // slots of the entity index of the dedup (>= 2 * MD_L)
 #ifndef GRIM_MID_WG_PER_CU
 #define GRIM_MID_WG_PER_CU 3
 #endif
@@ -52,11 +51,16 @@
 #define MD_OFF_ENTS (MD_OFF_ENTE + 4u * MD_E)
 #define MD_ARENA_A (MD_OFF_ENTS + MD_E)
 #define MD_OFF_BM 0u
-#define MD_OFF_DK ((MD_OFF_BM + MD_NPB / 8u + 255u) & ~255u)
-#define MD_OFF_DM (MD_OFF_DK + 8u * MD_DSLOTS)
-#define MD_ARENA_B (MD_OFF_DM + 4u * MD_DSLOTS)
+#define MD_BM_BYTES ((MD_NPB / 8u + 255u) & ~255u)
+#define MD_OFF_SMASK (MD_OFF_BM + MD_BM_BYTES)          // entity index: keys while it is built, then the entities' side masks
+#define MD_OFF_EOFF (MD_OFF_SMASK + 4u * MD_ESLOTS)     // first occurrence of entity slot r in the position list
+#define MD_OFF_ESLOT (MD_OFF_EOFF + ((2u * (MD_ESLOTS + 2u) + 255u) & ~255u))  // slot of every list entry
+#define MD_OFF_EPOS (MD_OFF_ESLOT + 2u * MD_L)          // positions, by entity and side
+#define MD_OFF_BM2 (MD_OFF_EPOS + MD_L)
+#define MD_ARENA_B (MD_OFF_BM2 + MD_BM_BYTES)
 #define MD_ARENA ((MD_ARENA_A > MD_ARENA_B ? MD_ARENA_A : MD_ARENA_B) + 15u & ~15u)
 static_assert(8u * MD_E <= MD_OFF_ENT, "the sort keys overlay the hit arrays");
+static_assert(MD_ESLOTS >= 2u * MD_L && MD_ESLOTS <= 65535u && GRIM_TOPCAP <= 256, "entity index: load <= 1/2, 16-bit slots, 8-bit positions");
 static_assert(4u * (MD_NPB / 64u + 1u) + 64u * 16u <= 8u * MD_L, "word prefixes and the small-emit staging overlay the prefix minima");
 
 #ifdef GRIM_STAMPS  // diagnostic build: workgroup time per stage, hand-overs by reason
@@ -110,8 +114,10 @@ struct MidView {  // typed pointers into the arena
   uint32_t *ente;
   uint8_t *ents;
   uint64_t *bm;
-  lds_u64 *dk;
-  lds_u32 *dm;
+  uint64_t *bm2;
+  lds_u32 *smask;
+  uint16_t *eoff, *eslot;
+  uint8_t *epos;
   uint32_t *wpre;
   uint32_t *se1, *se2;
   double *sprob;
@@ -128,8 +134,11 @@ __device__ __forceinline__ MidView mid_view(MidShared &M) {
   v.ente = (uint32_t *)(M.arena + MD_OFF_ENTE);
   v.ents = M.arena + MD_OFF_ENTS;
   v.bm = (uint64_t *)(M.arena + MD_OFF_BM);
-  v.dk = (lds_u64 *)(M.arena + MD_OFF_DK);
-  v.dm = (lds_u32 *)(M.arena + MD_OFF_DM);
+  v.bm2 = (uint64_t *)(M.arena + MD_OFF_BM2);
+  v.smask = (lds_u32 *)(M.arena + MD_OFF_SMASK);
+  v.eoff = (uint16_t *)(M.arena + MD_OFF_EOFF);
+  v.eslot = (uint16_t *)(M.arena + MD_OFF_ESLOT);
+  v.epos = M.arena + MD_OFF_EPOS;
   v.wpre = (uint32_t *)M.T_m;
   v.sprob = (double *)((uint8_t *)M.T_m + ((4u * (MD_NPB / 64u + 1u) + 7u) & ~7u));
   v.se1 = (uint32_t *)(v.sprob + 64);
@@ -212,60 +221,122 @@ __device__ inline uint32_t mid_pass(const DevArgs &A, MidShared &M, const MidVie
   for (int w2 = 0; w2 < GRIM_NWAVE; ++w2) nA += M.tmp[w2];
   __syncthreads();
   if (!nodup && nA > 0) {
-    // first-wins dedup (impute.py:506-511, 603-611): one slot per unordered entity pair, the smallest bit number wins it.  The
-    // LDS table holds a pass of up to MD_DEDUP accepted pairs at load <= 1/2; a pass that accepted more is the general
-    // kernel's (its table is in HBM).  (Going through the table in rounds by key partition was tried: a round is two sweeps
-    // over the whole bitmap, and the subjects that need it need dozens -- 7.1 ms for the kernel instead of 2.0.)
-    if (nA > MD_DEDUP) return GRIM_NONE;  // (uniform)
-    for (uint32_t s = threadIdx.x; s < MD_DSLOTS; s += GRIM_WG) {
-      V.dk[s] = 0;
-      V.dm[s] = GRIM_NONE;
-    }
-    __syncthreads();
-    cnt = 0;
-    for (int sweep = 0; sweep < 2; ++sweep) {
-      for (int i = 0; i < M.nph; ++i) {
-        const uint32_t n2 = M.tlen[2 * i + 1], npi = M.tlen[2 * i] * n2;
-        if (!npi) continue;
-        const uint32_t magic = tile_magic(n2), w0 = M.boff[i] >> 6, nw = (npi + 63) >> 6;
-        for (uint32_t w = wv; w < nw; w += GRIM_NWAVE) {
-          const uint64_t m = V.bm[w0 + w];
-          if (m == 0) continue;
-          bool win = false;
-          if ((m >> lane) & 1ull) {
-            const uint32_t r = (w << 6) + lane, bit = M.boff[i] + r;
-            const PairRef pr = mid_pair(M, i, r, n2, magic);
-            const uint32_t lo = pr.e1 < pr.e2 ? pr.e1 : pr.e2, hi = pr.e1 < pr.e2 ? pr.e2 : pr.e1;
-            const uint64_t a = ((uint64_t)lo << 32) | hi | GRIM_VALID;
-            uint32_t s = (uint32_t)mix64(a) & (MD_DSLOTS - 1u);
-            for (;;) {  // (at most MD_DEDUP keys in MD_DSLOTS slots: an empty slot ends every probe sequence)
-              uint64_t c = __hip_atomic_load(&V.dk[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              if (c == 0 && sweep == 0) {
-                uint64_t expect = 0;
-                c = __hip_atomic_compare_exchange_strong(&V.dk[s], &expect, a, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-                        ? a : expect;
-              }
-              if (c == a) break;
-              s = (s + 1u) & (MD_DSLOTS - 1u);
+    // First-wins dedup (impute.py:506-511, 603-611) WITHOUT a table of pairs.  A pair is (entity x of side 2i at h, entity y
+    // of side 2i+1 at k); the same unordered {x, y} can only come up again where x and y sit in the two lists of another
+    // phase (either way round) or the other way round in this one.  Every entity knows the sides it is in (a 32-bit mask)
+    // and its position in each of them, so the earlier occurrences of a pair are a few bit operations away, and whether
+    // one of them was ACCEPTED is a bit of the pass's bitmap: the pair loses iff an occurrence with a smaller bit number
+    // has its bit set.  O(list entries) to set up, once per subject; no limit on the pairs a pass accepts.
+    if (!M.bc[6]) {
+      const int nsides = 2 * M.nph;
+      for (uint32_t t = threadIdx.x; t < MD_ESLOTS; t += GRIM_WG) V.smask[t] = 0;
+      if (threadIdx.x == 0) M.bc[5] = 0;
+      __syncthreads();
+      for (int sd = 0; sd < nsides; ++sd) {  // the entity index: slot of (hap, pop); bit 31 marks a used slot
+        const uint32_t a0 = M.seg[sd], len = M.tlen[sd];
+        for (uint32_t q = threadIdx.x; q < len; q += GRIM_WG) {
+          const uint32_t key = M.T_e[a0 + q] | 0x80000000u;
+          uint32_t t = (key * 0x9E3779B1u) >> 21;  // 11 bits
+          for (;;) {
+            uint32_t c = __hip_atomic_load(&V.smask[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (c == 0) {
+              uint32_t expect = 0;
+              c = __hip_atomic_compare_exchange_strong(&V.smask[t], &expect, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                      ? key : expect;
             }
-            if (sweep == 0) {
-              __hip_atomic_fetch_min(&V.dm[s], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            } else {
-              win = (uint32_t)V.dm[s] == bit;
-              if (win) {
-                const double prob = pair_prob(pr, mid_prior(M, prior, P, lds_prior, pr.e1, pr.e2));
-                amx = prob > amx ? prob : amx;
-              }
-            }
+            if (c == key) break;
+            t = (t + 1u) & (MD_ESLOTS - 1u);
           }
-          if (sweep == 1) {
-            const uint64_t mw = __ballot(win);
-            if (lane == 0) V.bm[w0 + w] = mw;
-            cnt += (uint32_t)__popcll(mw);
-          }
+          V.eslot[a0 + q] = (uint16_t)t;
         }
       }
       __syncthreads();
+      for (uint32_t t = threadIdx.x; t < MD_ESLOTS; t += GRIM_WG) V.smask[t] = 0;  // the keys are spent: the slots hold side masks now
+      __syncthreads();
+      for (int sd = 0; sd < nsides; ++sd) {
+        const uint32_t a0 = M.seg[sd], len = M.tlen[sd];
+        for (uint32_t q = threadIdx.x; q < len; q += GRIM_WG) {
+          const uint32_t old = __hip_atomic_fetch_or(&V.smask[V.eslot[a0 + q]], 1u << sd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if ((old >> sd) & 1u) M.bc[5] = 1;  // an entity twice in one list (never, by adjs_query's dict): not this scheme's case
+        }
+      }
+      __syncthreads();
+      {  // first occurrence per slot: exclusive prefix of the masks' popcounts (eight slots per thread)
+        constexpr uint32_t PER = MD_ESLOTS / GRIM_WG;
+        uint32_t sum = 0;
+        for (uint32_t q = 0; q < PER; ++q) sum += (uint32_t)__popc((uint32_t)V.smask[threadIdx.x * PER + q]);
+        uint32_t total;
+        uint32_t at = wg_excl_scan(sum, M.tmp, total);
+        for (uint32_t q = 0; q < PER; ++q) {
+          V.eoff[threadIdx.x * PER + q] = (uint16_t)at;
+          at += (uint32_t)__popc((uint32_t)V.smask[threadIdx.x * PER + q]);
+        }
+      }
+      __syncthreads();
+      for (int sd = 0; sd < nsides; ++sd) {  // positions, by entity and (ascending) side
+        const uint32_t a0 = M.seg[sd], len = M.tlen[sd];
+        for (uint32_t q = threadIdx.x; q < len; q += GRIM_WG) {
+          const uint32_t t = V.eslot[a0 + q];
+          V.epos[V.eoff[t] + (uint32_t)__popc((uint32_t)V.smask[t] & ((1u << sd) - 1u))] = (uint8_t)q;
+        }
+      }
+      if (threadIdx.x == 0) M.bc[6] = 1;
+      __syncthreads();
+    }
+    if (M.bc[5]) return GRIM_NONE;  // (uniform: read behind a barrier)
+    cnt = 0;
+    for (int i = 0; i < M.nph; ++i) {
+      const uint32_t n2 = M.tlen[2 * i + 1], npi = M.tlen[2 * i] * n2;
+      if (!npi) continue;
+      const uint32_t magic = tile_magic(n2), w0 = M.boff[i] >> 6, nw = (npi + 63) >> 6;
+      const uint32_t below = (4u << (2 * i)) - 1u;  // sides of the phases up to and including this one
+      for (uint32_t w = wv; w < nw; w += GRIM_NWAVE) {
+        const uint64_t m = V.bm[w0 + w];
+        if (m == 0) {
+          if (lane == 0) V.bm2[w0 + w] = 0;
+          continue;
+        }
+        bool win = false;
+        if ((m >> lane) & 1ull) {
+          const uint32_t r = (w << 6) + lane, bit = M.boff[i] + r;
+          const uint32_t h = n2 > 1 ? __umulhi(r, magic) : r, k = r - h * n2;
+          const uint32_t ea = M.seg[2 * i] + h, eb = M.seg[2 * i + 1] + k;
+          const uint32_t tx = V.eslot[ea], ty = V.eslot[eb];
+          const uint32_t mx = V.smask[tx], my = V.smask[ty];
+          const uint32_t ox = V.eoff[tx], oy = V.eoff[ty];
+          // bit 2j of `same`: x is in side 2j and y in side 2j+1; of `swap`: y in side 2j and x in side 2j+1
+          uint32_t same = mx & (my >> 1) & 0x55555555u & below & ~(1u << (2 * i));  // (not this occurrence itself)
+          uint32_t swp = my & (mx >> 1) & 0x55555555u & below;
+          bool lost = false;
+          while ((same | swp) && !lost) {
+            const bool sw = same == 0;
+            const uint32_t bits = sw ? swp : same;
+            const int sd = __ffs((int)bits) - 1;  // the even side of the phase, 2j
+            if (sw) swp &= swp - 1; else same &= same - 1;
+            const int j = sd >> 1;
+            // entity of the phase's first list: x (same way round) or y (swapped); its position there, and the other's
+            const uint32_t m1 = sw ? my : mx, m2 = sw ? mx : my, o1 = sw ? oy : ox, o2 = sw ? ox : oy;
+            const uint32_t h2 = V.epos[o1 + (uint32_t)__popc(m1 & ((1u << sd) - 1u))];
+            const uint32_t k2 = V.epos[o2 + (uint32_t)__popc(m2 & ((2u << sd) - 1u))];
+            const uint32_t bit2 = M.boff[j] + h2 * M.tlen[2 * j + 1] + k2;
+            if (bit2 < bit && ((V.bm[bit2 >> 6] >> (bit2 & 63u)) & 1ull)) lost = true;
+          }
+          win = !lost;
+          if (win) {
+            const PairRef pr = mid_pair(M, i, r, n2, magic);
+            const double prob = pair_prob(pr, mid_prior(M, prior, P, lds_prior, pr.e1, pr.e2));
+            amx = prob > amx ? prob : amx;
+          }
+        }
+        const uint64_t mw = __ballot(win);
+        if (lane == 0) V.bm2[w0 + w] = mw;
+        cnt += (uint32_t)__popcll(mw);
+      }
+    }
+    __syncthreads();
+    {  // the winners become the pass's bitmap
+      const uint32_t W = M.boff[GRIM_MAXPH] >> 6;
+      for (uint32_t w = threadIdx.x; w < W; w += GRIM_WG) V.bm[w] = V.bm2[w];
     }
     if (lane == 0) M.tmp[wv] = cnt;
     __syncthreads();
@@ -302,6 +373,7 @@ __device__ inline int mid_subject(const DevArgs &A, MidShared &M, uint32_t si) {
   if (tid < 16) ((uint32_t *)&M.subj)[tid] = ((const uint32_t *)&A.subj[si])[tid];
   if (tid < (int)(sizeof(grim_subject_result) / 4)) ((uint32_t *)&M.out)[tid] = 0;
   if (tid < GRIM_SIDES) M.cnt_side[tid] = 0;
+  if (tid == 0) M.bc[6] = 0;  // the dedup's entity index is not built yet
   __syncthreads();
   const grim_subject &sj = M.subj;
   const int n = sj.n_loci;

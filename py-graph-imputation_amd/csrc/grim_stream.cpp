@@ -11,7 +11,9 @@
 // the staging area (one H2D copy per range); a chunk whose results overflow its bounded row pool is split and run
 // again in halves.  No GPU code here: the device work goes through the engine.
 #include <errno.h>
+#include <execinfo.h>
 #include <fcntl.h>
+#include <signal.h>
 #include <sched.h>
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
@@ -40,6 +42,8 @@
 #include "../../include/grim_hip.h"
 #include "grim_engine_internal.h"
 #include "grim_host_internal.h"
+
+static thread_local uint64_t tl_dbg[8];  // what copy_pieces was doing (read by the GRIM_DEBUG_SEGV handler)
 
 namespace {
 
@@ -940,6 +944,8 @@ static void copy_pieces(grim_stream *s) {
     const uint32_t k = (uint32_t)t;
     if ((ng >> 32) != (t >> 32) || k >= (uint32_t)ng) return;  // another block's count, or past the end of this one
     grim_stream::CopyJob &job = s->copy_jobs[k];
+    tl_dbg[0] = k; tl_dbg[1] = (uint64_t)job.dst; tl_dbg[2] = (uint64_t)job.src; tl_dbg[3] = job.n; tl_dbg[4] = (uint64_t)job.nl.data();
+    tl_dbg[5] = job.nl.size(); tl_dbg[6] = t; tl_dbg[7] = ng;
     job.n_nl = copy_and_mark(job.dst, job.src, job.n, job.nl.data());
     s->copy_left.fetch_sub(1, std::memory_order_release);
   }
@@ -1227,8 +1233,11 @@ extern "C" int grim_stream_write(grim_stream *s, const char *text, uint64_t len)
       // pieces of ~48 KB (whole cache lines), at least one per thread
       const size_t nh = s->copiers.size();
       size_t parts = std::min<size_t>(COPY_PIECES, std::max<size_t>(nh + 1, (size_t)(blk / (48u << 10))));
-      const size_t per = ((blk / parts) + 63) & ~(size_t)63;
+      // (ceiling first: with the floor, a quotient that is already a multiple of 64 left a remainder for a 65th piece -- one
+      //  more than copy_jobs holds)
+      const size_t per = (((blk + parts - 1) / parts) + 63) & ~(size_t)63;
       parts = (size_t)((blk + per - 1) / per);
+      if (parts > COPY_PIECES) parts = COPY_PIECES;  // (cannot happen: per >= blk / parts)
       {
         std::lock_guard<std::mutex> lk(s->copy_mu);
         for (size_t k = 0; k < parts; ++k) {
@@ -1559,10 +1568,33 @@ extern "C" uint32_t grim_default_threads(void) {
   return nt;
 }
 
+// GRIM_DEBUG_SEGV=1: a SIGSEGV in any of the pipeline's threads prints the faulting thread's native frames (addresses inside
+// libgrim_hip.so resolve with addr2line against the same file) before the default action takes over.  Diagnostic aid only.
+static void segv_backtrace(int sig, siginfo_t *si, void *) {
+  void *frames[48];
+  const int n = backtrace(frames, 48);
+  char buf[512];
+  const int m = snprintf(buf, sizeof(buf), "grim: SIGSEGV at address %p; copy job: k=%llu dst=%llx src=%llx n=%llu nl=%llx nl_size=%llu ticket=%llx np_gen=%llx\n"
+                         "native frames of the faulting thread:\n", si ? si->si_addr : nullptr, (unsigned long long)tl_dbg[0], (unsigned long long)tl_dbg[1],
+                         (unsigned long long)tl_dbg[2], (unsigned long long)tl_dbg[3], (unsigned long long)tl_dbg[4], (unsigned long long)tl_dbg[5],
+                         (unsigned long long)tl_dbg[6], (unsigned long long)tl_dbg[7]);
+  (void)!write(2, buf, (size_t)m);
+  backtrace_symbols_fd(frames, n, 2);
+  signal(sig, SIG_DFL);
+  raise(sig);
+}
+
 extern "C" grim_stream *grim_stream_open(grim_ctx *ctx, const grim_graph *g, const grim_dict *dict, const grim_params *prm,
                                          const grim_prior_spec *priors, const char *const *pop_names, uint32_t n_pops,
                                          const grim_stream_opts *opts) {
   if (!ctx || !g || !dict || !prm || !priors || !pop_names || !opts || n_pops == 0) return nullptr;
+  if (getenv("GRIM_DEBUG_SEGV")) {
+    struct sigaction sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.sa_sigaction = segv_backtrace;
+    sa.sa_flags = SA_SIGINFO;
+    sigaction(SIGSEGV, &sa, nullptr);
+  }
   grim_stream *s = new grim_stream();
   s->ctx = ctx;
   s->graph = g;

@@ -340,7 +340,7 @@ def impute_sharded(conf_file, hap_pop_pair=False, graph=None, compute=None, proj
     chunk_lines = int(chunk_lines or os.environ.get("GRIM_SHARD_LINES", DEFAULT_CHUNK_LINES))
     names = {key: (path_key, flag) for key, path_key, flag in _I._OUT_FILES}
     error = peer_failed = None
-    sink = None
+    sink = unlinker = None
     files_announced = False
     alone = ctl.world == 1  # the one rank's stream appends to the output files: nothing to place
     # the job's id: unique per call and per job, published by rank 0 (keys of an earlier job on the same store never match)
@@ -358,12 +358,22 @@ def impute_sharded(conf_file, hap_pop_pair=False, graph=None, compute=None, proj
         if ctl.rank == 0:
             pathlib.Path(out_dir).mkdir(parents=False, exist_ok=True)
             if not alone:
-                # the shared output files: made (emptied) by rank 0 before any rank opens them for its pieces
+                # the shared output files: made by rank 0 before any rank opens them for its pieces.  An earlier run's file
+                # is moved aside and unlinked by a helper thread while the job runs -- truncating hundreds of megabytes of
+                # cached pages costs tens of milliseconds, and every other rank would be waiting for it
+                stale = []
                 for k in OUTPUT_KEYS:
                     if flags[k]:
+                        if os.path.isfile(out_paths[k]) and os.path.getsize(out_paths[k]) > (1 << 20):
+                            old = "%s.grim_old.%s" % (out_paths[k], tag)
+                            os.rename(out_paths[k], old)
+                            stale.append(old)
                         os.close(os.open(out_paths[k], os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644))
                 ctl.set(files_key, "ok")
                 files_announced = True
+                if stale:
+                    unlinker = threading.Thread(target=lambda: [os.unlink(f) for f in stale], name="grim-unlink", daemon=True)
+                    unlinker.start()
         elif ctl.wait_key(files_key, tag) != "ok":
             raise RuntimeError("impute_sharded: rank 0 could not create the output files")
         offs = chunk_offsets(in_path, chunk_lines)
@@ -431,6 +441,8 @@ def impute_sharded(conf_file, hap_pop_pair=False, graph=None, compute=None, proj
                 elif not return_texts:
                     result[k] = config[path_key]
     finally:
+        if unlinker is not None:
+            unlinker.join()
         ctl.barrier()  # one barrier at the end on every path: nobody leaves while another rank still reads the store
     if ctl.rank == 0 and return_texts and result is not None:
         for k in OUTPUT_KEYS:

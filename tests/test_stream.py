@@ -291,3 +291,45 @@ def test_device_tokenizer_equals_host_tokenizer(monkeypatch):
     for k in nat.TEXT_KEYS:
         assert t1[k] == t0[k], k
     assert st1.bytes_h2d > 0 and st1.subjects == st0.subjects == 3000
+
+
+def test_one_big_write_whose_pieces_divide_evenly():
+    """The reader copies a big write in up to 64 pieces (grim_stream_write): a block whose size / 64 is a multiple of the
+    piece granule plus a remainder used to be cut into 65 -- one more than the job array holds (a crash in the sharded
+    driver, whose segments happened to have such sizes).  One write of exactly 64 * 64 * 800 + 5 bytes against the same
+    text fed in small pieces."""
+    from grim import _native as nat
+
+    rows = synth.read_freqs(synth.CAU_FREQS)
+    lines = synth.SubjectGen(rows, 77).full(40000)
+    want = 64 * 64 * 800 + 5
+    text, n = [], 0
+    for l in lines:
+        if n + len(l) + 1 > want - 200:
+            break
+        text.append(l)
+        n += len(l) + 1
+    pad = want - n - 1 - len(lines[len(text)])  # the last line's id grows by what is missing
+    last = lines[len(text)]
+    text.append("X" * pad + last)
+    data = ("\n".join(text) + "\n").encode()
+    assert len(data) == want
+    conf = harness.base_conf(["CAU"])
+    imp, cfg = _imp("cau", conf)
+    params = imp._params(cfg, cfg["planb"], False, False)
+    ps, keep = nat.prior_spec(cfg["priority"], imp.unk_priors, imp.count_by_prob)
+    ctx = nat.default_context(None)
+    out = []
+    for step in (len(data), 4099):
+        st = nat.Stream(ctx, imp.netGraph.device(ctx), imp.netGraph.adict, params, ps, imp.populations, n_threads=16)
+        try:
+            for a in range(0, len(data), step):
+                st.write(data[a:a + step])
+            st.finish()
+            out.append({key: st.text(k) for k, key in enumerate(nat.TEXT_KEYS)})
+            assert not st.unsupported()
+        finally:
+            st.close()
+    for k in out[0]:
+        assert out[0][k] == out[1][k], k
+    assert out[0]["umug"].count("\n") == len(text)

@@ -43,4 +43,16 @@ for w in ("config2", "config4", "config5"):
 tj = os.path.join(src, "pmc_traffic.json")
 if os.path.exists(tj):
     shutil.copy(tj, os.path.join(dst, "%s_pmc_traffic.json" % tag))
+# which build the profiles are of: a digest of the kernel / host sources (bench.py computes the same one at run time and says
+# whether the committed profile it cites is of the build it is measuring) and the commit they were collected at
+import hashlib, json, subprocess
+sys.path.insert(0, ROOT)
+import bench
+meta = {"source_digest": bench.source_digest(), "tag": tag}
+try:
+    meta["commit"] = subprocess.check_output(["git", "rev-parse", "HEAD"], cwd=ROOT).decode().strip()
+    meta["dirty"] = bool(subprocess.check_output(["git", "status", "--porcelain", "--", "py-graph-imputation_amd/csrc", "include"], cwd=ROOT).decode().strip())
+except Exception:
+    pass
+json.dump(meta, open(os.path.join(dst, "%s_meta.json" % tag), "w"), indent=1)
 print("profiles/%s_* written" % tag)
