@@ -123,6 +123,7 @@ struct DevArgs {
   double *pprob;
 };
 #define GRIM_F_NO_NODUP 2u       // DevArgs.flags (GRIM_NO_NODUP=1): the pair passes always run their dedup (test switch)
+#define GRIM_F_NO_SIDEMASK 4u    // (GRIM_NO_SIDEMASK=1): tiled passes dedup through the slot's hash table as before round 4 (test switch)
 #define GRIM_NQ 24               // u32 words of `queue` (the run state block is counters + queue):
                                  // [13] bucket-start slots used [14] work units [15] units done by earlier launches of the run
                                  // [16] work counter of the mid-size kernel [17] its hand-overs to the general kernel

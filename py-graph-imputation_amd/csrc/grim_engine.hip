@@ -738,7 +738,8 @@ static void batch_init_params(grim_batch *b, const grim_graph *g, const grim_par
   L.save = take(p->save_mode ? 8ull * GRIM_NWAVE * 2 * GRIM_SAVE_CAP * (P + 1) : 0);
   L.stride = align256(o);
   b->timing = env_int("GRIM_TIMING", 0) != 0;
-  A.flags = (env_int("GRIM_TABLES_HBM", 0) ? GRIM_F_TABLES_HBM : 0u) | (env_int("GRIM_NO_NODUP", 0) ? GRIM_F_NO_NODUP : 0u);
+  A.flags = (env_int("GRIM_TABLES_HBM", 0) ? GRIM_F_TABLES_HBM : 0u) | (env_int("GRIM_NO_NODUP", 0) ? GRIM_F_NO_NODUP : 0u) |
+            (env_int("GRIM_NO_SIDEMASK", 0) ? GRIM_F_NO_SIDEMASK : 0u);
   memset(b->acc_ms, 0, sizeof(b->acc_ms));
   b->n_timed = 0;
   b->n_subj = b->n_small = b->n_medium = b->n_general = 0;

@@ -213,6 +213,7 @@ struct PairTile {
   uint32_t e1[GRIM_TOPCAP], e2[GRIM_TOPCAP];
   uint16_t d1[GRIM_TOPCAP], d2[GRIM_TOPCAP];    // dense numbers of the entities (pair_dense_ids), when the pass asked for them
   uint64_t bm[GRIM_TOPCAP * GRIM_TOPCAP / 64];  // accepted pairs of the phase, one bit each
+  uint64_t wbm[GRIM_TOPCAP * GRIM_TOPCAP / 64]; // ... and the winners among them (side-mask dedup)
   double lp[64];                                 // the prior matrix when it has at most 64 cells
 };
 static_assert(sizeof(PairTile) <= 16 * GRIM_WG * 4, "the phase tile lives in the histogram area");
@@ -332,6 +333,190 @@ __device__ inline int ladder_first(const DevArgs &A, WgShared &sh, const Slot &S
   return r;
 }
 
+// ---- a tiled pass with the SIDE-MASK dedup (round 4; first in the mid-size kernel, grim_mid.h) ---------------------------
+// First-wins dedup of calc_haps_pairs (impute.py:506-511, 603-611) without a table of pairs.  A pair is (entity x of side
+// 2i at h, entity y of side 2i+1 at k); the same unordered {x, y} can only come up again where x and y sit in the two lists
+// of another phase (either way round) or the other way round in this one.  Every entity (dense number d < D,
+// pair_dense_ids) knows the sides it is in -- a 32-bit mask -- and its position in each, so the earlier occurrences of a
+// pair are a few bit operations away, and whether one of them was ACCEPTED is a bit of that phase's accept bitmap: a pair
+// loses iff an occurrence with a smaller pair number has its bit set.  Two sweeps over the phase tiles: the first leaves
+// every phase's accept bits in the slot (32 KB, where the hash table was), the second decides and lists the winners in
+// pair order.  What it replaces for a subject with ~40 000 accepted pairs (config 5): 16 bytes of list per accepted pair,
+// a 1 MB table cleared per pass and one random 64-byte line per insert -- 15 MB of slot traffic per subject and a quarter
+// of the kernel's time.  The masks and positions live in the LDS behind the phase tile (the waves' top-K work areas are
+// free during the pair stage).  Returns GRIM_NONE when they do not fit, or a list names an entity twice: the caller takes
+// the table path.  All threads call.
+#define GRIM_SM_LDS_OFF (16u * GRIM_WG * 4u)
+__device__ inline uint32_t pair_pass_sidemask(const DevArgs &A, WgShared &sh, const Slot &S, const double *prior, uint32_t np,
+                                              double eps, bool emit, double *maxp) {
+  const int P = A.g.P;
+  const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
+  const uint64_t lt = (1ull << lane) - 1ull;
+  const uint32_t nsides = 2u * (uint32_t)sh.nph, n_ent = nsides * GRIM_TOPCAP;
+  constexpr uint32_t GW = GRIM_TOPCAP * GRIM_TOPCAP / 64;  // bitmap words per phase
+  if (A.tab_cap < GRIM_MAXPH * GW) return GRIM_NONE;
+  uint16_t *dense = (uint16_t *)S.gstart;
+  pair_dense_ids(A, sh, S, dense);  // (ends with a barrier) sh.bc[6] = distinct entities
+  const uint32_t D = sh.bc[6];
+  uint32_t ltot = 0;
+  for (uint32_t sd = 0; sd < nsides; ++sd) ltot += sh.Tn[sd];
+  const uint32_t lds_room = (uint32_t)(sizeof(WaveTop) * GRIM_NWAVE) - GRIM_SM_LDS_OFF;
+  const uint32_t off_eoff = 4u * D, off_epos = off_eoff + ((2u * (D + 2u) + 3u) & ~3u);
+  __syncthreads();
+  if (off_epos + ltot > lds_room) return GRIM_NONE;  // (uniform)
+  uint8_t *lds = (uint8_t *)sh.hist + GRIM_SM_LDS_OFF;
+  uint32_t *smask = (uint32_t *)lds;
+  uint16_t *eoff = (uint16_t *)(lds + off_eoff);
+  uint8_t *epos = lds + off_epos;
+  for (uint32_t d = tid; d < D; d += GRIM_WG) smask[d] = 0;
+  if (tid == 0) sh.bc[7] = 0;
+  __syncthreads();
+  for (uint32_t q = tid; q < n_ent; q += GRIM_WG) {
+    const uint32_t sd = q / GRIM_TOPCAP, idx = q % GRIM_TOPCAP;
+    if (idx >= sh.Tn[sd]) continue;
+    const uint32_t old = atomicOr(&smask[dense[q]], 1u << sd);
+    if ((old >> sd) & 1u) sh.bc[7] = 1;  // an entity twice in one list: not this scheme's case
+  }
+  __syncthreads();
+  if (sh.bc[7]) {
+    __syncthreads();
+    return GRIM_NONE;
+  }
+  {
+    const uint32_t per = (D + GRIM_WG - 1) / GRIM_WG;
+    const uint32_t d0 = tid * per < D ? tid * per : D, d1 = d0 + per < D ? d0 + per : D;
+    uint32_t sum = 0;
+    for (uint32_t d = d0; d < d1; ++d) sum += (uint32_t)__popc(smask[d]);
+    uint32_t total;
+    uint32_t at = wg_excl_scan(sum, sh.tmp, total);
+    for (uint32_t d = d0; d < d1; ++d) {
+      eoff[d] = (uint16_t)at;
+      at += (uint32_t)__popc(smask[d]);
+    }
+  }
+  __syncthreads();
+  for (uint32_t q = tid; q < n_ent; q += GRIM_WG) {
+    const uint32_t sd = q / GRIM_TOPCAP, idx = q % GRIM_TOPCAP;
+    if (idx >= sh.Tn[sd]) continue;
+    const uint32_t d = dense[q];
+    epos[eoff[d] + (uint32_t)__popc(smask[d] & ((1u << sd) - 1u))] = (uint8_t)idx;
+  }
+  PairTile &T = *(PairTile *)sh.hist;
+  uint64_t *G = (uint64_t *)S.k0;  // [GRIM_MAXPH][GW]: the accept bits of every phase
+  const bool lds_prior = P * P <= 64;
+  if (lds_prior)
+    for (int c = tid; c < P * P; c += GRIM_WG) T.lp[c] = prior[c];
+  // ---- sweep 1: accept bits ----------------------------------------------------------------------------------------------
+  for (int i = 0; i < sh.nph; ++i) {
+    const uint32_t n2 = sh.Tn[2 * i + 1], npi = sh.Tn[2 * i] * n2;
+    if (!npi) continue;
+    __syncthreads();  // the previous tile is spent
+    tile_load(T, sh, S, i);
+    __syncthreads();
+    const uint32_t magic = tile_magic(n2);
+    const uint32_t q = ((npi + GRIM_NWAVE * 64 - 1) / (GRIM_NWAVE * 64)) * 64, r0 = wv * q, r1 = r0 + q < npi ? r0 + q : npi;
+    for (uint32_t c0 = r0; c0 < r1; c0 += 64) {
+      const uint32_t r = c0 + lane;
+      bool on = false;
+      if (r < r1) {
+        const PairRef pr = tile_pair(T, r, n2, magic);
+        const uint32_t cell = ENT_POP(pr.e1) * P + ENT_POP(pr.e2);
+        on = pair_accept(eps, pr, lds_prior ? T.lp[cell] : prior[cell]);
+      }
+      const uint64_t m = __ballot(on);
+      if (lane == 0) G[(uint32_t)i * GW + (c0 >> 6)] = m;
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  // ---- sweep 2: winners, in pair order -------------------------------------------------------------------------------------
+  uint32_t nU = 0;
+  double mx = 0.0;
+  for (int i = 0; i < sh.nph; ++i) {
+    const uint32_t n2 = sh.Tn[2 * i + 1], npi = sh.Tn[2 * i] * n2;
+    if (!npi) continue;
+    __syncthreads();
+    tile_load(T, sh, S, i, dense);
+    for (uint32_t w = tid; w < (npi + 63) / 64; w += GRIM_WG) T.bm[w] = G[(uint32_t)i * GW + w];
+    __syncthreads();
+    const uint32_t magic = tile_magic(n2);
+    const uint32_t q = ((npi + GRIM_NWAVE * 64 - 1) / (GRIM_NWAVE * 64)) * 64, r0 = wv * q, r1 = r0 + q < npi ? r0 + q : npi;
+    const uint32_t below = (4u << (2 * i)) - 1u;  // sides of the phases up to and including this one
+    uint32_t cnt = 0;
+    for (uint32_t c0 = r0; c0 < r1; c0 += 64) {
+      const uint64_t m = T.bm[c0 >> 6];
+      bool win = false;
+      if ((m >> lane) & 1ull) {
+        const uint32_t r = c0 + lane;
+        const uint32_t h = n2 > 1 ? __umulhi(r, magic) : r, k = r - h * n2;
+        const uint32_t dx = T.d1[h], dy = T.d2[k];
+        const uint32_t mkx = smask[dx], mky = smask[dy], ox = eoff[dx], oy = eoff[dy];
+        // bit 2j of `same`: x is in side 2j and y in side 2j+1; of `swp`: y in side 2j and x in side 2j+1
+        uint32_t same = mkx & (mky >> 1) & 0x55555555u & below & ~(1u << (2 * i));  // (not this occurrence itself)
+        uint32_t swp = mky & (mkx >> 1) & 0x55555555u & below;
+        bool lost = false;
+        while ((same | swp) && !lost) {
+          const bool sw = same == 0;
+          const uint32_t bits = sw ? swp : same;
+          const int sd = __ffs((int)bits) - 1;  // the even side of the phase, 2j
+          if (sw) swp &= swp - 1; else same &= same - 1;
+          const int j = sd >> 1;
+          const uint32_t m1 = sw ? mky : mkx, m2 = sw ? mkx : mky, o1 = sw ? oy : ox, o2 = sw ? ox : oy;
+          const uint32_t h2 = epos[o1 + (uint32_t)__popc(m1 & ((1u << sd) - 1u))];
+          const uint32_t k2 = epos[o2 + (uint32_t)__popc(m2 & ((2u << sd) - 1u))];
+          const uint32_t b2 = h2 * sh.Tn[2 * j + 1] + k2;
+          if (j == i) {
+            if (b2 < r && ((T.bm[b2 >> 6] >> (b2 & 63u)) & 1ull)) lost = true;
+          } else if ((G[(uint32_t)j * GW + (b2 >> 6)] >> (b2 & 63u)) & 1ull) {
+            lost = true;  // (an earlier phase: every pair of it comes first)
+          }
+        }
+        win = !lost;
+      }
+      const uint64_t mw = __ballot(win);
+      if (lane == 0) T.wbm[c0 >> 6] = mw;
+      cnt += (uint32_t)__popcll(mw);
+    }
+    if (lane == 0) sh.tmp[wv] = cnt;
+    __syncthreads();
+    uint32_t base = nU, total = 0;
+    for (int w2 = 0; w2 < GRIM_NWAVE; ++w2) {
+      if (w2 < wv) base += sh.tmp[w2];
+      total += sh.tmp[w2];
+    }
+    for (uint32_t c0 = r0; c0 < r1; c0 += 64) {
+      const uint64_t mw = T.wbm[c0 >> 6];
+      if ((mw >> lane) & 1ull) {
+        const uint32_t r = c0 + lane;
+        const PairRef pr = tile_pair(T, r, n2, magic);
+        const uint32_t cell = ENT_POP(pr.e1) * P + ENT_POP(pr.e2);
+        const double prob = pair_prob(pr, lds_prior ? T.lp[cell] : prior[cell]);
+        mx = prob > mx ? prob : mx;
+        if (emit) {
+          const uint32_t pos = base + (uint32_t)__popcll(mw & lt);
+          S.Useq[pos] = sh.poff[i] + r;
+          S.Uprob[pos] = prob;
+        }
+      }
+      base += (uint32_t)__popcll(mw);
+    }
+    nU += total;
+  }
+  __syncthreads();
+  for (int d = 32; d > 0; d >>= 1) {
+    const double o = __shfl_xor(mx, d);
+    if (o > mx) mx = o;
+  }
+  if (lane == 0) sh.dtmp[wv] = mx;
+  __syncthreads();
+  mx = sh.dtmp[0];
+  for (int w2 = 1; w2 < GRIM_NWAVE; ++w2)
+    if (sh.dtmp[w2] > mx) mx = sh.dtmp[w2];
+  __syncthreads();
+  *maxp = mx;
+  return nU;
+}
+
 // One full pass at `eps`: dedup (first f wins), MaxProb over winners, optionally the ordered list
 // U of winners.  Returns the number of winners; *maxp gets MaxProb.  (impute.py:512-527)
 __device__ inline uint32_t pair_pass(const DevArgs &A, WgShared &sh, const Slot &S, const double *prior, uint32_t np,
@@ -415,6 +600,10 @@ __device__ inline uint32_t pair_pass(const DevArgs &A, WgShared &sh, const Slot 
 #endif
   uint32_t nA = 0;
   const bool tiled = np >= GRIM_TILE_MIN;
+  if (tiled && !nodup && !(A.flags & GRIM_F_NO_SIDEMASK)) {
+    const uint32_t r = pair_pass_sidemask(A, sh, S, prior, np, eps, emit, maxp);
+    if (r != GRIM_NONE) return r;  // (else: the table path below)
+  }
   uint32_t *Akey32 = (uint32_t *)S.ska;       // tiled passes: 24-bit keys over dense entity numbers
   uint16_t *dense = (uint16_t *)S.gstart;
   if (tiled) {

@@ -259,6 +259,48 @@ def test_mid_size_kernel_equals_general_kernel(monkeypatch):
     assert imp.last_stats["n"] == 800
 
 
+def test_side_mask_dedup_equals_table_dedup(monkeypatch):
+    """The general and Plan-B kernels' tiled pair passes (>= 8192 scored pairs) dedup from the entities' side masks and
+    positions (pair_pass_sidemask, grim_pair.h) instead of a hash table of pairs in the slot; GRIM_NO_SIDEMASK=1 restores the
+    table.  Subjects built to need it: few typed loci (the lists saturate), heavy ambiguity, side 2 repeating side 1's
+    alternatives (overlapping lists: duplicates across phases and mirrored inside a phase), homozygous subjects; the
+    mid-size kernel off so that they all reach the general kernel.  Both ways, the mid-size kernel's own side-mask dedup,
+    and the oracle."""
+    rows = synth.read_freqs(synth.CAU_FREQS)
+    pops = harness.POPS["pop4"]
+    gen = synth.SubjectGen(rows, 343, pops=pops)
+    lines = []
+    for k, l in enumerate(gen.mixed(260, amb=0.9, miss=0.45, recomb=0.2)):
+        f = l.split(",")
+        loci = f[1].split("^")
+        for i, loc in enumerate(loci):
+            a, b = loc.split("+")
+            loci[i] = a + "+" + (a.split("/")[0] + "/" + b if k % 3 else a)
+        lines.append(",".join([f[0] + "y", "^".join(loci)] + f[2:]))
+    lines += gen.mixed(120, amb=0.8, miss=0.5, recomb=0.3)
+    conf = harness.base_conf(pops)
+    conf["UNK_priors"] = "MR"
+    out = {}
+    for mode in ("mid", "sidemask", "table"):
+        monkeypatch.delenv("GRIM_NO_MID", raising=False)
+        monkeypatch.delenv("GRIM_NO_SIDEMASK", raising=False)
+        if mode != "mid":
+            monkeypatch.setenv("GRIM_NO_MID", "1")
+        if mode == "table":
+            monkeypatch.setenv("GRIM_NO_SIDEMASK", "1")
+        out[mode], _, _ = _run("pop4", conf, lines, "smd_" + mode)
+    monkeypatch.delenv("GRIM_NO_MID", raising=False)
+    monkeypatch.delenv("GRIM_NO_SIDEMASK", raising=False)
+    for k in out["table"]:
+        assert out["sidemask"][k] == out["table"][k], ("side mask vs table", k)
+        assert out["mid"][k] == out["table"][k], ("mid-size kernel vs table", k)
+    exp, _ = harness.run_oracle("pop4", conf, lines[:150], tag="smd_orc")
+    ids = {l.split(",")[0] for l in lines[:150]}
+    for k in ("umug", "umug_pops", "pmug", "pmug_pops"):
+        mine = [l for l in out["sidemask"][k].splitlines() if l.split(",", 1)[0] in ids]
+        assert mine == exp[k].splitlines(), k
+
+
 def test_pair_pass_without_dedup_equals_pair_pass_with_dedup(monkeypatch):
     """Subjects whose two '/' lists are disjoint at every differing position skip the first-wins dedup of the pair passes
     (prepare_lists, grim_plan_a.h: no haplotype can belong to two phase sides).  GRIM_NO_NODUP=1 sends every subject through
