@@ -182,6 +182,15 @@ __device__ __forceinline__ bool pair_accept(double eps, const PairRef &pr, doubl
   return w * pr.p2 >= thr;
 }
 
+// the same test with the quotient x = eps / P1 at hand: it depends on the pair's FIRST entry only, so a phase tile computes
+// it once per first-list entry (128 IEEE divisions) instead of once per scored pair (up to 16 384)
+__device__ __forceinline__ bool pair_accept_x(double x, const PairRef &pr, double w) {
+  if (!(pr.m2 >= x)) return false;
+  if (!(w > 0.0)) return false;
+  double thr = (ENT_HAP(pr.e1) == ENT_HAP(pr.e2)) ? x * 2.0 : x;
+  return w * pr.p2 >= thr;
+}
+
 __device__ __forceinline__ double pair_prob(const PairRef &pr, double w) {
   double prob = pr.p1 * pr.p2 * w;  // (P1*P2)*prior, impute.py:515-521
   if (ENT_HAP(pr.e1) != ENT_HAP(pr.e2)) prob = prob * 2.0;
@@ -214,9 +223,11 @@ struct PairTile {
   uint16_t d1[GRIM_TOPCAP], d2[GRIM_TOPCAP];    // dense numbers of the entities (pair_dense_ids), when the pass asked for them
   uint64_t bm[GRIM_TOPCAP * GRIM_TOPCAP / 64];  // accepted pairs of the phase, one bit each
   uint64_t wbm[GRIM_TOPCAP * GRIM_TOPCAP / 64]; // ... and the winners among them (side-mask dedup)
+  double xq[GRIM_TOPCAP];                        // eps / p1[h] of the pass in hand (tile_quotients)
   double lp[64];                                 // the prior matrix when it has at most 64 cells
 };
 static_assert(sizeof(PairTile) <= 16 * GRIM_WG * 4, "the phase tile lives in the histogram area");
+#define GRIM_SM_LDS_OFF (16u * GRIM_WG * 4u)  // the LDS behind the tile, up to the end of the waves' top-K work areas: free in the pair stage
 
 // all threads; the caller synchronises before reading the tile and again before the next tile_load
 __device__ __forceinline__ void tile_load(PairTile &T, const WgShared &sh, const Slot &S, int i, const uint16_t *dense = nullptr) {
@@ -284,6 +295,11 @@ __device__ __forceinline__ PairRef tile_pair(const PairTile &T, uint32_t r, uint
   pr.e2 = T.e2[k];
   return pr;
 }
+// eps / p1[h] for the rows of the tile in hand; all threads, between the barrier behind tile_load and the pairs
+__device__ __forceinline__ void tile_quotients(PairTile &T, uint32_t n1, double eps) {
+  for (uint32_t h = threadIdx.x; h < n1; h += GRIM_WG) T.xq[h] = eps / T.p1[h];
+}
+__device__ __forceinline__ uint32_t tile_row(uint32_t r, uint32_t n2, uint32_t magic) { return n2 > 1 ? __umulhi(r, magic) : r; }
 __device__ __forceinline__ uint32_t tile_magic(uint32_t n2) { return n2 > 1 ? (uint32_t)(0x100000000ull / n2) + 1u : 0u; }
 
 // first ladder index at which ANY pair is accepted (n_ladder if none).  Equals the reference's
@@ -304,18 +320,31 @@ __device__ inline int ladder_first(const DevArgs &A, WgShared &sh, const Slot &S
     }
   } else {
     PairTile &T = *(PairTile *)sh.hist;
+    // the quotients ladder[idx] / p1[h] of a phase, once per row and step, in the LDS behind the tile (the waves' top-K work
+    // areas are free during the pair stage): a pair then costs compares only, whatever the number of steps it is tried at
+    double *X = (double *)((uint8_t *)sh.hist + GRIM_SM_LDS_OFF);
+    const int nl = A.prm.n_ladder;
+    const bool rowq = (uint32_t)nl * GRIM_TOPCAP * 8u <= (uint32_t)(sizeof(WaveTop) * GRIM_NWAVE) - GRIM_SM_LDS_OFF;
     for (int i = 0; i < sh.nph; ++i) {
-      const uint32_t n2 = sh.Tn[2 * i + 1], npi = sh.Tn[2 * i] * n2;
+      const uint32_t n1 = sh.Tn[2 * i], n2 = sh.Tn[2 * i + 1], npi = n1 * n2;
       if (!npi) continue;
       __syncthreads();
       tile_load(T, sh, S, i);
       __syncthreads();
+      if (rowq) {
+        for (uint32_t t = threadIdx.x; t < (uint32_t)nl * n1; t += GRIM_WG) {
+          const uint32_t idx = t / n1, h = t - idx * n1;
+          X[idx * GRIM_TOPCAP + h] = A.prm.ladder[idx] / T.p1[h];
+        }
+        __syncthreads();
+      }
       const uint32_t magic = tile_magic(n2);
       for (uint32_t r = threadIdx.x; r < npi && best > 0; r += GRIM_WG) {
         const PairRef q = tile_pair(T, r, n2, magic);
         const double w = prior[ENT_POP(q.e1) * P + ENT_POP(q.e2)];
+        const uint32_t h = tile_row(r, n2, magic);
         for (int idx = 0; idx < best; ++idx) {
-          if (pair_accept(A.prm.ladder[idx], q, w)) {
+          if (rowq ? pair_accept_x(X[idx * GRIM_TOPCAP + h], q, w) : pair_accept(A.prm.ladder[idx], q, w)) {
             best = idx;
             break;
           }
@@ -346,7 +375,6 @@ __device__ inline int ladder_first(const DevArgs &A, WgShared &sh, const Slot &S
 // of the kernel's time.  The masks and positions live in the LDS behind the phase tile (the waves' top-K work areas are
 // free during the pair stage).  Returns GRIM_NONE when they do not fit, or a list names an entity twice: the caller takes
 // the table path.  All threads call.
-#define GRIM_SM_LDS_OFF (16u * GRIM_WG * 4u)
 __device__ inline uint32_t pair_pass_sidemask(const DevArgs &A, WgShared &sh, const Slot &S, const double *prior, uint32_t np,
                                               double eps, bool emit, double *maxp) {
   const int P = A.g.P;
@@ -413,6 +441,8 @@ __device__ inline uint32_t pair_pass_sidemask(const DevArgs &A, WgShared &sh, co
     __syncthreads();  // the previous tile is spent
     tile_load(T, sh, S, i);
     __syncthreads();
+    tile_quotients(T, sh.Tn[2 * i], eps);
+    __syncthreads();
     const uint32_t magic = tile_magic(n2);
     const uint32_t q = ((npi + GRIM_NWAVE * 64 - 1) / (GRIM_NWAVE * 64)) * 64, r0 = wv * q, r1 = r0 + q < npi ? r0 + q : npi;
     for (uint32_t c0 = r0; c0 < r1; c0 += 64) {
@@ -421,7 +451,7 @@ __device__ inline uint32_t pair_pass_sidemask(const DevArgs &A, WgShared &sh, co
       if (r < r1) {
         const PairRef pr = tile_pair(T, r, n2, magic);
         const uint32_t cell = ENT_POP(pr.e1) * P + ENT_POP(pr.e2);
-        on = pair_accept(eps, pr, lds_prior ? T.lp[cell] : prior[cell]);
+        on = pair_accept_x(T.xq[tile_row(r, n2, magic)], pr, lds_prior ? T.lp[cell] : prior[cell]);
       }
       const uint64_t m = __ballot(on);
       if (lane == 0) G[(uint32_t)i * GW + (c0 >> 6)] = m;
@@ -621,6 +651,8 @@ __device__ inline uint32_t pair_pass(const DevArgs &A, WgShared &sh, const Slot 
       __syncthreads();  // the previous tile is spent
       tile_load(T, sh, S, i, nodup ? nullptr : dense);
       __syncthreads();
+      tile_quotients(T, sh.Tn[2 * i], eps);
+      __syncthreads();
       const uint32_t magic = tile_magic(n2);
       // wave w owns the w-th stretch of the phase's pairs (whole chunks of 64): pass 1 marks and counts the accepted ones,
       // pass 2 writes them behind the waves before it -- two barriers per phase instead of two per 1024 pairs
@@ -632,7 +664,7 @@ __device__ inline uint32_t pair_pass(const DevArgs &A, WgShared &sh, const Slot 
         if (r < r1) {
           const PairRef pr = tile_pair(T, r, n2, magic);
           const uint32_t cell = ENT_POP(pr.e1) * P + ENT_POP(pr.e2);
-          on = pair_accept(eps, pr, lds_prior ? T.lp[cell] : prior[cell]);
+          on = pair_accept_x(T.xq[tile_row(r, n2, magic)], pr, lds_prior ? T.lp[cell] : prior[cell]);
         }
         const uint64_t m = __ballot(on);
         if (lane == 0) T.bm[c0 >> 6] = m;
