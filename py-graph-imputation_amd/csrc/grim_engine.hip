@@ -109,12 +109,14 @@ __global__ __launch_bounds__(GRIM_WG, GRIM_WG_PER_CU) void grim_plan_a_kernel(De
       double mx = 0.0;
       if (e < A.prm.n_ladder) {
         double eps = A.prm.ladder[e];
+        bool first = true;
         if (eps > 0.0) {
           pair_pass(A, sh, S, prior, np, eps, false, &mx);
           STAMP(10);
           eps = mx / 100000.0;  // impute.py:1685
+          first = false;
         }
-        nU = pair_pass(A, sh, S, prior, np, eps, true, &mx);
+        nU = pair_pass(A, sh, S, prior, np, eps, true, &mx, first);
         STAMP(11);
       }
       const unsigned long long t_pairs = STAMP_NOW();
@@ -1090,6 +1092,7 @@ extern "C" grim_batch *grim_batch_upload(grim_ctx *c, const grim_graph *g, const
   // the ones that reproduce the reference's misses)
   rule.small_ok = (P == 1) && p->opt_threshold > 1 && !getenv("GRIM_NO_SMALL") && g->d.order_bad == 0;
   rule.medium_ok = !getenv("GRIM_NO_MEDIUM") && g->d.order_bad == 0;
+  rule.medium_max_cost = getenv("GRIM_MEDIUM_MAXCOST") ? atof(getenv("GRIM_MEDIUM_MAXCOST")) : 0.0;
   rule.graph_loci = g->d.n_loci;
   rule.opt_threshold = p->opt_threshold;
   std::vector<uint32_t> os, om, og;

@@ -59,12 +59,14 @@ enum { GRIM_CLS_SMALL = 0, GRIM_CLS_MEDIUM = 1, GRIM_CLS_GENERAL = 2 };
 struct ClassRule {
   bool small_ok;           // one population, options threshold > 1, half-wave kernel not disabled
   bool medium_ok;          // one-wave kernel not disabled
+  double medium_max_cost;  // subjects whose grim_cost exceeds it skip the one-wave kernel (0: no limit): it would hand them on
   uint32_t graph_loci;
   uint64_t opt_threshold;
 };
 
 // fully typed + unambiguous + one population -> half-wave kernel; all sides opened by the cartesian branch and few
 // candidates in total -> one-wave kernel; everything else -> general kernel
+static inline double grim_cost(const grim_subject &sj);
 static inline int grim_classify(const ClassRule &R, const grim_subject &sj) {
   bool sm = R.small_ok && sj.n_loci == GRIM_MAXL && R.graph_loci == GRIM_MAXL && sj.flags == 0;
   for (int l = 0; l < GRIM_MAXL && sm; ++l) sm = sj.cnt[l][0] == 1 && sj.cnt[l][1] == 1 && sj.wid[l][0] == 1 && sj.wid[l][1] == 1;
@@ -76,6 +78,7 @@ static inline int grim_classify(const ClassRule &R, const grim_subject &sj) {
     opts *= (double)(sj.wid[l][0] > sj.wid[l][1] ? sj.wid[l][0] : sj.wid[l][1]);
   }
   md = md && cand <= 2048.0 && opts < (double)R.opt_threshold;
+  if (md && R.medium_max_cost > 0.0 && grim_cost(sj) > R.medium_max_cost) md = false;
   return md ? GRIM_CLS_MEDIUM : GRIM_CLS_GENERAL;
 }
 

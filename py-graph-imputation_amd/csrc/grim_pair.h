@@ -42,6 +42,7 @@ struct WgShared {
   uint16_t bestc[GRIM_SIDES][GRIM_MAXL];
   uint8_t reduced;
   uint8_t nodup;       // no two scored pairs of this subject can be the same unordered entity pair (prepare_lists)
+  uint8_t sm_ok;       // the side-mask dedup's entity masks / positions (LDS behind the phase tile) describe the current lists
   uint32_t comp_mask;  // slots - 1 of the composite-haplotype table as cleared for the current pass (plan B / C)
   // abits[l][c]: bit a set = allele id a is in the subject's list of position l, column c (version 0).
   // The intersection opening tests a graph node against a side with one bit per position.
@@ -325,6 +326,9 @@ __device__ inline int ladder_first(const DevArgs &A, WgShared &sh, const Slot &S
     double *X = (double *)((uint8_t *)sh.hist + GRIM_SM_LDS_OFF);
     const int nl = A.prm.n_ladder;
     const bool rowq = (uint32_t)nl * GRIM_TOPCAP * 8u <= (uint32_t)(sizeof(WaveTop) * GRIM_NWAVE) - GRIM_SM_LDS_OFF;
+    const bool lds_prior = P * P <= 64;  // (a global load per pair -- an L1 round trip inside the loop -- was most of the ladder's time)
+    if (lds_prior)
+      for (int c = threadIdx.x; c < P * P; c += GRIM_WG) T.lp[c] = prior[c];
     for (int i = 0; i < sh.nph; ++i) {
       const uint32_t n1 = sh.Tn[2 * i], n2 = sh.Tn[2 * i + 1], npi = n1 * n2;
       if (!npi) continue;
@@ -341,7 +345,8 @@ __device__ inline int ladder_first(const DevArgs &A, WgShared &sh, const Slot &S
       const uint32_t magic = tile_magic(n2);
       for (uint32_t r = threadIdx.x; r < npi && best > 0; r += GRIM_WG) {
         const PairRef q = tile_pair(T, r, n2, magic);
-        const double w = prior[ENT_POP(q.e1) * P + ENT_POP(q.e2)];
+        const uint32_t cell = ENT_POP(q.e1) * P + ENT_POP(q.e2);
+        const double w = lds_prior ? T.lp[cell] : prior[cell];
         const uint32_t h = tile_row(r, n2, magic);
         for (int idx = 0; idx < best; ++idx) {
           if (rowq ? pair_accept_x(X[idx * GRIM_TOPCAP + h], q, w) : pair_accept(A.prm.ladder[idx], q, w)) {
@@ -376,7 +381,7 @@ __device__ inline int ladder_first(const DevArgs &A, WgShared &sh, const Slot &S
 // free during the pair stage).  Returns GRIM_NONE when they do not fit, or a list names an entity twice: the caller takes
 // the table path.  All threads call.
 __device__ inline uint32_t pair_pass_sidemask(const DevArgs &A, WgShared &sh, const Slot &S, const double *prior, uint32_t np,
-                                              double eps, bool emit, double *maxp) {
+                                              double eps, bool emit, double *maxp, bool fresh) {
   const int P = A.g.P;
   const int tid = threadIdx.x, lane = lane_id(), wv = wave_id();
   const uint64_t lt = (1ull << lane) - 1ull;
@@ -384,29 +389,42 @@ __device__ inline uint32_t pair_pass_sidemask(const DevArgs &A, WgShared &sh, co
   constexpr uint32_t GW = GRIM_TOPCAP * GRIM_TOPCAP / 64;  // bitmap words per phase
   if (A.tab_cap < GRIM_MAXPH * GW) return GRIM_NONE;
   uint16_t *dense = (uint16_t *)S.gstart;
-  pair_dense_ids(A, sh, S, dense);  // (ends with a barrier) sh.bc[6] = distinct entities
-  const uint32_t D = sh.bc[6];
+  // the second pass on the same lists (final epsilon after the MaxProb pass) finds numbers, masks and positions in place
+  const bool build = fresh || !sh.sm_ok;
+  if (!fresh && !sh.sm_ok) return GRIM_NONE;  // (uniform) the first pass took the table path: so does this one
+  if (build) pair_dense_ids(A, sh, S, dense);  // (ends with a barrier) sh.bc[6] = distinct entities
+  if (build && threadIdx.x == 0) sh.bc[5] = sh.bc[6];
+  __syncthreads();
+  const uint32_t D = sh.bc[5];
   uint32_t ltot = 0;
   for (uint32_t sd = 0; sd < nsides; ++sd) ltot += sh.Tn[sd];
   const uint32_t lds_room = (uint32_t)(sizeof(WaveTop) * GRIM_NWAVE) - GRIM_SM_LDS_OFF;
   const uint32_t off_eoff = 4u * D, off_epos = off_eoff + ((2u * (D + 2u) + 3u) & ~3u);
   __syncthreads();
-  if (off_epos + ltot > lds_room) return GRIM_NONE;  // (uniform)
+  if (off_epos + ltot > lds_room) {  // (uniform)
+    if (tid == 0) sh.sm_ok = 0;
+    __syncthreads();
+    return GRIM_NONE;
+  }
   uint8_t *lds = (uint8_t *)sh.hist + GRIM_SM_LDS_OFF;
   uint32_t *smask = (uint32_t *)lds;
   uint16_t *eoff = (uint16_t *)(lds + off_eoff);
   uint8_t *epos = lds + off_epos;
+  if (build) {
   for (uint32_t d = tid; d < D; d += GRIM_WG) smask[d] = 0;
-  if (tid == 0) sh.bc[7] = 0;
+  if (tid == 0) {
+    sh.bc[4] = 0;
+    sh.sm_ok = 0;
+  }
   __syncthreads();
   for (uint32_t q = tid; q < n_ent; q += GRIM_WG) {
     const uint32_t sd = q / GRIM_TOPCAP, idx = q % GRIM_TOPCAP;
     if (idx >= sh.Tn[sd]) continue;
     const uint32_t old = atomicOr(&smask[dense[q]], 1u << sd);
-    if ((old >> sd) & 1u) sh.bc[7] = 1;  // an entity twice in one list: not this scheme's case
+    if ((old >> sd) & 1u) sh.bc[4] = 1;  // an entity twice in one list: not this scheme's case
   }
   __syncthreads();
-  if (sh.bc[7]) {
+  if (sh.bc[4]) {
     __syncthreads();
     return GRIM_NONE;
   }
@@ -429,6 +447,8 @@ __device__ inline uint32_t pair_pass_sidemask(const DevArgs &A, WgShared &sh, co
     const uint32_t d = dense[q];
     epos[eoff[d] + (uint32_t)__popc(smask[d] & ((1u << sd) - 1u))] = (uint8_t)idx;
   }
+  if (tid == 0) sh.sm_ok = 1;
+  }  // build
   PairTile &T = *(PairTile *)sh.hist;
   uint64_t *G = (uint64_t *)S.k0;  // [GRIM_MAXPH][GW]: the accept bits of every phase
   const bool lds_prior = P * P <= 64;
@@ -549,8 +569,9 @@ __device__ inline uint32_t pair_pass_sidemask(const DevArgs &A, WgShared &sh, co
 
 // One full pass at `eps`: dedup (first f wins), MaxProb over winners, optionally the ordered list
 // U of winners.  Returns the number of winners; *maxp gets MaxProb.  (impute.py:512-527)
+// fresh_lists = false: the caller's previous pair_pass ran on these very top lists (the MaxProb pass before the final one)
 __device__ inline uint32_t pair_pass(const DevArgs &A, WgShared &sh, const Slot &S, const double *prior, uint32_t np,
-                                     double eps, bool emit, double *maxp) {
+                                     double eps, bool emit, double *maxp, bool fresh_lists = true) {
   const int P = A.g.P;
   const int tid = threadIdx.x;
   // nodup (prepare_lists): every scored pair is a different unordered entity pair, so every accepted pair wins -- no
@@ -631,7 +652,7 @@ __device__ inline uint32_t pair_pass(const DevArgs &A, WgShared &sh, const Slot 
   uint32_t nA = 0;
   const bool tiled = np >= GRIM_TILE_MIN;
   if (tiled && !nodup && !(A.flags & GRIM_F_NO_SIDEMASK)) {
-    const uint32_t r = pair_pass_sidemask(A, sh, S, prior, np, eps, emit, maxp);
+    const uint32_t r = pair_pass_sidemask(A, sh, S, prior, np, eps, emit, maxp, fresh_lists);
     if (r != GRIM_NONE) return r;  // (else: the table path below)
   }
   uint32_t *Akey32 = (uint32_t *)S.ska;       // tiled passes: 24-bit keys over dense entity numbers

@@ -922,11 +922,13 @@ __device__ inline uint32_t pb_plan_a(const DevArgs &A, WgShared &sh, const Slot 
   const int e = ladder_first(A, sh, S, prior, np);
   if (e >= A.prm.n_ladder) return 0;
   double eps = A.prm.ladder[e];
+  bool first = true;
   if (eps > 0.0) {
     pair_pass(A, sh, S, prior, np, eps, false, mx);
     eps = *mx / 100000.0;
+    first = false;
   }
-  return pair_pass(A, sh, S, prior, np, eps, true, mx);
+  return pair_pass(A, sh, S, prior, np, eps, true, mx, first);
 }
 
 // Plan C's reduction under `prior` (the all-ones matrix left by level 1): sets sh.bestc / sh.reduced

@@ -1638,6 +1638,7 @@ extern "C" grim_stream *grim_stream_open(grim_ctx *ctx, const grim_graph *g, con
   }
   s->rule.small_ok = (n_pops == 1) && prm->opt_threshold > 1 && !getenv("GRIM_NO_SMALL") && engine_graph_order_bad(g) == 0;
   s->rule.medium_ok = !getenv("GRIM_NO_MEDIUM") && engine_graph_order_bad(g) == 0;
+  s->rule.medium_max_cost = getenv("GRIM_MEDIUM_MAXCOST") ? atof(getenv("GRIM_MEDIUM_MAXCOST")) : 0.0;
   s->rule.graph_loci = s->snap.n_loci;
   s->rule.opt_threshold = prm->opt_threshold;
   s->chunk_lines = opts->chunk_lines ? opts->chunk_lines : 131072u;
