@@ -27,16 +27,20 @@
 #include "grim_pair.h"
 
 #define MD_C 8192u                   // candidates of all sides together
-#define MD_H 1024u                   // look-up hits
+#define MD_H 768u                    // look-up hits
 #define MD_T 2048u                   // haplotypes the hits expand to
-#define MD_E 1280u                   // (haplotype, population) entries with p > 0
+#define MD_E 1024u                   // (haplotype, population) entries with p > 0
 #define MD_SEG 1024u                 // ... of one side
-#define MD_L 1024u                   // entries kept in the top lists of all sides
+#define MD_L 704u                    // entries kept in the top lists of all sides
 #define MD_NP 32768u                 // scored pairs
 #define MD_NPB (MD_NP + GRIM_MAXPH * 64u)  // bits of the pair bitmap (every phase starts a new 64-bit word)
 #define MD_ESLOTS 2048u               // slots of the entity index of the dedup (>= 2 * MD_L)
+// Four workgroups per CU (39.8 KB of LDS each, 114 VGPRs): the kernel's stages are latency, so its rate is its resident waves.
+// Measured on config 4 (gpurun_out/r4m13, r4m14), capacities cut to fit: 3 per CU (1 024 hits / 1 280 entries / 1 024 list
+// entries; 298 subjects handed on) 2.18 ms + 0.53 ms of general kernel; 4 per CU (768 / 1 024 / 704; 445 handed on) 1.70 +
+// 0.56; 5 per CU (512 / 768 / 512, 96 VGPRs; 6 099 handed on) 1.27 + 1.35.
 #ifndef GRIM_MID_WG_PER_CU
-#define GRIM_MID_WG_PER_CU 3
+#define GRIM_MID_WG_PER_CU 4
 #endif
 
 // the arena: [hits | raw entries] while the sides are built, [sort keys | raw entries] while they are ranked,
@@ -60,7 +64,7 @@
 #define MD_ARENA_B (MD_OFF_BM2 + MD_BM_BYTES)
 #define MD_ARENA ((MD_ARENA_A > MD_ARENA_B ? MD_ARENA_A : MD_ARENA_B) + 15u & ~15u)
 static_assert(8u * MD_E <= MD_OFF_ENT, "the sort keys overlay the hit arrays");
-static_assert(MD_ESLOTS >= 2u * MD_L && MD_ESLOTS <= 65535u && GRIM_TOPCAP <= 256, "entity index: load <= 1/2, 16-bit slots, 8-bit positions");
+static_assert(MD_ESLOTS >= 2u * MD_L && MD_ESLOTS <= 65535u && (MD_ESLOTS & (MD_ESLOTS - 1u)) == 0 && GRIM_TOPCAP <= 256, "entity index: load <= 1/2, 16-bit slots, 8-bit positions");
 static_assert(4u * (MD_NPB / 64u + 1u) + 64u * 16u <= 8u * MD_L, "word prefixes and the small-emit staging overlay the prefix minima");
 
 #ifdef GRIM_STAMPS  // diagnostic build: workgroup time per stage, hand-overs by reason
@@ -236,7 +240,7 @@ __device__ inline uint32_t mid_pass(const DevArgs &A, MidShared &M, const MidVie
         const uint32_t a0 = M.seg[sd], len = M.tlen[sd];
         for (uint32_t q = threadIdx.x; q < len; q += GRIM_WG) {
           const uint32_t key = M.T_e[a0 + q] | 0x80000000u;
-          uint32_t t = (key * 0x9E3779B1u) >> 21;  // 11 bits
+          uint32_t t = ((key * 0x9E3779B1u) >> 16) & (MD_ESLOTS - 1u);
           for (;;) {
             uint32_t c = __hip_atomic_load(&V.smask[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (c == 0) {
