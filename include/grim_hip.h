@@ -45,6 +45,11 @@ void grim_destroy(grim_ctx *ctx);
 const char *grim_last_error(grim_ctx *ctx);
 /* 1 if a HIP device is usable by this process, 0 otherwise (never raises). */
 int grim_device_count(void);
+/* How a stream's results come from HBM to pinned host memory on this context: the bit of the SDMA engine the downloads are
+ * pinned to (hsa_amd_sdma_engine_id_t, > 1: csrc/grim_sdma.h -- uploads stay on engine 0x1, so both directions of the link
+ * run at once), 0 = a copy kernel (GRIM_EXPORT=kernel, or no second engine on offer), -1 = hipMemcpyAsync
+ * (GRIM_EXPORT=memcpy).  The reference has no counterpart (its results are Python objects). */
+int grim_export_engine(grim_ctx *ctx);
 
 /* ---- graph: replaces Graph.build_graph's in-memory product (networkx_graph.py:42-213) ----
  * Integer-encoded: node = (label bitmask over locus slots, <=5 allele ids); a node NAME lookup

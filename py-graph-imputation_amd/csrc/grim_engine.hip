@@ -23,6 +23,7 @@
 #include "grim_tokdev.h"
 #include "grim_engine_internal.h"
 #include "grim_host_internal.h"
+#include "grim_sdma.h"
 
 // =================================================================================================
 // Plan-A kernel: one workgroup per subject, pulled from a work counter.  Waves build the phase
@@ -266,6 +267,8 @@ struct grim_ctx {
   hipStream_t stream;
   hipStream_t copy_stream;  // D2H of a finished batch while the next batch's kernels run (engine_batch_fetch_async)
   hipStream_t up_stream;    // H2D of the next batch's input while this batch's kernels run (engine_batch_load)
+  GrimSdma *sdma;           // results D2H on an SDMA engine of its own (grim_sdma.h); nullptr: export kernel / hipMemcpyAsync
+  int export_mode;          // 2 = grim_sdma, 1 = grim_export_kernel, 0 = hipMemcpyAsync on the copy stream
   // Two threads of a stream use one context at the same time (device thread: loads and launches; copy thread: waits,
   // second stages, D2H), so the error text is written and read under its own lock; grim_last_error hands out a
   // per-thread copy.  Everything else a context owns is either immutable after grim_create or guarded by run_mu.
@@ -333,6 +336,9 @@ struct grim_batch {
   uint32_t n_small, n_general, small_stride;
   uint64_t scratch_need;  // bytes of per-workgroup scratch this batch's runs need (bound at run time)
   hipEvent_t ev_copy;  // behind the D2H copy of engine_batch_fetch_issue
+  int ct_slot = -1;    // GRIM_DEBUG_COPYTIME
+  uint64_t sdma_job = 0;  // completion signal of grim_sdma copies (made on first use)
+  bool fetch_hsa = false; // the copy in flight was issued through grim_sdma
   hipEvent_t ev_up;    // behind the H2D copy of engine_batch_load: the batch's kernels wait for it
   hipEvent_t ev_done;  // recorded behind the last kernel of a stage: what engine_batch_wait waits for (not the whole stream --
                        // the device thread may have queued the next chunk's kernels behind it already)
@@ -411,7 +417,32 @@ extern "C" grim_ctx *grim_create(int device_id) {
     return nullptr;
   }
   if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) c->n_cu = prop.multiProcessorCount;
+  // how a stream's results come down: GRIM_EXPORT=sdma|kernel|memcpy (GRIM_EXPORT_KERNEL=0/1 of round 3 still means
+  // memcpy / kernel); default sdma when ROCr offers an engine besides the uploads', else the export kernel
+  c->sdma = nullptr;
+  c->export_mode = 1;
+  {
+    const char *e = getenv("GRIM_EXPORT");
+    int want = 2;
+    if (e && !strcmp(e, "kernel")) want = 1;
+    else if (e && !strcmp(e, "memcpy")) want = 0;
+    else if (!e && getenv("GRIM_EXPORT_KERNEL")) want = atoi(getenv("GRIM_EXPORT_KERNEL")) ? 1 : 0;
+    if (want == 2) {
+      char bdf[64] = {0};
+      const char *why = nullptr;
+      if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), device_id) != hipSuccess) bdf[0] = 0;
+      c->sdma = grim_sdma_open(bdf[0] ? bdf : nullptr, device_id, &why);
+      if (!c->sdma && e) fprintf(stderr, "grim: GRIM_EXPORT=sdma is not available (%s); using the export kernel\n", why ? why : "?");
+      want = c->sdma ? 2 : 1;
+    }
+    c->export_mode = want;
+  }
   return c;
+}
+
+extern "C" int grim_export_engine(grim_ctx *c) {
+  if (!c) return -1;
+  return c->export_mode == 2 ? (int)grim_sdma_engine(c->sdma) : c->export_mode == 1 ? 0 : -1;
 }
 
 static void batch_destroy(grim_batch *b);
@@ -423,6 +454,8 @@ extern "C" void grim_destroy(grim_ctx *c) {
   c->spare.clear();
   if (c->scratch) hipFree(c->scratch);
   if (c->wctr) hipFree(c->wctr);
+  if (c->sdma) grim_sdma_close(c->sdma);
+  c->sdma = nullptr;
   hipStreamDestroy(c->stream);
   if (c->copy_stream) hipStreamDestroy(c->copy_stream);
   if (c->up_stream) hipStreamDestroy(c->up_stream);
@@ -1537,16 +1570,53 @@ int engine_batch_fetch_async(grim_batch *b) { return b ? batch_fetch_on(b, 0, b-
 // the same in two halves: the copy is queued on the copy stream with an event behind it (issue), another thread waits for
 // that event (wait) -- so the thread that watches the kernels is not held up by a PCIe transfer
 static int batch_fetch_on(grim_batch *b, uint32_t res_lo, uint32_t res_hi, grim_row *rows_dst, hipStream_t st, bool wait);
+// GRIM_DEBUG_COPYTIME (diagnostic): the D2H's own duration by a pair of timing events on the copy stream
+static std::atomic<uint64_t> g_ct_ns, g_ct_n;
+static hipEvent_t g_ct_ev[2][64];
+static std::atomic<uint32_t> g_ct_k;
+static int ct_on() {
+  static const int on = [] {
+    const int v = env_int("GRIM_DEBUG_COPYTIME", 0);
+    if (v) {
+      for (int i = 0; i < 64; ++i) { (void)hipEventCreate(&g_ct_ev[0][i]); (void)hipEventCreate(&g_ct_ev[1][i]); }
+      atexit([] { if (g_ct_n.load()) fprintf(stderr, "grim: D2H on the copy stream: %.1f us average over %llu copies\n", g_ct_ns.load() / 1e3 / (double)g_ct_n.load(), (unsigned long long)g_ct_n.load()); });
+    }
+    return v;
+  }();
+  return on;
+}
 int engine_batch_fetch_issue(grim_batch *b) {
   if (!b) return -1;
+  if (ct_on()) {
+    const uint32_t k = g_ct_k.fetch_add(1) & 63;
+    b->ct_slot = (int)k;
+    (void)hipEventRecord(g_ct_ev[0][k], b->ctx->copy_stream);
+    if (batch_fetch_on(b, 0, b->n_subj, nullptr, b->ctx->copy_stream, false) != 0) return -1;
+    (void)hipEventRecord(g_ct_ev[1][k], b->ctx->copy_stream);
+    HIPCHK(hipEventRecord(b->ev_copy, b->ctx->copy_stream), b->ctx, -1);
+    return 0;
+  }
   if (batch_fetch_on(b, 0, b->n_subj, nullptr, b->ctx->copy_stream, false) != 0) return -1;
-  HIPCHK(hipEventRecord(b->ev_copy, b->ctx->copy_stream), b->ctx, -1);
+  if (!b->fetch_hsa) HIPCHK(hipEventRecord(b->ev_copy, b->ctx->copy_stream), b->ctx, -1);
   return 0;
 }
 int engine_batch_fetch_wait(grim_batch *b) {
   if (!b) return -1;
   use_device(b->ctx->device);
+  if (b->fetch_hsa) {
+    b->fetch_hsa = false;
+    if (grim_sdma_wait(b->ctx->sdma, b->sdma_job) != 0) {
+      set_err(b->ctx, "engine_batch_fetch: the SDMA copy of the results failed");
+      return -1;
+    }
+    return 0;
+  }
   HIPCHK(hipEventSynchronize(b->ev_copy), b->ctx, -1);
+  if (ct_on() && b->ct_slot >= 0) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, g_ct_ev[0][b->ct_slot], g_ct_ev[1][b->ct_slot]) == hipSuccess) { g_ct_ns += (uint64_t)(ms * 1e6); ++g_ct_n; }
+    b->ct_slot = -1;
+  }
   return 0;
 }
 static int batch_fetch_on(grim_batch *b, uint32_t res_lo, uint32_t res_hi, grim_row *rows_dst, hipStream_t st) {
@@ -1556,6 +1626,7 @@ static int batch_fetch_on(grim_batch *b, uint32_t res_lo, uint32_t res_hi, grim_
   if (!b) return -1;
   grim_ctx *c = b->ctx;
   use_device(c->device);
+  b->fetch_hsa = false;
   if (res_hi > b->n_subj) res_hi = b->n_subj;
   // the pinned landing area mirrors the out arena as far as it is used; it grows on demand
   const uint64_t need = b->off_rows + sizeof(grim_row) * (uint64_t)(rows_dst ? 0 : b->rows_used);
@@ -1577,9 +1648,15 @@ static int batch_fetch_on(grim_batch *b, uint32_t res_lo, uint32_t res_hi, grim_
   if (whole && b->off_rows - sizeof(grim_subject_result) * (uint64_t)b->n_subj < 4096) {
     // headers and rows are (nearly) back to back: one copy
     const uint64_t bytes = b->rows_used ? b->off_rows + sizeof(grim_row) * (uint64_t)b->rows_used : sizeof(grim_subject_result) * (uint64_t)b->n_subj;
-    static const int by_kernel = env_int("GRIM_EXPORT_KERNEL", 1);
     const uint64_t n16 = (bytes + 15) / 16;  // (both arenas are 256-byte granular: the last sixteen bytes exist)
-    if (bytes && by_kernel && 16 * n16 <= b->h_out_cap && 16 * n16 <= b->out_cap) {
+    if (bytes && !wait && c->export_mode == 2 && st == c->copy_stream) {
+      // an SDMA engine of our own (grim_sdma.h); the caller has waited for the kernels that wrote the arena
+      if (!b->sdma_job && grim_sdma_job_create(c->sdma, &b->sdma_job) != 0) b->sdma_job = 0;
+      if (b->sdma_job && grim_sdma_d2h_issue(c->sdma, b->sdma_job, b->h_out, b->d_out, bytes) == 0) b->fetch_hsa = true;
+    }
+    const int by_kernel = c->export_mode == 1;
+    if (b->fetch_hsa) {
+    } else if (bytes && by_kernel && 16 * n16 <= b->h_out_cap && 16 * n16 <= b->out_cap) {
       uint32_t grid = (uint32_t)((n16 + 1023) / 1024);
       if (grid > 32) grid = 32;
       hipLaunchKernelGGL(grim_export_kernel, dim3(grid), dim3(256), 0, st, (uint4 *)b->h_out, (const uint4 *)b->d_out, n16);
@@ -1623,6 +1700,7 @@ static void batch_destroy(grim_batch *b) {
     if (b->ev[i]) hipEventDestroy(b->ev[i]);
   if (b->ev_done) hipEventDestroy(b->ev_done);
   if (b->ev_copy) hipEventDestroy(b->ev_copy);
+  if (b->sdma_job && b->ctx->sdma) grim_sdma_job_destroy(b->ctx->sdma, b->sdma_job);
   if (b->ev_up) hipEventDestroy(b->ev_up);
   if (b->gexec) hipGraphExecDestroy(b->gexec);
   void *dev[] = {b->d_in, b->d_work, b->d_out, b->d_priors, b->d_pool};

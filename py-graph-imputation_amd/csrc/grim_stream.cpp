@@ -116,6 +116,7 @@ struct Chunk {
   bool in_flight = false;      // stage 1 of the whole chunk is enqueued: the copy thread waits for it
   std::vector<uint32_t> og_sorted;  // general-kernel subjects, heaviest first
   Clock::time_point t_dev0;
+  Clock::time_point tl[10];  // GRIM_DEBUG_STREAM: when the chunk passed each stage (tl_note)
   uint32_t segment = 0;        // input segment the chunk belongs to (grim_stream_segment)
   int slot_no = 0;
   grim_batch *batch = nullptr;
@@ -144,6 +145,16 @@ struct Chunk {
   uint32_t n_devtok = 0;  // lines left to the device tokenizer
   bool records_out = false, records_released = false;
 };
+
+// per-chunk stage times: slot taken, filled (dispatch), tokenised, device thread starts, launched, kernels seen done, export
+// issued, results on the host, handed to the consumer, released -- summed over the chunks between consecutive stamps
+static std::atomic<uint64_t> g_tl_ns[10];
+static std::atomic<uint64_t> g_tl_n;
+static inline void tl_note(Chunk *c, int k) { c->tl[k] = Clock::now(); }
+static void tl_close(Chunk *c) {
+  for (int k = 1; k < 10; ++k) g_tl_ns[k] += (uint64_t)(secs(c->tl[k - 1], c->tl[k]) * 1e9);
+  ++g_tl_n;
+}
 
 struct Task {
   int type;  // 0 tokenize, 1 format, 2 write
@@ -316,6 +327,7 @@ static void assemble(grim_stream *s, Chunk *c) {
   std::lock_guard<std::mutex> lk(s->mu);
   if (race_overflow) s->fail("more than 65534 distinct race pairs in one run");
   c->state = CH_TOKENIZED;
+  tl_note(c, 2);
   s->cv_dev.notify_all();
 }
 
@@ -582,6 +594,7 @@ static void device_loop(grim_stream *s) {
     }
     const auto t0 = Clock::now();
     c->t_dev0 = t0;
+    c->tl[3] = t0;
     int rc = 0;
     c->extra_rows.clear();
     c->rows = nullptr;
@@ -619,6 +632,7 @@ static void device_loop(grim_stream *s) {
         return;
       }
       c->state = CH_RUN_DONE;
+      tl_note(c, 4);
       s->copy_q.push_back(c);
       s->cv_copy.notify_all();
     }
@@ -648,6 +662,7 @@ static void copy_loop(grim_stream *s) {
       if (c->in_flight) {
         c->in_flight = false;
         const int wrc = engine_batch_wait(c->batch);
+        tl_note(c, 5);
         auto lb = [](const std::vector<uint32_t> &v, uint32_t x) { return (size_t)(std::lower_bound(v.begin(), v.end(), x) - v.begin()); };
         const size_t rng[4] = {0, lb(c->os, c->n_lines), 0, lb(c->om, c->n_lines)};
         rc = finish_part(s, c, 0, c->n_lines, true, wrc, rng, (uint32_t)c->og_sorted.size(), ps);
@@ -665,6 +680,7 @@ static void copy_loop(grim_stream *s) {
       issued = fetched_ok;
     }
     c->device_s = secs(c->t_dev0, Clock::now());
+    tl_note(c, 6);
     {
       std::lock_guard<std::mutex> lk(s->mu);
       for (int k = 0; k < 7; ++k) s->st.kernel_ms[k] += ps.kernel_ms[k];
@@ -704,6 +720,7 @@ static void fetch_loop(grim_stream *s) {
     }
     const auto t0 = Clock::now();
     const bool ok = engine_batch_fetch_wait(c->batch) == 0;
+    tl_note(c, 7);
     g_dbg_ns[3] += (uint64_t)(secs(t0, Clock::now()) * 1e9);
     {
       std::lock_guard<std::mutex> lk(s->mu);
@@ -990,6 +1007,7 @@ static Chunk *acquire_chunk(grim_stream *s) {
     for (auto &c : s->chunks)
       if (c->state == CH_FREE) {
         c->state = CH_FILLING;
+        tl_note(c.get(), 0);
         c->index = s->next_index++;
         c->first_line = s->next_line;
         c->text.clear();
@@ -1040,6 +1058,7 @@ static int dispatch(grim_stream *s, Chunk *c) {
   s->st.lines += n;
   ++s->st.chunks;
   c->state = CH_TOKENIZING;
+  tl_note(c, 1);
   c->pending.store((int)R);
   for (uint32_t r = 0; r < R; ++r) s->q_lo.push_back(Task{0, c, r});
   s->cv_work.notify_one();  // (a worker that takes a task wakes the next one while tasks are left: waking all thirty from
@@ -1523,6 +1542,7 @@ extern "C" int grim_stream_next_records(grim_stream *s, grim_stream_records *out
     Chunk *c = s->by_index(s->next_record);
     if (c && c->state >= CH_COMMITTED && !c->records_out) {
       c->records_out = true;
+      tl_note(c, 8);
       ++s->next_record;
       out->first_line = c->first_line;
       out->n_lines = c->n_lines;
@@ -1544,6 +1564,8 @@ extern "C" int grim_stream_release_records(grim_stream *s, grim_stream_records *
   Chunk *c = (Chunk *)rec->chunk;
   std::lock_guard<std::mutex> lk(s->mu);
   c->records_released = true;
+  tl_note(c, 9);
+  tl_close(c);
   rec->chunk = nullptr;
   release_if_done(s, c);
   return 0;
@@ -1746,6 +1768,12 @@ extern "C" void grim_stream_free(grim_stream *s) {
     fprintf(stderr, "grim stream: device thread ms: staging %.3f load %.3f | copy thread ms: wait + stage 2 %.3f fetch %.3f | reader ms: work %.3f "
             "(copy %.3f scan %.3f dispatch %.3f) waiting for a slot %.3f | consumer waiting %.3f over %llu chunks\n", g_dbg_ns[0] / 1e6, g_dbg_ns[1] / 1e6, g_dbg_ns[2] / 1e6,
             g_dbg_ns[3] / 1e6, g_dbg_ns[4] / 1e6, g_dbg_ns[8] / 1e6, g_dbg_ns[9] / 1e6, g_dbg_ns[7] / 1e6, g_dbg_ns[5] / 1e6, g_dbg_ns[6] / 1e6, (unsigned long long)s->st.chunks);
+  if (getenv("GRIM_DEBUG_STREAM") && g_tl_n.load()) {
+    static const char *nm[10] = {"", "fill", "tokenise", "-> device thread", "load + launch", "-> kernels done", "stage 2 + export issued", "-> on the host", "-> consumer", "consumer"};
+    fprintf(stderr, "grim stream: a chunk's way, us per chunk (%llu chunks):", (unsigned long long)g_tl_n.load());
+    for (int k = 1; k < 10; ++k) fprintf(stderr, " %s %.1f |", nm[k], g_tl_ns[k] / 1e3 / (double)g_tl_n.load());
+    fprintf(stderr, "\n");
+  }
   {
     std::lock_guard<std::mutex> lk(s->mu);
     s->stop = true;

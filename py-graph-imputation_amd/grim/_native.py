@@ -111,6 +111,8 @@ def lib():
     L = C.CDLL(LIB_PATH)
     L.grim_create.restype = C.c_void_p
     L.grim_create.argtypes = [C.c_int]
+    L.grim_export_engine.restype = C.c_int
+    L.grim_export_engine.argtypes = [C.c_void_p]
     L.grim_destroy.argtypes = [C.c_void_p]
     L.grim_last_error.restype = C.c_char_p
     L.grim_last_error.argtypes = [C.c_void_p]
@@ -142,7 +144,7 @@ def lib():
 
 
 EXPORTS = [
-    "grim_create", "grim_destroy", "grim_last_error", "grim_device_count", "grim_graph_upload", "grim_graph_free",
+    "grim_create", "grim_destroy", "grim_last_error", "grim_device_count", "grim_export_engine", "grim_graph_upload", "grim_graph_free",
     "grim_graph_device_bytes", "grim_batch_upload", "grim_batch_run", "grim_batch_kernel_ms", "grim_batch_counters",
     "grim_batch_total_rows", "grim_batch_results", "grim_batch_free", "grim_batch_set_timing", "grim_batch_run_repeat",
 ]
@@ -164,6 +166,10 @@ class Context:
 
     def error(self):
         return lib().grim_last_error(self.h).decode()
+
+    def export_engine(self):
+        """SDMA engine bit of the result downloads (> 1), 0 = copy kernel, -1 = hipMemcpyAsync (grim_export_engine)"""
+        return int(lib().grim_export_engine(self.h))
 
     def close(self):
         if self.h:

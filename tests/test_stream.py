@@ -34,13 +34,13 @@ def _imp(gname, conf):
     return imp, cfg
 
 
-def _stream_texts(imp, cfg, lines, em_mr=False, **kw):
+def _stream_texts(imp, cfg, lines, em_mr=False, ctx=None, **kw):
     """the six texts of `lines` through a stream opened with explicit options (chunk size, row pool, threads)"""
     from grim import _native as nat
 
     params = imp._params(cfg, cfg["planb"], em_mr, False)
     ps, keep = nat.prior_spec(cfg["priority"], imp.unk_priors, imp.count_by_prob)
-    ctx = nat.default_context(None)
+    ctx = ctx or nat.default_context(None)
     st = nat.Stream(ctx, imp.netGraph.device(ctx), imp.netGraph.adict, params, ps, imp.populations, **kw)
     try:
         data = ("\n".join(lines) + "\n").encode() if lines else b""
@@ -333,3 +333,39 @@ def test_one_big_write_whose_pieces_divide_evenly():
     for k in out[0]:
         assert out[0][k] == out[1][k], k
     assert out[0]["umug"].count("\n") == len(text)
+
+
+def test_results_come_down_on_their_own_sdma_engine(monkeypatch):
+    """A stream's results leave HBM on an SDMA engine the library names itself (csrc/grim_sdma.h: ROCr's
+    hsa_amd_memory_async_copy_on_engine; the HIP runtime would put uploads and downloads on engine 0 both).  The default
+    context of an MI355X box must have got one (a bit > 1: not the uploads' engine), and the two other ways down -- the copy
+    kernel of round 3 (GRIM_EXPORT=kernel) and hipMemcpyAsync (GRIM_EXPORT=memcpy) -- must give the same six files, small
+    chunks and one big chunk, and the same records."""
+    from grim import _native as nat
+
+    rows = synth.read_freqs(synth.CAU_FREQS)
+    gen = synth.SubjectGen(rows, 4242)
+    lines = gen.full(6000) + gen.mixed(600, amb=0.3, miss=0.3, recomb=0.2)
+    conf = harness.base_conf(["CAU"])
+    imp, cfg = _imp("cau", conf)
+    assert nat.default_context(None).export_engine() > 1
+    base_small, _, _ = _stream_texts(imp, cfg, lines, chunk_lines=900, n_threads=3, depth=3)
+    base_big, _, _ = _stream_texts(imp, cfg, lines, n_threads=4)
+    for mode, engine in (("kernel", 0), ("memcpy", -1), ("sdma", None)):
+        monkeypatch.setenv("GRIM_EXPORT", mode)
+        ctx = nat.Context(0)
+        try:
+            assert ctx.export_engine() == engine if engine is not None else ctx.export_engine() > 1
+            small, _, _ = _stream_texts(imp, cfg, lines, ctx=ctx, chunk_lines=900, n_threads=3, depth=3)
+            big, _, _ = _stream_texts(imp, cfg, lines, ctx=ctx, n_threads=4)
+        finally:
+            dg = imp.netGraph._dev.pop(id(ctx), None)  # the graph's HBM copy on this context goes before the context does
+            if dg is not None:
+                dg.close()
+            ctx.close()
+        for k in nat.TEXT_KEYS:
+            assert small[k] == base_small[k], (mode, k)
+            assert big[k] == base_big[k], (mode, k)
+    monkeypatch.delenv("GRIM_EXPORT", raising=False)
+    for k in nat.TEXT_KEYS:
+        assert base_small[k] == base_big[k], k
