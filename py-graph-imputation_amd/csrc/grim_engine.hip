@@ -339,6 +339,7 @@ struct grim_batch {
   int ct_slot = -1;    // GRIM_DEBUG_COPYTIME
   uint64_t sdma_job = 0;  // completion signal of grim_sdma copies (made on first use)
   bool fetch_hsa = false; // the copy in flight was issued through grim_sdma
+  bool up_pending = false; // an input copy is on the upload stream and the launch stream has not been ordered behind it yet
   hipEvent_t ev_up;    // behind the H2D copy of engine_batch_load: the batch's kernels wait for it
   hipEvent_t ev_done;  // recorded behind the last kernel of a stage: what engine_batch_wait waits for (not the whole stream --
                        // the device thread may have queued the next chunk's kernels behind it already)
@@ -1044,7 +1045,7 @@ int engine_batch_load(grim_batch *b, const EngineLoad *ld) {
   // launch stream waits for it (the batch's buffers are its own: nothing else orders the two streams)
   HIPCHK(hipMemcpyAsync(b->d_in, b->h_in, bytes, hipMemcpyHostToDevice, c->up_stream), c, -1);
   HIPCHK(hipEventRecord(b->ev_up, c->up_stream), c, -1);
-  HIPCHK(hipStreamWaitEvent(st, b->ev_up, 0), c, -1);
+  b->up_pending = true;  // engine_batch_enqueue orders the launch stream behind it (or finds it done)
   g_moved[0] += bytes;
   {
     // arena of the table kernels: a pair pool of 512 records per subject that can reach them directly, a few for the
@@ -1354,6 +1355,15 @@ extern "C" int grim_batch_set_timing(grim_batch *b, int on) {
 // general kernel, finish kernel) behind whatever the context's stream holds and returns at once; engine_batch_wait waits for
 // that stage, launches stage 2 (Plan B / C, the table kernels) when the state block says subjects or accepted pairs are
 // waiting, and returns what grim_batch_run returns.  The two may be called from different threads (one after the other).
+// has the input copy of the last engine_batch_load arrived?  (any thread; never blocks)
+int engine_batch_upload_done(grim_batch *b) {
+  if (!b || !b->up_pending) return 1;
+  use_device(b->ctx->device);
+  if (hipEventQuery(b->ev_up) == hipSuccess) return 1;
+  (void)hipGetLastError();
+  return 0;
+}
+
 int engine_batch_enqueue(grim_batch *b) {
   if (!b) return -1;
   grim_ctx *c = b->ctx;
@@ -1367,6 +1377,17 @@ int engine_batch_enqueue(grim_batch *b) {
   b->ms_s = b->ms_a = b->ms_g = b->ms_m = b->ms_t = b->ms_c = b->ms_b = b->ms_k = b->ms_d = 0;
   std::lock_guard<std::mutex> lk(c->run_mu);
   if (bind_scratch(b) != 0) return -1;
+  if (b->up_pending) {
+    // The batch's input went up on the upload stream.  A wait for its event in the launch stream costs the stream ~9 us
+    // (a barrier packet on a signal of another queue: 46 -> 55 us per four 10-us kernels, profiles/r4_notes.md); when the
+    // copy is over already -- the stream pipeline launches a chunk after it has sent the NEXT chunk's input up -- the
+    // host has seen so and a launch from here on is ordered behind it without any packet.
+    b->up_pending = false;
+    if (hipEventQuery(b->ev_up) != hipSuccess) {
+      (void)hipGetLastError();
+      HIPCHK(hipStreamWaitEvent(c->stream, b->ev_up, 0), c, -1);
+    }
+  }
   if (b->timing) {
     if (enqueue_stage1(b, true) != 0) {
       set_err(c, "grim_batch_run: kernel launch failed");

@@ -63,6 +63,7 @@ int engine_batch_fetch_wait(grim_batch *b);
 // a run in two halves (grim_batch_run = enqueue + wait): stage 1 is launched behind whatever the context's stream holds and
 // the call returns; engine_batch_wait (any thread, after enqueue returned) waits for it, runs stage 2 when the run state
 // asks for it and returns grim_batch_run's code (0, -1, -2 = a pool overflowed)
+int engine_batch_upload_done(grim_batch *b);  // the H2D copy of the last load is over (never blocks)
 int engine_batch_enqueue(grim_batch *b);
 int engine_batch_wait(grim_batch *b);
 // device form of the allele dictionary (grim_tok.h), built once per stream from the frozen snapshot the host tokenizer

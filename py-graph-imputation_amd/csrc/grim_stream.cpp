@@ -579,7 +579,36 @@ static int device_part_sync(grim_stream *s, Chunk *c, uint32_t lo, uint32_t hi, 
 
 static void enqueue_format(grim_stream *s, Chunk *c);
 
+// The device thread.  A chunk's input goes up as soon as the chunk is tokenised; its kernels are launched when the copy has
+// arrived -- the thread watches it: the kernels could not start earlier anyway -- or, when another chunk turns up first, after
+// that chunk's input has been sent up as well.  Either way the host has seen the upload finish before it launches, and the
+// launch stream needs no wait for the upload stream's event (engine_batch_enqueue): that wait, a barrier packet on another
+// queue's signal, costs the launch stream ~9 us per chunk (profiles/r4_notes.md).  Chunks reach the copy thread in input order.
 static void device_loop(grim_stream *s) {
+  static const bool eager = getenv("GRIM_EAGER_LAUNCH") && atoi(getenv("GRIM_EAGER_LAUNCH"));  // test switch: launch at once
+  Chunk *loaded = nullptr;  // input sent up, kernels not launched yet
+  auto launch = [&](Chunk *c, int rc) -> bool {  // kernels of a loaded chunk, then on to the copy thread
+    const auto t0 = Clock::now();
+    if (rc == 0 && c->n_dev_subjects) {
+      rc = engine_batch_enqueue(c->batch);
+      if (rc == 0) c->in_flight = true;
+      else if (rc == -2) rc = 0;  // a pool too small before anything ran: the copy thread sorts it out (in_flight stays false)
+    }
+    const double busy = secs(t0, Clock::now());
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->st.device_s += busy;
+    s->st.subjects += c->n_dev_subjects;
+    if (rc != 0) {
+      const char *e = grim_last_error(s->ctx);
+      s->fail(std::string("device stage failed: ") + (e ? e : ""));
+      return false;
+    }
+    c->state = CH_RUN_DONE;
+    tl_note(c, 4);
+    s->copy_q.push_back(c);
+    s->cv_copy.notify_all();
+    return true;
+  };
   for (;;) {
     Chunk *c = nullptr;
     {
@@ -589,52 +618,74 @@ static void device_loop(grim_stream *s) {
         c = s->by_index(s->next_device);
         if (c && c->state == CH_TOKENIZED) break;
         c = nullptr;
+        if (loaded) break;  // nothing else is ready: see to the chunk that is loaded
         s->cv_dev.wait(lk);
       }
+      if (c) ++s->next_device;
     }
-    const auto t0 = Clock::now();
-    c->t_dev0 = t0;
-    c->tl[3] = t0;
-    int rc = 0;
-    c->extra_rows.clear();
-    c->rows = nullptr;
-    c->fetch_pending = false;
-    c->in_flight = false;
-    if (c->n_dev_subjects) {
-      // longest-processing-time-first for the general kernel; stable: equal-cost subjects stay in input order
-      const std::vector<uint32_t> &og = c->og;
-      const grim_subject *subj = engine_batch_host(c->batch)->subj;
-      std::vector<double> cost(og.size());
-      for (size_t k = 0; k < og.size(); ++k) cost[k] = grim_cost(subj[og[k]]);
-      std::vector<uint32_t> perm(og.size());
-      for (size_t k = 0; k < perm.size(); ++k) perm[k] = (uint32_t)k;
-      std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
-      c->og_sorted.resize(og.size());
-      for (size_t k = 0; k < perm.size(); ++k) c->og_sorted[k] = og[perm[k]];
-      size_t rng[4];
-      uint32_t ng = 0;
-      rc = stage_part(s, c, 0, c->n_lines, rng, ng);
-      if (rc == 0) {
-        rc = engine_batch_enqueue(c->batch);
-        if (rc == 0) c->in_flight = true;
-        else if (rc == -2) rc = 0;  // a pool too small before anything ran: the copy thread sorts it out (in_flight stays false)
+    if (!c && loaded && !eager) {
+      // watch the copy (tens of microseconds) and the queue; whichever comes first -- the copy done: launch; another chunk
+      // tokenised: send that one's input up first
+      const auto w0 = Clock::now();
+      for (int spin = 0;; ++spin) {
+        if (engine_batch_upload_done(loaded->batch)) break;
+        if ((spin & 7) == 7) {
+          if (secs(w0, Clock::now()) > 200e-6) break;  // (a copy that takes this long: let the launch stream wait for it)
+          std::unique_lock<std::mutex> lk(s->mu, std::try_to_lock);
+          if (lk.owns_lock()) {
+            if (s->stop || s->failed) return;
+            Chunk *n = s->by_index(s->next_device);
+            if (n && n->state == CH_TOKENIZED) {
+              c = n;
+              ++s->next_device;
+              break;
+            }
+          }
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
       }
     }
-    const double busy = secs(t0, Clock::now());
-    {
+    int rc = 0;
+    if (c) {
+      const auto t0 = Clock::now();
+      c->t_dev0 = t0;
+      c->tl[3] = t0;
+      c->extra_rows.clear();
+      c->rows = nullptr;
+      c->fetch_pending = false;
+      c->in_flight = false;
+      if (c->n_dev_subjects) {
+        // longest-processing-time-first for the general kernel; stable: equal-cost subjects stay in input order
+        const std::vector<uint32_t> &og = c->og;
+        const grim_subject *subj = engine_batch_host(c->batch)->subj;
+        std::vector<double> cost(og.size());
+        for (size_t k = 0; k < og.size(); ++k) cost[k] = grim_cost(subj[og[k]]);
+        std::vector<uint32_t> perm(og.size());
+        for (size_t k = 0; k < perm.size(); ++k) perm[k] = (uint32_t)k;
+        std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+        c->og_sorted.resize(og.size());
+        for (size_t k = 0; k < perm.size(); ++k) c->og_sorted[k] = og[perm[k]];
+        size_t rng[4];
+        uint32_t ng = 0;
+        rc = stage_part(s, c, 0, c->n_lines, rng, ng);  // (ends with engine_batch_load: the H2D copy on the upload stream)
+      }
+      const double busy = secs(t0, Clock::now());
       std::lock_guard<std::mutex> lk(s->mu);
       s->st.device_s += busy;
-      s->st.subjects += c->n_dev_subjects;
-      ++s->next_device;
-      if (rc != 0) {
-        const char *e = grim_last_error(s->ctx);
-        s->fail(std::string("device stage failed: ") + (e ? e : ""));
+    }
+    if (loaded) {
+      Chunk *l = loaded;
+      loaded = nullptr;
+      if (!launch(l, 0)) return;
+    }
+    if (c) {
+      if (c->n_dev_subjects && rc == 0) {
+        loaded = c;
+      } else if (!launch(c, rc)) {  // nothing for the device (or a failed load: reported there)
         return;
       }
-      c->state = CH_RUN_DONE;
-      tl_note(c, 4);
-      s->copy_q.push_back(c);
-      s->cv_copy.notify_all();
     }
   }
 }
