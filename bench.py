@@ -423,6 +423,8 @@ def main():
                                 "back-to-back regions (barrier + drained pipeline on both sides of each)" % (chunks_per_step, chunk_lines, args.depth),
                 "host_threads": int(os.environ.get("GRIM_HOST_THREADS", "0")) or int(nat.host_lib().grim_default_threads()),
                 "stream_cpu_s": {"tokenize": sstats.tokenize_cpu_s, "device_thread_busy": sstats.device_s},
+                "results_download": (lambda e: "SDMA engine 0x%x named through ROCr (csrc/grim_sdma.h); uploads on the HIP runtime's engine" % e
+                                     if e > 1 else "copy kernel (grim_export_kernel)" if e == 0 else "hipMemcpyAsync")(ctx.export_engine()),
             },
             "kernel_only": {
                 "subjects_per_s": len(subj) / (all_ms * 1e-3) if all_ms > 0 else None,

@@ -34,7 +34,7 @@ if os.path.exists(ko):
         lines = [l for l in open(log) if l.startswith("{")]
         if lines:
             open(os.path.join(dst, "%s_config2_kernel_only.json" % tag), "w").write(lines[-1])
-for w in ("config2", "config4", "config5"):
+for w in ("config2", "config2_steps20", "config3", "config4", "config5"):
     bj = os.path.join(src, "bench_%s.json" % w)
     if os.path.exists(bj):
         lines = [l for l in open(bj) if l.startswith("{")]

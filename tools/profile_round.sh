@@ -17,7 +17,9 @@ run() {  # name, rocprof options, bench options
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/config2_kernel_only -o r -- python3 $R/tools/kernel_only.py --workload config2 --runs 300 > $O/config2_kernel_only.log 2>&1
 [ "${ONLY_KERNEL_ONLY:-0}" = "1" ] && exit 0
 # the bench lines of the same build (full JSON with roofline), unprofiled
-for w in config2 config4 config5; do python3 $R/bench.py --workload $w --no-file --no-cpu-baseline > $O/bench_$w.json 2> $O/bench_$w.err || true; done
+for w in config2 config3 config4 config5; do python3 $R/bench.py --workload $w --no-file --no-cpu-baseline > $O/bench_$w.json 2> $O/bench_$w.err || true; done
+# ... and the driver's own invocation (20 steps per timed region: the pipeline's fill and drain weigh more)
+python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-file --no-cpu-baseline > $O/bench_config2_steps20.json 2> $O/bench_config2_steps20.err || true
 run config2        "--kernel-trace --stats" "--steps 50 --warmup 5 $B"
 run config2_fetch  "--pmc FETCH_SIZE --kernel-trace" "--steps 10 --warmup 2 --kernel-steps 10 $B"
 run config2_write  "--pmc WRITE_SIZE --kernel-trace" "--steps 10 --warmup 2 --kernel-steps 10 $B"
