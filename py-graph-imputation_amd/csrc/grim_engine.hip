@@ -1721,6 +1721,7 @@ static void batch_destroy(grim_batch *b) {
     if (b->ev[i]) hipEventDestroy(b->ev[i]);
   if (b->ev_done) hipEventDestroy(b->ev_done);
   if (b->ev_copy) hipEventDestroy(b->ev_copy);
+  if (b->fetch_hsa && b->ctx->sdma) (void)grim_sdma_wait(b->ctx->sdma, b->sdma_job);  // (an abandoned stream: the copy still writes h_out)
   if (b->sdma_job && b->ctx->sdma) grim_sdma_job_destroy(b->ctx->sdma, b->sdma_job);
   if (b->ev_up) hipEventDestroy(b->ev_up);
   if (b->gexec) hipGraphExecDestroy(b->gexec);
