@@ -433,6 +433,25 @@ extern "C" grim_ctx *grim_create(int device_id) {
       const char *why = nullptr;
       if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), device_id) != hipSuccess) bdf[0] = 0;
       c->sdma = grim_sdma_open(bdf[0] ? bdf : nullptr, device_id, &why);
+      if (c->sdma) {
+        // the engine by measurement (grim_sdma_pick: a chunk's worth of results down on every engine on offer, ~1 ms)
+        const size_t probe = 1500000;
+        void *hp = nullptr, *dp = nullptr;
+        char report[256];
+        uint32_t got = 0;
+        if (hipHostMalloc(&hp, probe, hipHostMallocDefault) == hipSuccess && hipMalloc(&dp, probe) == hipSuccess &&
+            hipMemset(dp, 0, probe) == hipSuccess && hipDeviceSynchronize() == hipSuccess)
+          got = grim_sdma_pick(c->sdma, hp, dp, probe, report, sizeof(report));
+        (void)hipGetLastError();
+        if (dp) (void)hipFree(dp);
+        if (hp) (void)hipHostFree(hp);
+        if (getenv("GRIM_DEBUG_STREAM")) fprintf(stderr, "grim: SDMA engines for the downloads: %s -> 0x%x\n", got ? report : "none worked", got);
+        if (!got) {
+          why = "no SDMA engine completed a test copy";
+          grim_sdma_close(c->sdma);
+          c->sdma = nullptr;
+        }
+      }
       if (!c->sdma && e) fprintf(stderr, "grim: GRIM_EXPORT=sdma is not available (%s); using the export kernel\n", why ? why : "?");
       want = c->sdma ? 2 : 1;
     }

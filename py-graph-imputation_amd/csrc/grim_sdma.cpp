@@ -13,6 +13,8 @@ struct GrimSdma {
   hsa_agent_t gpu, cpu;
   hsa_amd_sdma_engine_id_t engine;
   uint64_t spin_ticks;  // ~100 us of the signal clock
+  uint32_t rec, avail;  // ROCr's recommended / available engines for device -> host at open time
+  bool pinned_by_env;
 };
 
 namespace {
@@ -72,7 +74,13 @@ GrimSdma *grim_sdma_open(const char *hip_pci_bus_id, int hip_device_ordinal, con
   if (hsa_amd_memory_copy_engine_status(s->cpu, s->gpu, &avail) != HSA_STATUS_SUCCESS) avail = 0;
   uint32_t pick = rec & ~1u;
   if (!pick) pick = avail & ~1u;
-  if (const char *e = getenv("GRIM_SDMA_ENGINE")) pick = (uint32_t)strtoul(e, nullptr, 0);
+  s->rec = rec;
+  s->avail = avail;
+  s->pinned_by_env = false;
+  if (const char *e = getenv("GRIM_SDMA_ENGINE")) {
+    pick = (uint32_t)strtoul(e, nullptr, 0);
+    s->pinned_by_env = true;
+  }
   if (!pick) {
     *why = "no SDMA engine besides engine 0";
     delete s;
@@ -93,6 +101,57 @@ void grim_sdma_close(GrimSdma *s) {
 }
 
 uint32_t grim_sdma_engine(const GrimSdma *s) { return s ? (uint32_t)s->engine : 0; }
+
+uint32_t grim_sdma_pick(GrimSdma *s, void *dst_host, const void *src_dev, size_t bytes, char *report, size_t report_len) {
+  if (!s) return 0;
+  if (report && report_len) report[0] = 0;
+  if (s->pinned_by_env) return (uint32_t)s->engine;
+  uint64_t job = 0;
+  if (grim_sdma_job_create(s, &job) != 0) return (uint32_t)s->engine;
+  uint64_t hz = 0;
+  if (hsa_system_get_info(HSA_SYSTEM_INFO_TIMESTAMP_FREQUENCY, &hz) != HSA_STATUS_SUCCESS || !hz) hz = 100000000ull;
+  auto now = [] {
+    uint64_t t = 0;
+    hsa_system_get_info(HSA_SYSTEM_INFO_TIMESTAMP, &t);
+    return t;
+  };
+  const hsa_amd_sdma_engine_id_t before = s->engine;
+  uint32_t cand = (s->avail ? s->avail : s->rec) & 0xFEu;  // engines 1-7 (the ones beyond are no faster over PCIe: 160-220 us)
+  if (!cand) cand = (uint32_t)before;
+  double best = 0, t_of[16];
+  uint32_t best_e = 0;
+  size_t used = 0;
+  for (int k = 0; k < 16; ++k) {
+    t_of[k] = 0;
+    const uint32_t e = 1u << k;
+    if (!(cand & e)) continue;
+    s->engine = (hsa_amd_sdma_engine_id_t)e;
+    bool ok = grim_sdma_d2h_issue(s, job, dst_host, src_dev, bytes) == 0 && grim_sdma_wait(s, job) == 0;  // (the first copy on an engine sets its queue up)
+    double fastest = 0;
+    for (int r = 0; r < 3 && ok; ++r) {
+      const uint64_t t0 = now();
+      ok = grim_sdma_d2h_issue(s, job, dst_host, src_dev, bytes) == 0 && grim_sdma_wait(s, job) == 0;
+      const double us = (double)(now() - t0) * 1e6 / (double)hz;
+      if (ok && (fastest == 0 || us < fastest)) fastest = us;
+    }
+    if (!ok || fastest == 0) continue;
+    t_of[k] = fastest;
+    if (report && used + 24 < report_len) used += (size_t)snprintf(report + used, report_len - used, "%s0x%x %.0f us", used ? ", " : "", e, fastest);
+    if (best == 0 || fastest < best) {
+      best = fastest;
+      best_e = e;
+    }
+  }
+  // ROCr's recommended engines first among those within a quarter of the fastest
+  uint32_t pick = 0;
+  for (int pass = 0; pass < 2 && !pick; ++pass)
+    for (int k = 0; k < 16 && !pick; ++k)
+      if (t_of[k] > 0 && t_of[k] <= 1.25 * best && (pass == 1 || (s->rec & (1u << k)))) pick = 1u << k;
+  if (!pick) pick = best_e;
+  grim_sdma_job_destroy(s, job);
+  s->engine = pick ? (hsa_amd_sdma_engine_id_t)pick : before;
+  return pick;
+}
 
 int grim_sdma_job_create(GrimSdma *s, uint64_t *job) {
   if (!s || !job) return -1;

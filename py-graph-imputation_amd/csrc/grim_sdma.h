@@ -23,6 +23,13 @@ struct GrimSdma;
 GrimSdma *grim_sdma_open(const char *hip_pci_bus_id, int hip_device_ordinal, const char **why);
 void grim_sdma_close(GrimSdma *s);
 uint32_t grim_sdma_engine(const GrimSdma *s);  // the engine's bit (hsa_amd_sdma_engine_id_t)
+// Chooses the engine by MEASUREMENT: a few copies of `bytes` from `src_dev` to `dst_host` on every engine on offer except
+// engine 0, the fastest wins (ROCr's recommended engines first among equals).  Why: an engine can be slow for reasons nobody
+// reports -- on MI355X engines 4-7 move 11 GB/s over PCIe where engines 0-3 move 40, and engine 1, the recommended one, drops
+// to 9 GB/s for every later process once some process has allocated and freed tens of GB (profiles/r4_notes.md,
+// tools/microbench/sdma_engines.hip).  Returns the engine's bit, 0 when no copy worked (the caller keeps another way).
+// `report` (optional) gets one line of the timings.  GRIM_SDMA_ENGINE pins the choice and skips the measurement.
+uint32_t grim_sdma_pick(GrimSdma *s, void *dst_host, const void *src_dev, size_t bytes, char *report, size_t report_len);
 
 // one job = one completion signal, reused
 int grim_sdma_job_create(GrimSdma *s, uint64_t *job);
