@@ -147,6 +147,8 @@ def main():
     ap.add_argument("--workload", default="config2", choices=sorted(WORKLOADS) + ["full"])
     ap.add_argument("--subjects", type=int, default=0, help="subjects per step and GPU (default: the workload's size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--copy-input", action="store_true", help="the stream copies the GL strings it is given (grim_stream_write) instead of reading "
+                    "them where they are (grim_stream_write_borrowed: the default here -- the strings are in memory for the whole run)")
     ap.add_argument("--no-file", action="store_true", help="skip the file -> file leg")
     ap.add_argument("--file-subjects", type=int, default=1000000, help="lines of the file -> file leg (config 2/3: 1M = config 3's file)")
     ap.add_argument("--cpu-workers", type=int, default=8, help="processes of the CPU baseline (cpu_baseline.cores)")
@@ -284,7 +286,7 @@ def main():
                     break
                 # one call per region (the way a file comes in: big blocks): the library cuts the text into steps of
                 # chunk_lines lines itself, and this thread does not compete for the interpreter with the consumer
-                st.write(region_text if n == args.steps else text * n)
+                st.write(region_text if n == args.steps else text * n, borrowed=not args.copy_input)
             st.finish()
         except Exception as e:  # pragma: no cover
             feed_err.append(e)
@@ -417,6 +419,7 @@ def main():
                                     "; %d subjects per step and GPU" % n_step),
                 "subjects_per_step_per_gpu": n_step, "subjects_with_results_per_step": n_ok_per_step, "ranks": ranks_seen,
                 "graph_nodes": int(graph.arrays["n_nodes"]), "populations": P,
+                "input": "copied by the stream (grim_stream_write)" if args.copy_input else "lent to the stream (grim_stream_write_borrowed): the tokenizer threads read the strings where they lie",
                 "timed_region": "host GL strings in memory -> grim_stream (tokenizer threads, pinned staging, H2D, kernels, D2H) -> "
                                 "result records in pinned host memory, read by the caller; %d device batch(es) of %d lines per step, "
                                 "%d in flight; value = subjects of one region of --steps steps / the MEDIAN region time over `repeats` "

@@ -349,6 +349,11 @@ grim_stream *grim_stream_open(grim_ctx *ctx, const grim_graph *g, const grim_dic
                               const grim_prior_spec *priors, const char *const *pop_names, uint32_t n_pops,
                               const grim_stream_opts *opts);
 int grim_stream_write(grim_stream *s, const char *text, uint64_t len);
+/* The same, but the caller LENDS the bytes instead of having them copied: they must stay valid and unchanged until
+ * grim_stream_finish has returned (or the stream is freed).  Chunks that begin inside the buffer read their lines where
+ * they lie ('\n' line ends only).  For a caller that holds its input in memory anyway (a mapped file, a buffer it owns):
+ * the reference's counterpart is the file object impute_file reads from (impute.py:2019-2027). */
+int grim_stream_write_borrowed(grim_stream *s, const char *text, uint64_t len);
 /* the same with universal newlines, as Python's open(): "\r\n" and "\r" end a line too (a "\r\n" may straddle two calls) */
 int grim_stream_write_text(grim_stream *s, const char *text, uint64_t len);
 /* reads the file in blocks and feeds it through grim_stream_write_text */

@@ -77,26 +77,52 @@ struct StreamRaces : RaceResolver {  // race pair -> prior matrix, shared by eve
 // a chunk's text: a growable byte buffer that can be enlarged WITHOUT touching the new bytes (std::string::resize would
 // zero a megabyte per chunk just to have it overwritten)
 struct TextBuf {
-  char *p = nullptr;
-  size_t n = 0, cap = 0;
+  char *p = nullptr;      // the bytes: own_p, or memory of the caller's (a view)
+  size_t n = 0, cap = 0;  // cap: of own_p
+  char *own_p = nullptr;  // the buffer's own allocation: kept while the buffer is a view, used again afterwards
+  // A VIEW (grim_stream_write_borrowed): the chunk's lines lie in a buffer the caller lends the stream until it is finished,
+  // and nobody copies them before the tokenizer threads read them.  Never written, never freed; anything that wants to add
+  // bytes takes a copy first (own()).
+  bool view = false;
   TextBuf() {}
   TextBuf(const TextBuf &) = delete;
   TextBuf &operator=(const TextBuf &) = delete;
-  ~TextBuf() { free(p); }
+  ~TextBuf() { free(own_p); }
   const char *data() const { return p; }
   char *data() { return p; }
   size_t size() const { return n; }
   bool empty() const { return n == 0; }
   char back() const { return p[n - 1]; }
-  void clear() { n = 0; }
-  void reserve(size_t want) {
+  void clear() {
+    p = own_p;
+    n = 0;
+    view = false;
+  }
+  void set_view(const char *q, size_t k) {
+    p = const_cast<char *>(q);
+    n = k;
+    view = true;
+  }
+  void grow(size_t want) {
     if (want <= cap) return;
     size_t c = cap ? cap : (1u << 16);
     while (c < want) c *= 2;
-    char *q = (char *)realloc(p, c);
+    char *q = (char *)realloc(own_p, c);
     if (!q) throw std::bad_alloc();
-    p = q;
+    own_p = q;
     cap = c;
+  }
+  void own() {  // a view becomes a copy
+    if (!view) return;
+    grow(n);
+    if (n) memcpy(own_p, p, n);
+    p = own_p;
+    view = false;
+  }
+  void reserve(size_t want) {
+    own();
+    grow(want);
+    p = own_p;
   }
   void resize(size_t want) {  // new bytes are NOT initialised
     reserve(want);
@@ -988,11 +1014,31 @@ __attribute__((target("avx2"))) static uint32_t copy_and_mark_avx2(char *dst, co
   return k;
 }
 #endif
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) static uint32_t scan_and_mark_avx2(const char *src, size_t n, uint32_t *nl) {  // the same, nothing copied
+  const __m256i nlv = _mm256_set1_epi8('\n');
+  uint32_t k = 0;
+  size_t i = 0;
+  for (; i + 32 <= n; i += 32) {
+    const __m256i v = _mm256_loadu_si256((const __m256i *)(src + i));
+    for (uint32_t m = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v, nlv)); m; m &= m - 1) nl[k++] = (uint32_t)i + (uint32_t)__builtin_ctz(m);
+  }
+  for (; i < n; ++i)
+    if (src[i] == '\n') nl[k++] = (uint32_t)i;
+  return k;
+}
+#endif
 static uint32_t copy_and_mark(char *dst, const char *src, size_t n, uint32_t *nl) {
 #if defined(__x86_64__)
   static const bool avx2 = __builtin_cpu_supports("avx2");
-  if (avx2) return copy_and_mark_avx2(dst, src, n, nl);
+  if (avx2) return dst ? copy_and_mark_avx2(dst, src, n, nl) : scan_and_mark_avx2(src, n, nl);
 #endif
+  if (!dst) {
+    uint32_t k = 0;
+    for (size_t i = 0; i < n; ++i)
+      if (src[i] == '\n') nl[k++] = (uint32_t)i;
+    return k;
+  }
   uint32_t k = 0;
   for (size_t i = 0; i < n; ++i) {
     dst[i] = src[i];
@@ -1274,7 +1320,16 @@ extern "C" int64_t grim_chunk_offsets(const char *path, uint32_t chunk_lines, ui
 }
 extern "C" void grim_free(void *p) { free(p); }
 
-extern "C" int grim_stream_write(grim_stream *s, const char *text, uint64_t len) {
+static int stream_write(grim_stream *s, const char *text, uint64_t len, bool borrowed);
+extern "C" int grim_stream_write(grim_stream *s, const char *text, uint64_t len) { return stream_write(s, text, len, false); }
+// The caller LENDS the bytes: they stay where they are, valid and unchanged, until grim_stream_finish has returned (or the
+// stream is freed).  A chunk that begins inside such a buffer is a view of it: the reader and its helpers only find the line
+// ends (a read of the cold bytes instead of a read and a write), the tokenizer threads read the lines where they lie.
+extern "C" int grim_stream_write_borrowed(grim_stream *s, const char *text, uint64_t len) {
+  static const bool off = getenv("GRIM_NO_BORROW") && atoi(getenv("GRIM_NO_BORROW"));  // test switch: copy after all
+  return stream_write(s, text, len, !off);
+}
+static int stream_write(grim_stream *s, const char *text, uint64_t len, bool borrowed) {
   if (!s || s->input_closed) return -1;
   uint64_t a = 0;
   while (a < len) {
@@ -1299,7 +1354,8 @@ extern "C" int grim_stream_write(grim_stream *s, const char *text, uint64_t len)
     uint32_t got = 0;
     if (remaining >= (256u << 10) && !s->copiers.empty()) {
       blk = std::min<uint64_t>(remaining, (uint64_t)want * s->avg_line + 4096);
-      c->text.resize(base + blk);
+      const bool as_view = borrowed && base == 0 && c->n_lines == 0;  // the chunk begins here: its lines stay in the caller's buffer
+      if (!as_view) c->text.resize(base + blk);
       // pieces of ~48 KB (whole cache lines), at least one per thread
       const size_t nh = s->copiers.size();
       size_t parts = std::min<size_t>(COPY_PIECES, std::max<size_t>(nh + 1, (size_t)(blk / (48u << 10))));
@@ -1314,7 +1370,7 @@ extern "C" int grim_stream_write(grim_stream *s, const char *text, uint64_t len)
           const size_t o = std::min<size_t>(blk, k * per), e = std::min<size_t>(blk, (k + 1) * per);
           grim_stream::CopyJob &j = s->copy_jobs[k];
           j.src = text + a + o;
-          j.dst = c->text.data() + base + o;
+          j.dst = as_view ? nullptr : c->text.data() + base + o;
           j.n = e - o;
           j.n_nl = 0;
           if (j.nl.size() < j.n + 64) j.nl.resize(j.n + 64);
@@ -1349,7 +1405,8 @@ extern "C" int grim_stream_write(grim_stream *s, const char *text, uint64_t len)
           full = true;
         }
       }
-      c->text.resize(base + used);
+      if (as_view) c->text.set_view(text + a, used);
+      else c->text.resize(base + used);
       g_dbg_ns[9] += (uint64_t)(secs(tr2, Clock::now()) * 1e9);
     } else {
       blk = std::min<uint64_t>(remaining, 64u << 10);

@@ -311,7 +311,7 @@ EXPORTS += [
     "grim_parsed_subject_array", "grim_parsed_tokens", "grim_parsed_kinds", "grim_parsed_dev_index",
     "grim_parsed_n_races", "grim_parsed_race", "grim_parsed_id", "grim_parsed_set_kind", "grim_parsed_set_flags", "grim_format", "grim_text_get", "grim_text_free",
     "grim_format_double", "grim_hostgraph_load_csv", "grim_hostgraph_desc", "grim_hostgraph_free", "grim_graphgen_csv", "grim_hostgraph_from_hpf",
-    "grim_parsed_allele", "grim_prior_matrix", "grim_stream_open", "grim_stream_write", "grim_stream_write_file", "grim_stream_finish",
+    "grim_parsed_allele", "grim_prior_matrix", "grim_stream_open", "grim_stream_write", "grim_stream_write_borrowed", "grim_stream_write_file", "grim_stream_finish",
     "grim_stream_error", "grim_stream_text", "grim_stream_get_stats", "grim_stream_n_unsupported", "grim_stream_unsupported",
     "grim_stream_next_records", "grim_stream_release_records", "grim_stream_free", "grim_stream_write_text",
     "grim_stream_segment", "grim_stream_n_segments", "grim_stream_segment_end", "grim_stream_segment_wait", "grim_stream_segment_place", "grim_default_threads", "grim_chunk_offsets", "grim_free",
@@ -415,6 +415,8 @@ def host_lib():
                                    C.c_uint32, C.POINTER(StreamOpts)]
     L.grim_stream_write.restype = C.c_int
     L.grim_stream_write.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64]
+    L.grim_stream_write_borrowed.restype = C.c_int
+    L.grim_stream_write_borrowed.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64]
     L.grim_stream_write_file.restype = C.c_int
     L.grim_stream_write_file.argtypes = [C.c_void_p, C.c_char_p]
     L.grim_stream_finish.restype = C.c_int
@@ -741,6 +743,7 @@ class Stream:
             o.n_masks = len(masks)
         names = (C.c_char_p * len(pops))(*[p.encode() for p in pops])
         self.line_offset = int(line_offset)
+        self._lent = []  # buffers lent to the stream (write(..., borrowed=True)): alive until close()
         self.h = L.grim_stream_open(ctx.h, dgraph.h, adict.h, C.byref(params), C.byref(ps), names, len(pops), C.byref(o))
         if not self.h:
             raise NativeError("grim_stream_open failed: " + ctx.error())
@@ -749,8 +752,16 @@ class Stream:
         if rc < 0:
             raise NativeError("grim_stream: " + host_lib().grim_stream_error(self.h).decode())
 
-    def write(self, data):
-        self._check(host_lib().grim_stream_write(self.h, data, len(data)))
+    def write(self, data, borrowed=False):
+        """feed bytes; `borrowed`: the stream reads them where they are (grim_stream_write_borrowed) -- this object keeps
+        `data` alive until finish() / close()"""
+        if borrowed:
+            if not isinstance(data, bytes):
+                raise TypeError("a borrowed buffer must be a bytes object")
+            self._lent.append(data)
+            self._check(host_lib().grim_stream_write_borrowed(self.h, data, len(data)))
+        else:
+            self._check(host_lib().grim_stream_write(self.h, data, len(data)))
 
     def write_text(self, data):
         """universal newlines, as Python's open(): "\r\n" and "\r" end a line too"""
@@ -827,6 +838,7 @@ class Stream:
         if self.h:
             host_lib().grim_stream_free(self.h)
             self.h = None
+        self._lent = []
 
     def __del__(self):
         try:

@@ -34,7 +34,7 @@ def _imp(gname, conf):
     return imp, cfg
 
 
-def _stream_texts(imp, cfg, lines, em_mr=False, ctx=None, **kw):
+def _stream_texts(imp, cfg, lines, em_mr=False, ctx=None, step=777, borrowed=False, **kw):
     """the six texts of `lines` through a stream opened with explicit options (chunk size, row pool, threads)"""
     from grim import _native as nat
 
@@ -45,9 +45,8 @@ def _stream_texts(imp, cfg, lines, em_mr=False, ctx=None, **kw):
     try:
         data = ("\n".join(lines) + "\n").encode() if lines else b""
         # feed in awkward pieces: lines straddle the calls
-        step = 777
         for a in range(0, len(data), step):
-            st.write(data[a:a + step])
+            st.write(data[a:a + step], borrowed=borrowed)
         st.finish()
         texts = {key: st.text(k) for k, key in enumerate(nat.TEXT_KEYS)}
         stats = st.stats()
@@ -369,3 +368,30 @@ def test_results_come_down_on_their_own_sdma_engine(monkeypatch):
     monkeypatch.delenv("GRIM_EXPORT", raising=False)
     for k in nat.TEXT_KEYS:
         assert base_small[k] == base_big[k], k
+
+
+def test_borrowed_input_equals_copied_input():
+    """grim_stream_write_borrowed: chunks that begin inside a lent buffer read their lines where they lie (the reader only
+    finds the line ends).  One big write, two writes cut in the middle of a line, and writes of 300 001 bytes (every one big
+    enough for views, every boundary inside a line, so that a chunk starts as a view and is completed from the next buffer)
+    must give the six texts of the copying path fed in 777-byte pieces -- ids, which the formatter reads from the chunk's
+    text, included."""
+    from grim import _native as nat
+
+    rows = synth.read_freqs(synth.CAU_FREQS)
+    gen = synth.SubjectGen(rows, 777)
+    lines = gen.full(30000) + gen.mixed(1500, amb=0.3, miss=0.3, recomb=0.2) + gen.full(2500)
+    conf = harness.base_conf(["CAU"])
+    imp, cfg = _imp("cau", conf)
+    n_bytes = sum(len(l) + 1 for l in lines)
+    assert n_bytes > 3000000
+    base, _, _ = _stream_texts(imp, cfg, lines, chunk_lines=4000, n_threads=4)
+    for step in (n_bytes, n_bytes // 2 + 13, 300001):
+        got, st, _ = _stream_texts(imp, cfg, lines, chunk_lines=4000, n_threads=4, step=step, borrowed=True)
+        assert st.lines == len(lines)
+        for k in nat.TEXT_KEYS:
+            assert got[k] == base[k], (step, k)
+    # the default chunk size (one chunk for everything) and a depth of two
+    got, _, _ = _stream_texts(imp, cfg, lines, n_threads=5, depth=2, step=n_bytes, borrowed=True)
+    for k in nat.TEXT_KEYS:
+        assert got[k] == base[k], k
