@@ -127,6 +127,7 @@ struct DevArgs {
 #define GRIM_NQ 24               // u32 words of `queue` (the run state block is counters + queue):
                                  // [13] bucket-start slots used [14] work units [15] units done by earlier launches of the run
                                  // [16] work counter of the mid-size kernel [17] its hand-overs to the general kernel
+                                 // [18] lines the device tokenizer handed back (GRIM_Q_IRREGULAR, grim_tokdev.h); [11] [19] [20] free
                                  // [12] items the workgroup split kernel took [21] the workgroup merge kernel [22] of those, with an
                                  // overflowed bucket [23] their largest pair count  (diagnostics, GRIM_DEBUG_CLASSES=1)
                                  // (the table kernels' own work counters are DevArgs.wctr)
