@@ -531,7 +531,8 @@ class Imputation(object):
             if in_path is not None:
                 st.write_file(in_path)
             elif data:
-                st.write(data)
+                # the lines are in memory and stay there until the stream is closed: lent, not copied (grim_stream_write_borrowed)
+                st.write(data, borrowed=isinstance(data, bytes))
             st.finish()
             stats = st.stats()
             self.last_stats = {
