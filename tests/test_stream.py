@@ -395,3 +395,35 @@ def test_borrowed_input_equals_copied_input():
     got, _, _ = _stream_texts(imp, cfg, lines, n_threads=5, depth=2, step=n_bytes, borrowed=True)
     for k in nat.TEXT_KEYS:
         assert got[k] == base[k], k
+
+
+def test_big_input_files_with_every_line_end(tmp_path, monkeypatch):
+    """grim_stream_write_file on files of 4.5 MB (several 8 MB read blocks would be more; several chunks are): the same 40 000
+    lines with '\\n' ends and no final newline, with '\\r\\n' ends throughout, and with '\\n' ends but '\\r\\n' in the last tenth
+    and a lone '\\r' at the very end -- each against impute_lines on the same lines.  (Written for a variant of write_file that
+    mapped the file and lent the mapping to the stream until the first '\\r': correct, no faster -- file -> file is bound by
+    formatting and writing -- and dropped; the test stays.)"""
+    rows = synth.read_freqs(synth.CAU_FREQS)
+    gen = synth.SubjectGen(rows, 91)
+    lines = gen.full(36000) + gen.mixed(4000, amb=0.3, miss=0.3, recomb=0.2)
+    conf = harness.base_conf(["CAU"])
+    imp, cfg = _imp("cau", conf)
+    ref = imp.impute_lines(lines, cfg)
+    n = len(lines)
+    variants = {
+        "lf": "\n".join(lines).encode(),
+        "crlf": "\r\n".join(lines).encode() + b"\r\n",
+        "late_cr": "\n".join(lines[:n - n // 10]).encode() + b"\n" + "\r\n".join(lines[n - n // 10:]).encode() + b"\r",
+    }
+    for name, data in variants.items():
+        assert len(data) > (4 << 20)
+        p = tmp_path / (name + ".csv")
+        p.write_bytes(data)
+        cfg2 = dict(cfg)
+        cfg2["imputation_input_file"] = str(p)
+        for key, path_key, flag in imp._OUT_FILES:
+            cfg2[path_key] = str(tmp_path / (name + "_" + key + ".txt"))
+        monkeypatch.setenv("GRIM_CHUNK_LINES", "6000")  # several chunks, most of them views
+        imp.impute_file(cfg2)
+        for key, path_key, flag in imp._OUT_FILES:
+            assert open(cfg2[path_key]).read() == ref[key], (name, key)
