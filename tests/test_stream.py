@@ -337,7 +337,7 @@ def test_one_big_write_whose_pieces_divide_evenly():
 def test_results_come_down_on_their_own_sdma_engine(monkeypatch):
     """A stream's results leave HBM on an SDMA engine the library names itself (csrc/grim_sdma.h: ROCr's
     hsa_amd_memory_async_copy_on_engine; the HIP runtime would put uploads and downloads on engine 0 both).  The default
-    context of an MI355X box must have got one (a bit > 1: not the uploads' engine), and the two other ways down -- the copy
+    context of an MI355X box gets one (a bit > 1: not the uploads' engine), and the two other ways down -- the copy
     kernel of round 3 (GRIM_EXPORT=kernel) and hipMemcpyAsync (GRIM_EXPORT=memcpy) -- must give the same six files, small
     chunks and one big chunk, and the same records."""
     from grim import _native as nat
