@@ -399,6 +399,19 @@ def test_borrowed_input_equals_copied_input():
     got, _, _ = _stream_texts(imp, cfg, lines, n_threads=5, depth=2, step=n_bytes, borrowed=True)
     for k in nat.TEXT_KEYS:
         assert got[k] == base[k], k
+    # a four-population graph: every line is tokenised by the HOST's threads, straight from the lent buffer
+    pops = harness.POPS["pop4"]
+    lines4 = synth.SubjectGen(rows, 5, pops=pops).mixed(4000)
+    conf4 = harness.base_conf(pops)
+    conf4["UNK_priors"] = "MR"
+    imp4, cfg4 = _imp("pop4", conf4)
+    n4 = sum(len(l) + 1 for l in lines4)
+    assert n4 > 400000
+    base4, _, _ = _stream_texts(imp4, cfg4, lines4, chunk_lines=1000, n_threads=4)
+    for step in (n4, n4 // 2 + 7):
+        got4, _, _ = _stream_texts(imp4, cfg4, lines4, chunk_lines=1000, n_threads=4, step=step, borrowed=True)
+        for k in nat.TEXT_KEYS:
+            assert got4[k] == base4[k], (step, k)
 
 
 def test_big_input_files_with_every_line_end(tmp_path, monkeypatch):
